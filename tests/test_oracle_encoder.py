@@ -1,0 +1,65 @@
+"""Oracle E (oracle/zso_encoder.c, the scalar statement of this repo's block encoder):
+every frame must decode bit-exactly under oracle D (the restated reference decoder) and under
+upstream libzstd; ratio must stay within the stated tolerance of libzstd level 3.  CPU only."""
+import numpy as np
+import pytest
+import _oracle as O
+import _data as D
+
+INPUTS = D.mixed_inputs()
+
+
+@pytest.mark.parametrize("level", [1, 3])
+@pytest.mark.parametrize("name", sorted(INPUTS.keys()))
+def test_roundtrip(name, level):
+    data = INPUTS[name]
+    frame = O.compress(data, level)
+    assert len(frame) <= O.lib().zso_compressBound(len(data))
+    assert O.lib().zso_getDecompressedSize(frame, len(frame)) == len(data)
+    assert O.decompress(frame, len(data)) == data
+    if O.libzstd():
+        assert O.zstd_decompress(frame, len(data)) == data
+
+
+def test_fixture_contents_roundtrip():
+    for name, (_, data) in D.fixtures().items():
+        for cs in (65536, 131072):
+            for i in range(0, max(len(data), 1), cs):
+                c = data[i:i + cs]
+                f = O.compress(c, 3)
+                assert O.decompress(f, len(c)) == c, name
+
+
+def test_constructs_emitted():
+    """what the encoder's frames exercise in the decoder"""
+    tot = np.zeros(32, dtype=np.uint64)
+    for name, data in INPUTS.items():
+        f = O.compress(data, 3)
+        _, st = O.decode_stats(f, len(data))
+        tot += st
+    for k in (0, 2, 4, 5, 6, 7, 8, 9, 10, 12, 13, 14, 16, 17, 18, 20, 21, 22, 26, 28, 29):
+        assert tot[k] > 0, k
+
+
+@pytest.mark.skipif(not O.libzstd(), reason="libzstd not present")
+def test_ratio_vs_libzstd_level3():
+    """north_star tolerance: within 1 % of libzstd level 3 on 64 KiB chunks of the Zipf log stream"""
+    data = D.zipf_log(2 << 20)
+    cs = 65536
+    e = z = 0
+    for i in range(0, len(data), cs):
+        c = data[i:i + cs].tobytes()
+        e += len(O.compress(c, 3))
+        z += len(O.zstd_compress(c, 3))
+    assert e <= z * 1.01, (e, z)
+
+
+def test_batch_threads_agree():
+    data = D.zipf_log(1 << 20)
+    off = np.arange(0, len(data), 65536, dtype=np.uint64)
+    sz = np.full(len(off), 65536, dtype=np.uint32)
+    a1, o1, s1 = O.compress_batch(data, off, sz, 3, 1)
+    a4, o4, s4 = O.compress_batch(data, off, sz, 3, 4)
+    assert (s1 == s4).all()
+    for i in range(len(off)):
+        assert (a1[int(o1[i]):int(o1[i]) + int(s1[i])] == a4[int(o4[i]):int(o4[i]) + int(s4[i])]).all()
