@@ -24,9 +24,9 @@
  *  2. parse: each range is walked greedily and independently: next position with a
  *     candidate (or a 4-byte match at the previous offset), forward extension to the
  *     range end, one sequence per match.
- *  3. ranges are concatenated (touching matches with equal offset are merged), offsets
- *     become repcodes through a 3-entry most-recently-used list (inverse of
- *     ZStdDecompress.cs:1509-1530).
+ *  3. ranges are concatenated (a range's trailing literals go to the next range's first
+ *     sequence), offsets become repcodes through the decoder's 3-entry recent-offset list
+ *     (inverse of ZStdDecompress.cs:1509-1530).
  *  4. literals: histogram, length-limited (11 bit) Huffman by package-merge, weights
  *     written direct or FSE-compressed (inverse of EntropyCommon.cs:198-269 and
  *     HufDecompress.cs:117-180), 1 or 4 streams (inverse of HufDecompress.cs:247-358).
@@ -606,7 +606,7 @@ static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32
     if (n < 16) return 0;
     findCandidates(w, src, n, prm);
     {
-        /* stage 2 + 3a: walk ranges, concatenate, merge touching equal-offset matches */
+        /* stage 2 + 3a: walk ranges, concatenate */
         U32 carry = 0, pos = 0;
         static __thread Seq rangeSeq[RANGE_SIZE / 3 + 8];
         for (r = 0; r < nRanges; r++) {
@@ -617,8 +617,7 @@ static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32
             for (k = 0; k < ns; k++) {
                 Seq s = rangeSeq[k];
                 if (k == 0) s.litLength += carry;
-                if (s.litLength == 0 && nseq && w->seqs[nseq - 1].offset == s.offset) { w->seqs[nseq - 1].matchLength += s.matchLength; }
-                else { memcpy(w->lits + nlit, src + pos, s.litLength); nlit += s.litLength; w->seqs[nseq++] = s; }
+                memcpy(w->lits + nlit, src + pos, s.litLength); nlit += s.litLength; w->seqs[nseq++] = s;
                 pos += s.litLength + s.matchLength;
             }
             carry = ns ? trailing : carry + trailing;
@@ -665,7 +664,7 @@ static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32
         if (nseq < 128) *op++ = (BYTE)nseq;
         else if (nseq < 0x7F00) { op[0] = (BYTE)((nseq >> 8) + 0x80); op[1] = (BYTE)nseq; op += 2; }
         else { op[0] = 0xFF; wr16(op + 1, nseq - 0x7F00); op += 3; }
-        if (nseq == 0) return (size_t)(op - dst) < n ? (size_t)(op - dst) : 0;
+        if (nseq == 0) return (size_t)(op - dst);
         {
             BYTE *const modes = op++;
             CTable ctLL, ctOF, ctML;
@@ -738,7 +737,7 @@ static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32
                 op += s;
             }
         }
-        { size_t const total = (size_t)(op - dst); return (total < n) ? total : 0; }
+        return (size_t)(op - dst);
     }
 }
 
@@ -781,8 +780,10 @@ size_t zso_compress(void *dstv, size_t dstCapacity, const void *srcv, size_t src
         if (same && n > 0) {                                        /* RLE block (ZStdDecompress.cs:1945-1950) */
             wr24(op, (U32)last + (1u << 1) + (n << 3)); op[3] = src[pos]; op += 4;
         } else {
-            if (n) csize = compressBlock(w, op + 3, (size_t)(oend - op) - 3 < n ? (size_t)(oend - op) - 3 : n, src + pos, n, &prm, pos == 0);
-            if (csize) { wr24(op, (U32)last + (2u << 1) + ((U32)csize << 3)); op += 3 + csize; }
+            /* the payload is built in scratch of n + 512 bytes; it is used iff it is smaller than n
+             * (anything that would not fit the scratch is larger than n anyway) */
+            if (n) csize = compressBlock(w, w->tmp, n + 512, src + pos, n, &prm, pos == 0);
+            if (csize && csize < n && (size_t)(oend - op) >= 3 + csize) { wr24(op, (U32)last + (2u << 1) + ((U32)csize << 3)); memcpy(op + 3, w->tmp, csize); op += 3 + csize; }
             else {                                                   /* raw block (ZStdDecompress.cs:662-667) */
                 if ((size_t)(oend - op) < 3 + (size_t)n) return ERR(ZSO_dstSize_tooSmall);
                 wr24(op, (U32)last + (0u << 1) + (n << 3)); memcpy(op + 3, src + pos, n); op += 3 + n;
@@ -791,4 +792,38 @@ size_t zso_compress(void *dstv, size_t dstCapacity, const void *srcv, size_t src
         pos += n;
     } while (pos < srcSize);
     return (size_t)(op - dst);
+}
+
+/* ---- test hooks: intermediate results of stages 1 and 2 for one block (n <= 65536), so the HIP
+ *      kernels can be checked stage by stage ---- */
+int zso_debugCandidates(uint16_t *distOut, const void *src, uint32_t n, int level)
+{
+    EParams const prm = paramsForLevel(level);
+    Work *w = (Work *)malloc(sizeof(Work));
+    if (!w || n > BLOCK_MAX) { free(w); return -1; }
+    findCandidates(w, (const BYTE *)src, n, &prm);
+    memcpy(distOut, w->dist, n * sizeof(U16));
+    free(w);
+    return 0;
+}
+/* seqOut: per range r, up to 2048 triples (litLength, matchLength, offset) at seqOut[(r*2048 + k)*3];
+ * hdrOut[r*2] = number of sequences, hdrOut[r*2+1] = trailing literals of the range */
+int zso_debugWalk(uint32_t *seqOut, uint32_t *hdrOut, const void *src, uint32_t n, int level)
+{
+    EParams const prm = paramsForLevel(level);
+    Work *w = (Work *)malloc(sizeof(Work));
+    Seq *tmp = (Seq *)malloc(sizeof(Seq) * (RANGE_SIZE / 3 + 8));
+    U32 r, nRanges = (n + RANGE_SIZE - 1) >> RANGE_LOG;
+    if (!w || !tmp || n > BLOCK_MAX) { free(w); free(tmp); return -1; }
+    findCandidates(w, (const BYTE *)src, n, &prm);
+    for (r = 0; r < nRanges; r++) {
+        U32 const start = r << RANGE_LOG;
+        U32 const end = (start + RANGE_SIZE < n) ? start + RANGE_SIZE : n;
+        U32 trailing, k;
+        U32 const ns = walkRange(w, (const BYTE *)src, n, start, end, &prm, tmp, &trailing);
+        hdrOut[r * 2] = ns; hdrOut[r * 2 + 1] = trailing;
+        for (k = 0; k < ns; k++) { seqOut[(r * 2048 + k) * 3] = tmp[k].litLength; seqOut[(r * 2048 + k) * 3 + 1] = tmp[k].matchLength; seqOut[(r * 2048 + k) * 3 + 2] = tmp[k].offset; }
+    }
+    free(w); free(tmp);
+    return 0;
 }

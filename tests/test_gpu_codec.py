@@ -1,0 +1,177 @@
+"""Parity tests proper: the HIP codec (through the C ABI of libzsmi.so) against the CPU oracle.
+ - decode: k_decode_frames vs oracle D on the reference's golden vectors, the libzstd fixtures and damaged frames
+ - encode: HIP frames must (a) decode bit-exactly under oracle D (the restated reference decoder),
+           (b) be byte-identical to oracle E (the scalar statement of the same algorithm),
+           (c) decode under upstream libzstd when present, (d) keep the stated ratio tolerance.
+Run with -m gpu on an MI355X."""
+import ctypes, os
+import numpy as np
+import pytest
+import _oracle as O
+import _data as D
+
+pytestmark = pytest.mark.gpu
+
+ERR = 0xFFFFFF88
+
+
+@pytest.fixture(scope="module")
+def codec():
+    from zstandard_amd import BatchCodec
+    bc = BatchCodec()
+    yield bc
+    bc.close()
+
+
+def _u8(b):
+    return np.frombuffer(b, dtype=np.uint8) if len(b) else np.zeros(1, dtype=np.uint8)
+
+
+def _compress_many(codec, chunks, level=3):
+    src = np.concatenate([_u8(c)[:len(c)] for c in chunks] + [np.zeros(1, np.uint8)])
+    sizes = np.array([len(c) for c in chunks], dtype=np.uint32)
+    offs = np.zeros(len(chunks), dtype=np.uint64); offs[1:] = np.cumsum(sizes.astype(np.uint64))[:-1]
+    arena, do, dsz = codec.compress_host(src, offs, sizes, level)
+    out = []
+    for i in range(len(chunks)):
+        assert dsz[i] < ERR, (i, hex(int(dsz[i])))
+        out.append(arena[int(do[i]):int(do[i]) + int(dsz[i])].tobytes())
+    return out
+
+
+def _decompress_many(codec, frames, caps):
+    src = np.concatenate([_u8(f)[:len(f)] for f in frames] + [np.zeros(1, np.uint8)])
+    sizes = np.array([len(f) for f in frames], dtype=np.uint32)
+    offs = np.zeros(len(frames), dtype=np.uint64); offs[1:] = np.cumsum(sizes.astype(np.uint64))[:-1]
+    arena, do, dsz = codec.decompress_host(src, offs, sizes, np.array(caps, dtype=np.uint32))
+    return [(int(dsz[i]), arena[int(do[i]):int(do[i]) + (int(dsz[i]) if dsz[i] < ERR else 0)].tobytes()) for i in range(len(frames))]
+
+
+# ------------------------------------------------------------------ decode
+def test_decode_reference_golden_vectors(codec):
+    """csharp/test/TestDecompress.cs:53-99 and java/.../TestDecompress.java:6-20 through the HIP decoder"""
+    from zstandard_amd import ZStdDecompress, ZstdDecompressor
+    for n in ("csharp_alphabet", "java_a2z"):
+        frame = open(os.path.join(D.GOLDEN, n + ".zst"), "rb").read()
+        want = open(os.path.join(D.GOLDEN, n + ".bin"), "rb").read()
+        size = ZStdDecompress.GetDecompressedSize(frame)
+        assert size == len(want)
+        dst = bytearray(size)
+        r = ZStdDecompress.Decompress(dst, frame)
+        assert r == len(want) and bytes(dst) == want
+        out = bytearray(size)
+        assert ZstdDecompressor().decompress(frame, 0, len(frame), out, 0, size) == size and bytes(out) == want
+        assert ZstdDecompressor.getDecompressedSize(frame, 0, len(frame)) == size
+
+
+def test_decode_libzstd_fixtures(codec):
+    fx = D.fixtures()
+    names = sorted(fx)
+    res = _decompress_many(codec, [fx[k][0] for k in names], [max(len(fx[k][1]), 1) for k in names])
+    for k, (sz, got) in zip(names, res):
+        assert sz == len(fx[k][1]), (k, hex(sz))
+        assert got == fx[k][1], k
+
+
+def test_decode_errors_match_oracle(codec):
+    """damaged frames: the HIP decoder reports an error wherever oracle D does, with the same code for the
+    frame-level checks (magic, reserved bit, checksum, capacity, trailing bytes)"""
+    frame, want = D.fixtures()["text64k_l3"]
+    ck, ckw = D.fixtures()["one_byte"]
+    bad_ck = bytearray(ck); bad_ck[-1] ^= 0xFF
+    res_bit = bytearray(frame); res_bit[4] |= 0x08
+    cases = [(frame, len(want) - 1, 70), (b"\x00" * 16, 16, 10), (frame + b"\x01", len(want), 72),
+             (bytes(bad_ck), 1, 22), (bytes(res_bit), len(want), 14), (frame[:-5], len(want), None), (frame[:200], len(want), None)]
+    cs = open(os.path.join(D.GOLDEN, "csharp_alphabet.zst"), "rb").read()
+    for pos in (20, 100, 200, 300, 470):
+        b = bytearray(cs); b[pos] ^= 0x55
+        cases.append((bytes(b), 3409, None))
+    res = _decompress_many(codec, [c[0] for c in cases], [max(c[1], 1) for c in cases])
+    for (fr, cap, code), (sz, _) in zip(cases, res):
+        assert sz > ERR, "must be an error"
+        try:
+            O.decompress(fr, cap); oracle_code = 0
+        except O.OracleError as e:
+            oracle_code = e.code
+        assert oracle_code != 0
+        if code is not None:
+            assert (0x100000000 - sz) == code == oracle_code
+
+
+def test_decode_truncations(codec):
+    frame, want = D.fixtures()["small_text_l3"]
+    frames = [frame[:c] for c in range(1, len(frame))]
+    res = _decompress_many(codec, frames, [len(want)] * len(frames))
+    for c, (sz, _) in enumerate(res, start=1):
+        assert sz > ERR, c
+
+
+# ------------------------------------------------------------------ encode
+INPUTS = D.mixed_inputs()
+
+
+@pytest.mark.parametrize("level", [1, 3])
+def test_encode_roundtrip_and_bit_exact_vs_oracle(codec, level):
+    names = sorted(INPUTS)
+    frames = _compress_many(codec, [INPUTS[k] for k in names], level)
+    for k, f in zip(names, frames):
+        data = INPUTS[k]
+        assert O.lib().zso_getDecompressedSize(f, len(f)) == len(data), k
+        assert O.decompress(f, len(data)) == data, k                      # reference decoder semantics accept it, bit-exact
+        assert f == O.compress(data, level), k                            # same bytes as the scalar statement
+        if O.libzstd():
+            assert O.zstd_decompress(f, len(data)) == data, k
+    # and through this codec's own decoder
+    res = _decompress_many(codec, frames, [max(len(INPUTS[k]), 1) for k in names])
+    for k, (sz, got) in zip(names, res):
+        assert sz == len(INPUTS[k]) and got == INPUTS[k], k
+
+
+def test_encode_one_shot_api(codec):
+    from zstandard_amd import ZstdCompressor, ZStdDecompress
+    data = INPUTS["log_200001"]
+    f = ZstdCompressor(3).compress(data)
+    assert f == O.compress(data, 3)
+    dst = bytearray(len(data))
+    assert ZStdDecompress.Decompress(dst, f) == len(data) and bytes(dst) == data
+    small = bytearray(10)
+    assert ZStdDecompress.IsError(ZStdDecompress.Decompress(small, f))
+
+
+def test_encode_batch_64k_chunks_log(codec):
+    """headline shape: 64 KiB chunks of the Zipf log stream; bit-exact vs oracle E; ratio within 1 % of libzstd L3"""
+    data = D.zipf_log(8 << 20)
+    cs = 65536
+    n = len(data) // cs
+    offs = np.arange(n, dtype=np.uint64) * cs
+    sizes = np.full(n, cs, dtype=np.uint32)
+    arena, do, dsz = codec.compress_host(data, offs, sizes, 3)
+    assert (dsz < ERR).all()
+    ea, eo, es = O.compress_batch(data, offs, sizes, 3, 8)
+    assert (dsz == es).all()
+    for i in range(n):
+        assert (arena[int(do[i]):int(do[i]) + int(dsz[i])] == ea[int(eo[i]):int(eo[i]) + int(es[i])]).all(), i
+    # decode all with this codec and compare with the input
+    frames = np.concatenate([arena[int(do[i]):int(do[i]) + int(dsz[i])] for i in range(n)])
+    fo = np.zeros(n, dtype=np.uint64); fo[1:] = np.cumsum(dsz.astype(np.uint64))[:-1]
+    out, oo, osz = codec.decompress_host(frames, fo, dsz, sizes)
+    assert (osz == cs).all()
+    assert (out[:n * cs] == data[:n * cs]).all()
+    if O.libzstd():
+        z = sum(len(O.zstd_compress(data[i * cs:(i + 1) * cs].tobytes(), 3)) for i in range(0, n, 4))
+        e = int(dsz[::4].sum())
+        assert e <= z * 1.01, (e, z)
+
+
+def test_encode_128k_chunks_and_ragged(codec):
+    data = D.zipf_log(3 << 20, seed_lo=77)
+    rng = np.random.default_rng(5)
+    sizes = np.concatenate([np.full(8, 131072), rng.integers(0, 200000, 12)]).astype(np.uint32)
+    offs = np.zeros(len(sizes), dtype=np.uint64); offs[1:] = np.cumsum(sizes.astype(np.uint64))[:-1]
+    assert int(offs[-1]) + int(sizes[-1]) <= len(data)
+    arena, do, dsz = codec.compress_host(data, offs, sizes, 3)
+    for i in range(len(sizes)):
+        f = arena[int(do[i]):int(do[i]) + int(dsz[i])].tobytes()
+        c = data[int(offs[i]):int(offs[i]) + int(sizes[i])].tobytes()
+        assert O.decompress(f, len(c)) == c
+        assert f == O.compress(c, 3)

@@ -1,0 +1,66 @@
+#!/usr/bin/env python3
+"""Stage-by-stage comparison of the HIP encoder with oracle E on a few inputs (development aid, GPU box)."""
+import sys, os, ctypes
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _oracle as O, _data as D
+from zstandard_amd import BatchCodec, _lib
+
+def main():
+    names = sys.argv[1:] or ["log_65536", "log_1000", "zeros_65536", "rand_70000", "alphabet", "log_200001", "records", "sixbit_2000", "empty", "one", "skewed"]
+    inputs = D.mixed_inputs()
+    bc = BatchCodec()
+    L = O.lib(); Z = _lib.lib()
+    L.zso_debugCandidates.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]
+    L.zso_debugWalk.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int]
+    for name in names:
+        data = inputs[name]
+        src = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+        arena, do, dsz = bc.compress_host(src, [0], [len(data)], 3)
+        frame = arena[:int(dsz[0])].tobytes() if dsz[0] < 0xFFFFFF88 else None
+        ref = O.compress(data, 3)
+        ok_rt = None
+        if frame is not None:
+            try:
+                ok_rt = O.decompress(frame, len(data)) == data
+            except O.OracleError as e:
+                ok_rt = f"oracle error {e.code}"
+        print(f"{name:14s} n={len(data):7d} gpu={dsz[0]:10d} E={len(ref):7d} same={frame == ref} roundtrip={ok_rt}")
+        if frame != ref and len(data) >= 16:
+            n0 = min(len(data), 65536)
+            blk = data[:n0]
+            dist_e = np.zeros(n0, dtype=np.uint16); L.zso_debugCandidates(dist_e.ctypes.data_as(ctypes.c_void_p), blk, n0, 3)
+            dist_g = np.zeros(65536, dtype=np.uint16); Z.zsmi_dbg_copyScratch(bc.ctx, 0, dist_g.ctypes.data_as(ctypes.c_void_p), 65536 * 2)
+            bad = np.nonzero(dist_e != dist_g[:n0])[0]
+            print(f"   dist mismatches (block 0): {len(bad)}", bad[:8], dist_e[bad[:8]], dist_g[bad[:8]])
+            seq_e = np.zeros(8 * 2048 * 3, dtype=np.uint32); hdr_e = np.zeros(16, dtype=np.uint32)
+            L.zso_debugWalk(seq_e.ctypes.data_as(ctypes.c_void_p), hdr_e.ctypes.data_as(ctypes.c_void_p), blk, n0, 3)
+            hdr_g = np.zeros(16, dtype=np.uint32); Z.zsmi_dbg_copyScratch(bc.ctx, 2, hdr_g.ctypes.data_as(ctypes.c_void_p), 64)
+            seq_g = np.zeros(8 * 2048 * 4, dtype=np.uint16); Z.zsmi_dbg_copyScratch(bc.ctx, 1, seq_g.ctypes.data_as(ctypes.c_void_p), 8 * 2048 * 8)
+            print("   hdr E", hdr_e.tolist()); print("   hdr G", hdr_g.tolist())
+            se = seq_e.reshape(8, 2048, 3); sg = seq_g.reshape(8, 2048, 4)
+            for r in range(8):
+                ns = min(hdr_e[2 * r], hdr_g[2 * r])
+                g3 = np.stack([sg[r, :ns, 0], sg[r, :ns, 1] & 0x3FFF, sg[r, :ns, 2]], axis=1).astype(np.uint32)
+                d = np.nonzero((se[r, :ns] != g3).any(axis=1))[0]
+                if len(d):
+                    k = d[0]; print(f"   range {r}: first seq mismatch at {k}: E={se[r, k].tolist()} G={sg[r, k].tolist()}"); break
+            if frame is not None:
+                m = next((i for i in range(min(len(frame), len(ref))) if frame[i] != ref[i]), None)
+                print("   first byte diff at", m, "gpu", frame[max(0,(m or 0)-4):(m or 0)+12].hex(), "E", ref[max(0,(m or 0)-4):(m or 0)+12].hex())
+    # decode check
+    fx = D.fixtures()
+    for name in ["text64k_l3", "small_text_l3", "tiny_l3", "zeros_1m", "random_200k", "multi_skippable", "one_byte", "text300k_l19"]:
+        frame, want = fx[name]
+        src = np.frombuffer(frame, dtype=np.uint8)
+        arena, do, dsz = bc.decompress_host(src, [0], [len(frame)], [max(len(want), 1)])
+        got = arena[:int(dsz[0])].tobytes() if dsz[0] < 0xFFFFFF88 else None
+        print(f"decode {name:18s} size={dsz[0]:10d} want={len(want)} ok={got == want}")
+    for n in ("csharp_alphabet", "java_a2z"):
+        frame = open(os.path.join(D.GOLDEN, n + ".zst"), "rb").read(); want = open(os.path.join(D.GOLDEN, n + ".bin"), "rb").read()
+        arena, do, dsz = bc.decompress_host(np.frombuffer(frame, dtype=np.uint8), [0], [len(frame)], [len(want)])
+        print(f"decode golden {n}: size={dsz[0]} ok={arena[:int(dsz[0])].tobytes() == want}")
+
+if __name__ == "__main__":
+    main()

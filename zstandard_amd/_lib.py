@@ -1,0 +1,62 @@
+"""Loads libzsmi.so (HIP kernels + C ABI).  The library is built in-tree by __graft_entry__.build()
+(hipcc --offload-arch=gfx950).  There is no fallback: if the library is missing the import fails."""
+import ctypes, os, subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libzsmi.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+
+def build(force=False):
+    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "zsmi.h")]
+    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+        return LIB_PATH
+    os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH, os.path.join(CSRC, "zsmi_api.hip")]
+    subprocess.check_call(cmd)
+    return LIB_PATH
+
+
+_lib = None
+
+
+class KernelTime(ctypes.Structure):
+    _fields_ = [("name", ctypes.c_char * 48), ("seconds", ctypes.c_double), ("launches", ctypes.c_uint32)]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(f"{LIB_PATH} is missing: run __graft_entry__.build() (hipcc --offload-arch=gfx950); there is no CPU fallback")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, sz, u32, i32 = ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32, ctypes.c_int
+    L.zsmi_isError.restype = ctypes.c_uint; L.zsmi_isError.argtypes = [sz]
+    L.zsmi_getErrorCode.restype = ctypes.c_uint; L.zsmi_getErrorCode.argtypes = [sz]
+    L.zsmi_getErrorName.restype = ctypes.c_char_p; L.zsmi_getErrorName.argtypes = [sz]
+    L.zsmi_versionString.restype = ctypes.c_char_p
+    L.zsmi_compressBound.restype = sz; L.zsmi_compressBound.argtypes = [sz]
+    L.zsmi_getDecompressedSize.restype = ctypes.c_ulonglong; L.zsmi_getDecompressedSize.argtypes = [vp, sz]
+    L.zsmi_compress.restype = sz; L.zsmi_compress.argtypes = [vp, sz, vp, sz, i32]
+    L.zsmi_decompress.restype = sz; L.zsmi_decompress.argtypes = [vp, sz, vp, sz]
+    L.zsmi_createCtx.restype = vp; L.zsmi_createCtx.argtypes = [i32, vp]
+    L.zsmi_freeCtx.restype = None; L.zsmi_freeCtx.argtypes = [vp]
+    L.zsmi_sync.restype = i32; L.zsmi_sync.argtypes = [vp]
+    L.zsmi_compressBatchDevice.restype = i32; L.zsmi_compressBatchDevice.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, i32]
+    L.zsmi_decompressBatchDevice.restype = i32; L.zsmi_decompressBatchDevice.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
+    L.zsmi_compressBatchHost.restype = i32; L.zsmi_compressBatchHost.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, i32]
+    L.zsmi_decompressBatchHost.restype = i32; L.zsmi_decompressBatchHost.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
+    L.zsmi_packFramesDevice.restype = i32; L.zsmi_packFramesDevice.argtypes = [vp, vp, vp, vp, u32, vp, vp]
+    L.zsmi_enableKernelTiming.restype = i32; L.zsmi_enableKernelTiming.argtypes = [vp, i32]
+    L.zsmi_getKernelTimes.restype = i32; L.zsmi_getKernelTimes.argtypes = [vp, ctypes.POINTER(KernelTime), i32]
+    L.zsmi_dbg_copyScratch.restype = i32; L.zsmi_dbg_copyScratch.argtypes = [vp, i32, vp, sz]
+    _lib = L
+    return L
+
+
+EXPORTS = ["zsmi_isError", "zsmi_getErrorName", "zsmi_getErrorCode", "zsmi_decompress", "zsmi_getDecompressedSize",
+           "zsmi_compress", "zsmi_compressBound", "zsmi_createCtx", "zsmi_freeCtx", "zsmi_sync",
+           "zsmi_compressBatchDevice", "zsmi_decompressBatchDevice", "zsmi_compressBatchHost", "zsmi_decompressBatchHost",
+           "zsmi_packFramesDevice", "zsmi_enableKernelTiming", "zsmi_getKernelTimes", "zsmi_versionString"]

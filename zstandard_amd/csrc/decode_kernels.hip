@@ -1,0 +1,597 @@
+// Batch decoder: k_decode_frames, one wavefront per input item (one or more concatenated frames).
+// Follows the reference decoder function by function (csharp/src/ZStdDecompress.cs and friends);
+// the C restatement used as the checker is oracle/zso_decoder.c.  Same error codes
+// (csharp/src/ZStdErrors.cs:61-90).
+//
+//   frame / block layer   DecompressMultiFrame :2096-2160, DecompressFrame :2008-2091, GetcBlockSize :646-659
+//   frame header          ZSTD_getFrameHeader_advanced :421-499
+//   literals              DecodeLiteralsBlock :683-821, HufDecompress.cs:117-358, EntropyCommon.cs:198-269
+//   sequence tables       DecodeSeqHeaders :1110-1180, BuildFSETable :958-1034, ReadNCount EntropyCommon.cs:79-188
+//   sequences             DecodeSequence :1473-1553, ExecSequence :1265-1352, body :1555-1608
+//   checksum              XxHash.cs (XXH64 seed 0, low 32 bits) :2076-2085
+//
+// Work split inside the wavefront: headers and FSE/Huffman table parsing on lane 0 (small, serial),
+// Huffman streams on lanes 0..3 (one stream each), sequence decoding on lane 0 in tiles of 64,
+// literal and match copies by all 64 lanes.
+#include "zsmi_device.h"
+
+#define ZE(code) (0u - (uint32_t)(code))
+#define E_GENERIC 1
+#define E_prefix_unknown 10
+#define E_frameParameter_unsupported 14
+#define E_frameParameter_windowTooLarge 16
+#define E_corruption_detected 20
+#define E_checksum_wrong 22
+#define E_dictionary_corrupted 30
+#define E_dictionary_wrong 32
+#define E_tableLog_tooLarge 44
+#define E_dstSize_tooSmall 70
+#define E_srcSize_wrong 72
+__device__ __forceinline__ bool isErr(uint32_t v) { return v > ZE(120); }
+
+struct ZsDecItem { uint64_t srcOff; uint64_t dstOff; uint32_t srcSize; uint32_t dstCap; };
+
+__constant__ uint8_t d_LL_bits[36] = { 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0, 1,1,1,1,2,2,3,3, 4,6,7,8,9,10,11,12, 13,14,15,16 };
+__constant__ uint8_t d_ML_bits[53] = { 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0,
+                                      1,1,1,1,2,2,3,3, 4,4,5,7,8,9,10,11, 12,13,14,15,16 };
+__constant__ uint32_t d_LL_base[36] = { 0,1,2,3,4,5,6,7, 8,9,10,11,12,13,14,15, 16,18,20,22,24,28,32,40,
+                                       48,64,0x80,0x100,0x200,0x400,0x800,0x1000, 0x2000,0x4000,0x8000,0x10000 };
+__constant__ uint32_t d_ML_base[53] = { 3,4,5,6,7,8,9,10, 11,12,13,14,15,16,17,18, 19,20,21,22,23,24,25,26,
+                                       27,28,29,30,31,32,33,34, 35,37,39,41,43,47,51,59, 67,83,99,0x83,0x103,0x203,0x403,0x803,
+                                       0x1003,0x2003,0x4003,0x8003,0x10003 };
+__constant__ int16_t d_LL_defaultNorm[36] = { 4,3,2,2,2,2,2,2, 2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
+__constant__ int16_t d_ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,
+                                             1,1,1,1,1,1,1,1, 1,1,1,1,1,1,-1,-1, -1,-1,-1,-1,-1 };
+__constant__ int16_t d_OF_defaultNorm[29] = { 1,1,1,1,1,1,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, -1,-1,-1,-1,-1 };
+
+struct SeqSym { uint16_t nextState; uint8_t nbAdd; uint8_t nbBits; uint32_t base; };   // ZStdDecompress.cs:132-146
+struct SeqTab { uint32_t tableLog; SeqSym cells[512]; };
+struct DLds {
+    uint16_t huf[4096];                 // byte | nbBits << 8   (HufDecompress.cs:109-113)
+    uint32_t hufLog;
+    SeqTab LL, ML;
+    struct { uint32_t tableLog; SeqSym cells[256]; } OF;
+    uint8_t weights[256];
+    uint16_t symStart[256];
+    uint32_t rank[16];
+    int16_t norm[64];
+    uint16_t symbolNext[64];
+    uint32_t tileLL[64], tileML[64], tileOff[64];
+    uint32_t misc[16];
+    struct { uint16_t newState; uint8_t symbol; uint8_t nbBits; } wfse[64];   // weight FSE table (tableLog <= 6)
+};
+
+__device__ __forceinline__ uint32_t rd16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
+__device__ __forceinline__ uint32_t rd24(const uint8_t *p) { return rd16(p) | ((uint32_t)p[2] << 16); }
+__device__ __forceinline__ uint32_t rd32(const uint8_t *p) { return zs_load32(p); }
+
+// ---- backward bit reader (BitStream.cs:322-494).  64-bit container here; the reference's 32-bit reload
+//      points only decide where a damaged stream is rejected, the bits read are the same. ----
+struct BitR { const uint8_t *start; uint32_t size; int64_t bitPos; /* number of unread bits below the cursor */ uint32_t err; };
+__device__ __forceinline__ void br_init(BitR &b, const uint8_t *src, uint32_t size)
+{
+    b.start = src; b.size = size; b.err = 0; b.bitPos = 0;
+    if (size == 0) { b.err = 1; return; }
+    const uint32_t last = src[size - 1];
+    if (last == 0) { b.err = 1; return; }
+    b.bitPos = (int64_t)size * 8 - (int64_t)(8 - zs_highbit(last));      // bits below the end mark
+}
+// next n bits (n <= 32) below the cursor, most significant first; bits below the stream start read as 0
+__device__ __forceinline__ uint32_t br_look(const BitR &b, uint32_t n)
+{
+    if (n == 0 || b.bitPos <= 0) return 0;
+    const int64_t lo = b.bitPos - (int64_t)n;           // lowest stream bit wanted (may be negative)
+    uint64_t w; int64_t b0;
+    if (b.size >= 8) {
+        b0 = ((b.bitPos - 1) >> 3) - 7; if (b0 < 0) b0 = 0;
+        w = zs_load64(b.start + b0);
+    } else {
+        b0 = 0; w = 0;
+        for (uint32_t k = 0; k < b.size; k++) w |= (uint64_t)b.start[k] << (8 * k);
+    }
+    const int64_t rel = lo - 8 * b0;
+    const uint64_t v = (rel >= 0) ? (w >> (uint32_t)rel) : ((rel <= -64) ? 0ull : (w << (uint32_t)(-rel)));
+    return (uint32_t)(v & ((n >= 32) ? 0xFFFFFFFFull : ((1ull << n) - 1)));
+}
+__device__ __forceinline__ uint32_t br_read(BitR &b, uint32_t n) { const uint32_t v = br_look(b, n); b.bitPos -= n; return v; }
+
+// ---- ReadNCount (EntropyCommon.cs:79-188), lane 0 ----
+__device__ static uint32_t readNCount(int16_t *norm, uint32_t *maxSVPtr, uint32_t *tableLogPtr, const uint8_t *hdr, uint32_t hbSize)
+{
+    const uint8_t *const istart = hdr; const uint8_t *const iend = istart + hbSize; const uint8_t *ip = istart;
+    int nbBits, remaining, threshold, bitCount; uint32_t bitStream, charnum = 0; int previous0 = 0;
+    if (hbSize < 4) return ZE(E_srcSize_wrong);
+    bitStream = rd32(ip);
+    nbBits = (int)(bitStream & 0xF) + 5;
+    if (nbBits > 15) return ZE(E_tableLog_tooLarge);
+    bitStream >>= 4; bitCount = 4;
+    *tableLogPtr = (uint32_t)nbBits;
+    remaining = (1 << nbBits) + 1; threshold = 1 << nbBits; nbBits++;
+    while ((remaining > 1) & (charnum <= *maxSVPtr)) {
+        if (previous0) {
+            uint32_t n0 = charnum;
+            while ((bitStream & 0xFFFF) == 0xFFFF) {
+                n0 += 24;
+                if (ip < iend - 5) { ip += 2; bitStream = rd32(ip) >> bitCount; }
+                else { bitStream >>= 16; bitCount += 16; }
+            }
+            while ((bitStream & 3) == 3) { n0 += 3; bitStream >>= 2; bitCount += 2; }
+            n0 += bitStream & 3; bitCount += 2;
+            if (n0 > *maxSVPtr) return ZE(48);
+            while (charnum < n0) norm[charnum++] = 0;
+            if ((ip <= iend - 7) || (ip + (bitCount >> 3) <= iend - 4)) { ip += bitCount >> 3; bitCount &= 7; bitStream = rd32(ip) >> bitCount; }
+            else bitStream >>= 2;
+        }
+        {
+            const int max = (2 * threshold - 1) - remaining;
+            int count;
+            if ((bitStream & (uint32_t)(threshold - 1)) < (uint32_t)max) { count = (int)(bitStream & (uint32_t)(threshold - 1)); bitCount += nbBits - 1; }
+            else { count = (int)(bitStream & (uint32_t)(2 * threshold - 1)); if (count >= threshold) count -= max; bitCount += nbBits; }
+            count--;
+            remaining -= count < 0 ? -count : count;
+            norm[charnum++] = (int16_t)count;
+            previous0 = !count;
+            while (remaining < threshold) { nbBits--; threshold >>= 1; }
+            if ((ip <= iend - 7) || (ip + (bitCount >> 3) <= iend - 4)) { ip += bitCount >> 3; bitCount &= 7; }
+            else { bitCount -= (int)(8 * (iend - 4 - ip)); ip = iend - 4; }
+            bitStream = rd32(ip) >> (bitCount & 31);
+        }
+    }
+    if (remaining != 1) return ZE(E_corruption_detected);
+    if (bitCount > 32) return ZE(E_corruption_detected);
+    *maxSVPtr = charnum - 1;
+    ip += (bitCount + 7) >> 3;
+    return (uint32_t)(ip - istart);
+}
+
+// ---- BuildFSETable (ZStdDecompress.cs:958-1034), lane 0.  kind: 0 LL, 1 OF, 2 ML ----
+__device__ static void buildSeqTable(SeqSym *cells, uint32_t *tableLogOut, uint16_t *symbolNext, const int16_t *norm, uint32_t maxSym, uint32_t tableLog, int kind)
+{
+    const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    uint32_t highThreshold = tableSize - 1, position = 0;
+    *tableLogOut = tableLog;
+    for (uint32_t s = 0; s <= maxSym; s++) {
+        if (norm[s] == -1) { cells[highThreshold--].base = s; symbolNext[s] = 1; }
+        else symbolNext[s] = (uint16_t)norm[s];
+    }
+    for (uint32_t s = 0; s <= maxSym; s++)
+        for (int i = 0; i < norm[s]; i++) {
+            cells[position].base = s;
+            position = (position + step) & tableMask;
+            while (position > highThreshold) position = (position + step) & tableMask;
+        }
+    for (uint32_t u = 0; u < tableSize; u++) {
+        const uint32_t symbol = cells[u].base;
+        const uint32_t nextState = symbolNext[symbol]++;
+        const uint32_t nb = tableLog - zs_highbit(nextState);
+        cells[u].nbBits = (uint8_t)nb;
+        cells[u].nextState = (uint16_t)((nextState << nb) - tableSize);
+        if (kind == 1) { cells[u].nbAdd = (uint8_t)symbol; cells[u].base = symbol == 0 ? 0 : (symbol == 1 ? 1 : (symbol == 2 ? 1 : ((1u << symbol) - 3))); }
+        else if (kind == 0) { cells[u].nbAdd = d_LL_bits[symbol]; cells[u].base = d_LL_base[symbol]; }
+        else { cells[u].nbAdd = d_ML_bits[symbol]; cells[u].base = d_ML_base[symbol]; }
+    }
+}
+
+// ---- ReadStats + table fill (EntropyCommon.cs:198-269, HufDecompress.cs:117-180) ----
+// lane 0 parses the weights; all lanes fill the table.  returns header size or error.
+__device__ static uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t srcSize)
+{
+    const uint32_t lane = (uint32_t)zs_lane();
+    if (lane == 0) {
+        uint32_t result = 0, oSize = 0, iSize;
+        do {
+            if (!srcSize) { result = ZE(E_srcSize_wrong); break; }
+            iSize = src[0];
+            if (iSize >= 128) {
+                oSize = iSize - 127; iSize = (oSize + 1) / 2;
+                if (iSize + 1 > srcSize) { result = ZE(E_srcSize_wrong); break; }
+                if (oSize >= 256) { result = ZE(E_corruption_detected); break; }
+                for (uint32_t n = 0; n < oSize; n += 2) { L.weights[n] = src[1 + n / 2] >> 4; L.weights[n + 1] = src[1 + n / 2] & 15; }
+            } else {
+                // FSE-compressed weights (FseDecompress.cs:233-332), table log <= 6
+                if (iSize + 1 > srcSize) { result = ZE(E_srcSize_wrong); break; }
+                uint32_t tableLog, maxSV = 63;
+                const uint32_t nc = readNCount(L.norm, &maxSV, &tableLog, src + 1, iSize);
+                if (isErr(nc)) { result = nc; break; }
+                if (tableLog > 6 || maxSV > 63) { result = ZE(E_tableLog_tooLarge); break; }
+                {   // FseDecompress.cs:111-181
+                    const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
+                    uint32_t highThreshold = tableSize - 1, position = 0;
+                    for (uint32_t s = 0; s <= maxSV; s++) {
+                        if (L.norm[s] == -1) { L.wfse[highThreshold--].symbol = (uint8_t)s; L.symbolNext[s] = 1; } else L.symbolNext[s] = (uint16_t)L.norm[s];
+                    }
+                    for (uint32_t s = 0; s <= maxSV; s++)
+                        for (int i = 0; i < L.norm[s]; i++) { L.wfse[position].symbol = (uint8_t)s; position = (position + step) & tableMask; while (position > highThreshold) position = (position + step) & tableMask; }
+                    if (position != 0) { result = ZE(E_GENERIC); break; }
+                    for (uint32_t u = 0; u < tableSize; u++) {
+                        const uint32_t sy = L.wfse[u].symbol; const uint32_t ns = L.symbolNext[sy]++;
+                        L.wfse[u].nbBits = (uint8_t)(tableLog - zs_highbit(ns));
+                        L.wfse[u].newState = (uint16_t)((ns << L.wfse[u].nbBits) - tableSize);
+                    }
+                }
+                {   // two interleaved states, FseDecompress.cs:233-295
+                    BitR b; br_init(b, src + 1 + nc, iSize - nc);
+                    if (b.err || iSize <= nc) { result = ZE(E_corruption_detected); break; }
+                    uint32_t s1 = br_read(b, tableLog), s2 = br_read(b, tableLog);
+                    uint32_t op = 0; bool bad = false;
+                    for (;;) {
+                        if (op > 253) { bad = true; break; }
+                        L.weights[op++] = L.wfse[s1].symbol; { const uint32_t nb = L.wfse[s1].nbBits; s1 = L.wfse[s1].newState + br_read(b, nb); }
+                        if (b.bitPos < 0) { L.weights[op++] = L.wfse[s2].symbol; break; }
+                        if (op > 253) { bad = true; break; }
+                        L.weights[op++] = L.wfse[s2].symbol; { const uint32_t nb = L.wfse[s2].nbBits; s2 = L.wfse[s2].newState + br_read(b, nb); }
+                        if (b.bitPos < 0) { L.weights[op++] = L.wfse[s1].symbol; break; }
+                    }
+                    if (bad) { result = ZE(E_corruption_detected); break; }
+                    oSize = op;
+                }
+            }
+            for (int i = 0; i < 13; i++) L.rank[i] = 0;
+            uint32_t weightTotal = 0; bool bad = false;
+            for (uint32_t n = 0; n < oSize; n++) { if (L.weights[n] >= 12) { bad = true; break; } L.rank[L.weights[n]]++; weightTotal += (1u << L.weights[n]) >> 1; }
+            if (bad || weightTotal == 0) { result = ZE(E_corruption_detected); break; }
+            const uint32_t tableLog = zs_highbit(weightTotal) + 1;
+            if (tableLog > 12) { result = ZE(E_corruption_detected); break; }
+            {
+                const uint32_t total = 1u << tableLog, rest = total - weightTotal;
+                const uint32_t verif = 1u << zs_highbit(rest), lastWeight = zs_highbit(rest) + 1;
+                if (verif != rest) { result = ZE(E_corruption_detected); break; }
+                L.weights[oSize] = (uint8_t)lastWeight; L.rank[lastWeight]++;
+            }
+            if ((L.rank[1] < 2) || (L.rank[1] & 1)) { result = ZE(E_corruption_detected); break; }
+            L.hufLog = tableLog;
+            { uint32_t next = 0; for (uint32_t n = 1; n < tableLog + 1; n++) { const uint32_t cur = next; next += L.rank[n] << (n - 1); L.rank[n] = cur; } }
+            L.misc[1] = oSize + 1;
+            result = iSize + 1;
+        } while (0);
+        L.misc[0] = result;
+    }
+    __syncthreads();
+    const uint32_t res = L.misc[0];
+    if (isErr(res)) return res;
+    const uint32_t nbSymbols = L.misc[1], tableLog = L.hufLog;
+    if (lane == 0) for (uint32_t n = 0; n < nbSymbols; n++) { const uint32_t w = L.weights[n]; L.symStart[n] = (uint16_t)L.rank[w]; if (w) L.rank[w] += (1u << w) >> 1; }
+    __syncthreads();
+    for (uint32_t n = 0; n < nbSymbols; n++) {            // uniform loop; lanes fill one symbol's cells together
+        const uint32_t w = L.weights[n];
+        if (!w) continue;
+        const uint32_t length = (1u << w) >> 1, startAt = L.symStart[n];
+        const uint16_t e = (uint16_t)(n | ((tableLog + 1 - w) << 8));
+        for (uint32_t u = lane; u < length; u += 64) L.huf[startAt + u] = e;
+    }
+    __syncthreads();
+    return res;
+}
+
+// one Huffman stream, run by a single lane (HufDecompress.cs:222-264)
+__device__ static bool hufDecodeStream(const DLds &L, uint8_t *out, uint32_t n, const uint8_t *src, uint32_t size)
+{
+    BitR b; br_init(b, src, size);
+    if (b.err) return false;
+    const uint32_t dtLog = L.hufLog;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t e = L.huf[br_look(b, dtLog)];
+        out[i] = (uint8_t)e;
+        b.bitPos -= (e >> 8);
+    }
+    return b.bitPos == 0;          // EndOfDStream (BitStream.cs:494): every bit consumed, none over-read
+}
+
+// XXH64 seed 0 (XxHash.cs:896-1161), single lane
+__device__ static uint64_t rotl64(uint64_t x, int r) { return (x << r) | (x >> (64 - r)); }
+__device__ static uint64_t xxh64(const uint8_t *p, uint64_t len)
+{
+    const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL, P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
+    const uint8_t *const bEnd = p + len; uint64_t h64;
+    #define XXR(acc, in) { acc += (in) * P2; acc = rotl64(acc, 31); acc *= P1; }
+    if (len >= 32) {
+        const uint8_t *const limit = bEnd - 32;
+        uint64_t v1 = P1 + P2, v2 = P2, v3 = 0, v4 = 0 - P1;
+        do { XXR(v1, zs_load64(p)); p += 8; XXR(v2, zs_load64(p)); p += 8; XXR(v3, zs_load64(p)); p += 8; XXR(v4, zs_load64(p)); p += 8; } while (p <= limit);
+        h64 = rotl64(v1, 1) + rotl64(v2, 7) + rotl64(v3, 12) + rotl64(v4, 18);
+        #define XXM(v) { uint64_t t_ = 0; XXR(t_, v); h64 ^= t_; h64 = h64 * P1 + P4; }
+        XXM(v1); XXM(v2); XXM(v3); XXM(v4);
+        #undef XXM
+    } else h64 = P5;
+    h64 += len;
+    while (p + 8 <= bEnd) { uint64_t k1 = 0; XXR(k1, zs_load64(p)); h64 ^= k1; h64 = rotl64(h64, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= bEnd) { h64 ^= (uint64_t)zs_load32(p) * P1; h64 = rotl64(h64, 23) * P2 + P3; p += 4; }
+    while (p < bEnd) { h64 ^= (*p) * P5; h64 = rotl64(h64, 11) * P1; p++; }
+    #undef XXR
+    h64 ^= h64 >> 33; h64 *= P2; h64 ^= h64 >> 29; h64 *= P3; h64 ^= h64 >> 32;
+    return h64;
+}
+
+// ---- one compressed block (ZSTD_decompressBlock_internal :1868-1909). returns decoded size or error ----
+struct DState { uint32_t rep[3]; uint32_t litEntropy, fseEntropy; uint32_t llRepeatOk; };
+
+__device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, uint64_t frameStart, uint64_t op, uint64_t oend,
+                                       const uint8_t *src, uint32_t srcSize, uint8_t *litBuf, uint64_t windowSize)
+{
+    const uint32_t lane = (uint32_t)zs_lane();
+    if (srcSize >= (1u << 17)) return ZE(E_srcSize_wrong);
+    if (srcSize < 3) return ZE(E_corruption_detected);
+    // ---- literals (DecodeLiteralsBlock :683-821) ----
+    const uint8_t *litPtr; uint32_t litSize, litCSizeTot;
+    {
+        const uint32_t type = src[0] & 3, lhl = (src[0] >> 2) & 3;
+        if (type >= 2) {
+            if (type == 3 && st.litEntropy == 0) return ZE(E_dictionary_corrupted);
+            if (srcSize < 5) return ZE(E_corruption_detected);
+            const uint32_t lhc = rd32(src);
+            uint32_t lhSize, litCSize; bool single = false;
+            if (lhl < 2) { single = !lhl; lhSize = 3; litSize = (lhc >> 4) & 0x3FF; litCSize = (lhc >> 14) & 0x3FF; }
+            else if (lhl == 2) { lhSize = 4; litSize = (lhc >> 4) & 0x3FFF; litCSize = lhc >> 18; }
+            else { lhSize = 5; litSize = (lhc >> 4) & 0x3FFFF; litCSize = (lhc >> 22) + ((uint32_t)src[4] << 10); }
+            if (litSize > (1u << 17)) return ZE(E_corruption_detected);
+            if (litCSize + lhSize > srcSize) return ZE(E_corruption_detected);
+            const uint8_t *cs = src + lhSize; uint32_t csz = litCSize;
+            if (type == 2) {
+                if (!single && litSize == 0) return ZE(E_corruption_detected);
+                if (!single && litCSize == 0) return ZE(E_corruption_detected);
+                const uint32_t h = readHufTable(L, cs, csz);
+                if (isErr(h)) return ZE(E_corruption_detected);
+                if (h >= csz) return ZE(E_corruption_detected);
+                cs += h; csz -= h;
+            }
+            bool ok = true;
+            if (single) {
+                if (lane == 0) ok = hufDecodeStream(L, litBuf, litSize, cs, csz);
+            } else {
+                if (csz < 10) return ZE(E_corruption_detected);
+                const uint32_t l1 = rd16(cs), l2 = rd16(cs + 2), l3 = rd16(cs + 4);
+                if (l1 + l2 + l3 + 6 > csz) return ZE(E_corruption_detected);
+                const uint32_t l4 = csz - (l1 + l2 + l3 + 6);
+                const uint32_t seg = (litSize + 3) / 4;
+                if (3 * seg > litSize) return ZE(E_corruption_detected);
+                if (lane < 4) {
+                    const uint32_t off = 6 + (lane > 0 ? l1 : 0) + (lane > 1 ? l2 : 0) + (lane > 2 ? l3 : 0);
+                    const uint32_t len = lane == 0 ? l1 : (lane == 1 ? l2 : (lane == 2 ? l3 : l4));
+                    const uint32_t cnt = lane < 3 ? seg : litSize - 3 * seg;
+                    ok = hufDecodeStream(L, litBuf + lane * seg, cnt, cs + off, len);
+                }
+            }
+            if (__ballot(!ok)) return ZE(E_corruption_detected);
+            __syncthreads();
+            litPtr = litBuf; st.litEntropy = 1; litCSizeTot = litCSize + lhSize;
+        } else {
+            uint32_t lhSize;
+            if (lhl == 1) { lhSize = 2; litSize = rd16(src) >> 4; }
+            else if (lhl == 3) { lhSize = 3; litSize = rd24(src) >> 4; }
+            else { lhSize = 1; litSize = src[0] >> 3; }
+            if (type == 0) {
+                if (litSize + lhSize > srcSize) return ZE(E_corruption_detected);
+                litPtr = src + lhSize; litCSizeTot = lhSize + litSize;
+            } else {
+                if (lhl == 3 && srcSize < 4) return ZE(E_corruption_detected);
+                if (litSize > (1u << 17)) return ZE(E_corruption_detected);
+                const uint8_t v = src[lhSize];
+                for (uint32_t j = lane; j < litSize; j += 64) litBuf[j] = v;
+                __syncthreads();
+                litPtr = litBuf; litCSizeTot = lhSize + 1;
+            }
+        }
+    }
+    const uint8_t *ip = src + litCSizeTot;
+    uint32_t remaining = srcSize - litCSizeTot;
+    // ---- sequence headers (DecodeSeqHeaders :1110-1180) ----
+    uint32_t nbSeq;
+    {
+        if (remaining < 1) return ZE(E_srcSize_wrong);
+        const uint8_t *const iend = ip + remaining;
+        nbSeq = *ip++;
+        if (nbSeq) {
+            if (nbSeq > 0x7F) {
+                if (nbSeq == 0xFF) { if (ip + 2 > iend) return ZE(E_srcSize_wrong); nbSeq = rd16(ip) + 0x7F00; ip += 2; }
+                else { if (ip >= iend) return ZE(E_srcSize_wrong); nbSeq = ((nbSeq - 0x80) << 8) + *ip++; }
+            }
+            if (ip + 4 > iend) return ZE(E_srcSize_wrong);
+            const uint32_t modes = *ip++;
+            if (lane == 0) {
+                uint32_t err = 0; const uint8_t *p = ip;
+                for (int t = 0; t < 3 && !err; t++) {
+                    const uint32_t type = (modes >> (6 - 2 * t)) & 3;
+                    const uint32_t maxS = t == 0 ? 35 : (t == 1 ? 31 : 52), maxLog = t == 1 ? 8 : 9;
+                    SeqSym *cells = t == 0 ? L.LL.cells : (t == 1 ? L.OF.cells : L.ML.cells);
+                    uint32_t *tl = t == 0 ? &L.LL.tableLog : (t == 1 ? &L.OF.tableLog : &L.ML.tableLog);
+                    const uint32_t left = (uint32_t)(iend - p);
+                    if (type == 1) {
+                        if (!left) { err = ZE(E_srcSize_wrong); break; }
+                        const uint32_t symbol = *p;
+                        if (symbol > maxS) { err = ZE(E_corruption_detected); break; }
+                        *tl = 0; cells[0].nbBits = 0; cells[0].nextState = 0;
+                        if (t == 1) { cells[0].nbAdd = (uint8_t)symbol; cells[0].base = symbol == 0 ? 0 : (symbol <= 2 ? 1 : ((1u << symbol) - 3)); }
+                        else if (t == 0) { cells[0].nbAdd = d_LL_bits[symbol]; cells[0].base = d_LL_base[symbol]; }
+                        else { cells[0].nbAdd = d_ML_bits[symbol]; cells[0].base = d_ML_base[symbol]; }
+                        p += 1;
+                    } else if (type == 0) {
+                        const int16_t *dn = t == 0 ? d_LL_defaultNorm : (t == 1 ? d_OF_defaultNorm : d_ML_defaultNorm);
+                        const uint32_t dmax = t == 0 ? 35 : (t == 1 ? 28 : 52);
+                        for (uint32_t i = 0; i <= dmax; i++) L.norm[i] = dn[i];
+                        buildSeqTable(cells, tl, L.symbolNext, L.norm, dmax, t == 1 ? 5 : 6, t);
+                    } else if (type == 3) {
+                        if (!st.fseEntropy) { err = ZE(E_corruption_detected); break; }
+                    } else {
+                        uint32_t tableLog, max = maxS;
+                        const uint32_t h = readNCount(L.norm, &max, &tableLog, p, left);
+                        if (isErr(h)) { err = ZE(E_corruption_detected); break; }
+                        if (tableLog > maxLog) { err = ZE(E_corruption_detected); break; }
+                        buildSeqTable(cells, tl, L.symbolNext, L.norm, max, tableLog, t);
+                        p += h;
+                    }
+                }
+                L.misc[0] = err; L.misc[1] = (uint32_t)(p - ip);
+            }
+            __syncthreads();
+            if (L.misc[0]) return ZE(E_corruption_detected);
+            ip += L.misc[1];
+            remaining = (uint32_t)(iend - ip);
+        }
+    }
+    // ---- sequences (decompressSequences_body :1555-1608) ----
+    const uint64_t ostart = op;
+    uint32_t litPos = 0;
+    if (nbSeq) {
+        st.fseEntropy = 1;
+        const bool longOff = windowSize > (1ull << 25);
+        BitR b; uint32_t sLL = 0, sOF = 0, sML = 0;
+        uint32_t rep0 = st.rep[0], rep1 = st.rep[1], rep2 = st.rep[2];
+        if (lane == 0) {
+            br_init(b, ip, remaining);
+            if (!b.err) { sLL = br_read(b, L.LL.tableLog); sOF = br_read(b, L.OF.tableLog); sML = br_read(b, L.ML.tableLog); }
+            L.misc[0] = b.err;
+        }
+        __syncthreads();
+        if (L.misc[0]) return ZE(E_corruption_detected);
+        (void)longOff;
+        uint32_t left = nbSeq;
+        uint64_t syncedTo = op;                // output below this position is visible to every lane
+        while (left) {
+            const uint32_t T = min(64u, left);
+            if (lane == 0) {
+                uint32_t bad = 0;
+                for (uint32_t t = 0; t < T; t++) {
+                    if (b.bitPos < 0) { bad = 1; break; }            // stream exhausted before all sequences (:1582, :1594)
+                    const SeqSym eLL = L.LL.cells[sLL], eOF = L.OF.cells[sOF], eML = L.ML.cells[sML];
+                    uint32_t offset;
+                    if (eOF.nbAdd == 0) offset = 0; else offset = eOF.base + br_read(b, eOF.nbAdd);
+                    if (eOF.nbAdd <= 1) {
+                        offset += (eLL.base == 0);
+                        if (offset) {
+                            uint32_t temp = (offset == 3) ? rep0 - 1 : (offset == 1 ? rep1 : rep2);
+                            temp += !temp;
+                            if (offset != 1) rep2 = rep1;
+                            rep1 = rep0; rep0 = offset = temp;
+                        } else offset = rep0;
+                    } else { rep2 = rep1; rep1 = rep0; rep0 = offset; }
+                    const uint32_t ml = eML.base + (eML.nbAdd ? br_read(b, eML.nbAdd) : 0);
+                    const uint32_t ll = eLL.base + (eLL.nbAdd ? br_read(b, eLL.nbAdd) : 0);
+                    sLL = eLL.nextState + br_read(b, eLL.nbBits);
+                    sML = eML.nextState + br_read(b, eML.nbBits);
+                    sOF = eOF.nextState + br_read(b, eOF.nbBits);
+                    L.tileLL[t] = ll; L.tileML[t] = ml; L.tileOff[t] = offset;
+                }
+                L.misc[0] = bad;
+            }
+            __syncthreads();
+            if (L.misc[0]) return ZE(E_corruption_detected);
+            // execute the tile (ExecSequence :1265-1352): literals then match, all lanes copy
+            for (uint32_t t = 0; t < T; t++) {
+                const uint32_t ll = L.tileLL[t], ml = L.tileML[t], off = L.tileOff[t];
+                if ((uint64_t)ll + ml > oend - op) return ZE(E_dstSize_tooSmall);
+                if (ll > litSize - litPos) return ZE(E_corruption_detected);
+                for (uint32_t j = lane; j < ll; j += 64) dstBase[op + j] = litPtr[litPos + j];
+                op += ll; litPos += ll;
+                if (off > op - frameStart) return ZE(E_corruption_detected);
+                const uint64_t mstart = op - off;
+                const uint64_t srcEnd = (off >= ml) ? mstart + ml : op;      // highest byte read (exclusive)
+                if (srcEnd > syncedTo) { __syncthreads(); syncedTo = op; }
+                if (off >= ml) { for (uint32_t j = lane; j < ml; j += 64) dstBase[op + j] = dstBase[mstart + j]; }
+                else { for (uint32_t j = lane; j < ml; j += 64) dstBase[op + j] = dstBase[mstart + (j % off)]; }   // period = offset
+                op += ml;
+            }
+            left -= T;
+        }
+        st.rep[0] = (uint32_t)__shfl((int)rep0, 0); st.rep[1] = (uint32_t)__shfl((int)rep1, 0); st.rep[2] = (uint32_t)__shfl((int)rep2, 0);
+    }
+    {
+        const uint32_t lastLL = litSize - litPos;
+        if (lastLL > oend - op) return ZE(E_dstSize_tooSmall);
+        for (uint32_t j = lane; j < lastLL; j += 64) dstBase[op + j] = litPtr[litPos + j];
+        op += lastLL;
+    }
+    __syncthreads();
+    return (uint32_t)(op - ostart);
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint8_t *dstAll,
+                uint32_t *__restrict__ dstSizes, uint8_t *__restrict__ litScratchAll)
+{
+    __shared__ DLds L;
+    const ZsDecItem it = items[blockIdx.x];
+    const uint32_t lane = (uint32_t)zs_lane();
+    const uint8_t *src = srcAll + it.srcOff;
+    uint8_t *dstBase = dstAll + it.dstOff;
+    uint8_t *litBuf = litScratchAll + (size_t)blockIdx.x * ((1u << 17) + 64);
+    uint32_t srcSize = it.srcSize;
+    uint64_t ipos = 0, op = 0;
+    const uint64_t oend = it.dstCap;
+    uint32_t result = 0;
+
+    #define DONE(v) do { result = (v); goto finish; } while (0)
+    while (srcSize - ipos >= 5) {                                   // DecompressMultiFrame :2111-2160
+        const uint8_t *ip = src + ipos;
+        uint64_t rem = srcSize - ipos;
+        const uint32_t magic = rd32(ip);
+        if (magic != 0xFD2FB528u) {
+            if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+                if (rem < 8) DONE(ZE(E_srcSize_wrong));
+                const uint64_t skip = (uint64_t)rd32(ip + 4) + 8;
+                if (rem < skip) DONE(ZE(E_srcSize_wrong));
+                ipos += skip; continue;
+            }
+            DONE(ZE(E_prefix_unknown));
+        }
+        // ---- frame header (:389-499, :2008-2031) ----
+        if (rem < 6 + 3) DONE(ZE(E_srcSize_wrong));
+        const uint32_t fhd = ip[4];
+        const uint32_t dictIDCode = fhd & 3, checksumFlag = (fhd >> 2) & 1, singleSegment = (fhd >> 5) & 1, fcsID = fhd >> 6;
+        const uint32_t didSize = dictIDCode == 3 ? 4 : dictIDCode, fcsSize = fcsID == 0 ? 0 : (fcsID == 1 ? 2 : (fcsID == 2 ? 4 : 8));
+        const uint32_t fhs = 5 + !singleSegment + didSize + fcsSize + (singleSegment && !fcsID);
+        if (rem < fhs + 3) DONE(ZE(E_srcSize_wrong));
+        if (fhd & 0x08) DONE(ZE(E_frameParameter_unsupported));
+        uint32_t pos = 5; uint64_t windowSize = 0, fcs = ~0ull; uint32_t dictID = 0;
+        if (!singleSegment) {
+            const uint32_t wl = ip[pos++]; const uint32_t windowLog = (wl >> 3) + 10;
+            if (windowLog > 30) DONE(ZE(E_frameParameter_windowTooLarge));
+            windowSize = 1ull << windowLog; windowSize += (windowSize >> 3) * (wl & 7);
+        }
+        if (dictIDCode == 1) { dictID = ip[pos]; pos += 1; } else if (dictIDCode == 2) { dictID = rd16(ip + pos); pos += 2; } else if (dictIDCode == 3) { dictID = rd32(ip + pos); pos += 4; }
+        if (fcsID == 0) { if (singleSegment) fcs = ip[pos]; } else if (fcsID == 1) fcs = rd16(ip + pos) + 256; else if (fcsID == 2) fcs = rd32(ip + pos); else fcs = zs_load64(ip + pos);
+        if (singleSegment) windowSize = fcs;
+        if (dictID != 0) DONE(ZE(E_dictionary_wrong));
+        ipos += fhs;
+        DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = 0; st.llRepeatOk = 0;   // DecompressBegin :2478-2499
+        const uint64_t frameStart = op;
+        for (;;) {                                                   // block loop :2033-2067
+            if (srcSize - ipos < 3) DONE(ZE(E_srcSize_wrong));
+            const uint32_t bh = rd24(src + ipos);
+            const uint32_t lastBlock = bh & 1, btype = (bh >> 1) & 3, cSize = bh >> 3;
+            if (btype == 3) DONE(ZE(E_corruption_detected));
+            const uint32_t cBlockSize = btype == 1 ? 1 : cSize;
+            ipos += 3;
+            if (cBlockSize > srcSize - ipos) DONE(ZE(E_srcSize_wrong));
+            uint32_t decoded;
+            if (btype == 2) {
+                decoded = decodeBlock(L, st, dstBase, frameStart, op, oend, src + ipos, cBlockSize, litBuf, windowSize);
+                if (isErr(decoded)) DONE(decoded);
+            } else if (btype == 0) {
+                if (cBlockSize > oend - op) DONE(ZE(E_dstSize_tooSmall));
+                for (uint32_t j = lane; j < cBlockSize; j += 64) dstBase[op + j] = src[ipos + j];
+                decoded = cBlockSize;
+            } else {
+                if (cSize > oend - op) DONE(ZE(E_dstSize_tooSmall));
+                const uint8_t v = src[ipos];
+                for (uint32_t j = lane; j < cSize; j += 64) dstBase[op + j] = v;
+                decoded = cSize;
+            }
+            op += decoded; ipos += cBlockSize;
+            __syncthreads();
+            if (lastBlock) break;
+        }
+        if (fcs != ~0ull && (op - frameStart) != fcs) DONE(ZE(E_corruption_detected));
+        if (checksumFlag) {
+            if (srcSize - ipos < 4) DONE(ZE(E_checksum_wrong));
+            if (lane == 0) L.misc[2] = (uint32_t)xxh64(dstBase + frameStart, op - frameStart);
+            __syncthreads();
+            if (rd32(src + ipos) != L.misc[2]) DONE(ZE(E_checksum_wrong));
+            ipos += 4;
+        }
+    }
+    if (srcSize != ipos) DONE(ZE(E_srcSize_wrong));
+    result = (uint32_t)op;
+finish:
+    if (lane == 0) dstSizes[blockIdx.x] = result;
+    #undef DONE
+}

@@ -1,0 +1,841 @@
+// Entropy stage of the block encoder: k_encode_block turns the sequences left by k_lz_walk into one
+// Zstandard compressed block (literals section + sequences section).  One wavefront per block.
+// Scalar statement of the same algorithm: oracle/zso_encoder.c (compressBlock and below); the two
+// must agree bit for bit.  Every piece is the format-inverse of a function of the reference decoder:
+//   literals section        <-> DecodeLiteralsBlock            csharp/src/ZStdDecompress.cs:683-821
+//   Huffman table / streams <-> ReadStats, HUF_readDTableX2,   EntropyCommon.cs:198-269, HufDecompress.cs:117-358
+//   sequences header/tables <-> DecodeSeqHeaders, BuildFSETable ZStdDecompress.cs:958-1180, EntropyCommon.cs:79-188
+//   sequences bitstream     <-> DecodeSequence, decompressSequences_body  ZStdDecompress.cs:1473-1608
+#include "zsmi_device.h"
+
+#define MaxLL 35
+#define MaxML 52
+#define MaxOff 31
+
+// ---- constant tables (ZStdInternal.cs:158-192, ZStdDecompress.cs:1081-1105) ----
+__constant__ uint8_t c_LL_bits[36] = { 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0, 1,1,1,1,2,2,3,3, 4,6,7,8,9,10,11,12, 13,14,15,16 };
+__constant__ uint8_t c_ML_bits[53] = { 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0, 0,0,0,0,0,0,0,0,
+                                      1,1,1,1,2,2,3,3, 4,4,5,7,8,9,10,11, 12,13,14,15,16 };
+__constant__ uint32_t c_LL_base[36] = { 0,1,2,3,4,5,6,7, 8,9,10,11,12,13,14,15, 16,18,20,22,24,28,32,40,
+                                       48,64,0x80,0x100,0x200,0x400,0x800,0x1000, 0x2000,0x4000,0x8000,0x10000 };
+__constant__ uint32_t c_ML_base[53] = { 3,4,5,6,7,8,9,10, 11,12,13,14,15,16,17,18, 19,20,21,22,23,24,25,26,
+                                       27,28,29,30,31,32,33,34, 35,37,39,41,43,47,51,59, 67,83,99,0x83,0x103,0x203,0x403,0x803,
+                                       0x1003,0x2003,0x4003,0x8003,0x10003 };
+__constant__ int16_t c_LL_defaultNorm[36] = { 4,3,2,2,2,2,2,2, 2,2,2,2,2,1,1,1, 2,2,2,2,2,2,2,2, 2,3,2,1,1,1,1,1, -1,-1,-1,-1 };
+__constant__ int16_t c_ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1,
+                                             1,1,1,1,1,1,1,1, 1,1,1,1,1,1,-1,-1, -1,-1,-1,-1,-1 };
+__constant__ int16_t c_OF_defaultNorm[29] = { 1,1,1,1,1,1,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, -1,-1,-1,-1,-1 };
+__constant__ uint8_t c_LL_Code[64] = { 0,1,2,3,4,5,6,7, 8,9,10,11,12,13,14,15, 16,16,17,17,18,18,19,19, 20,20,20,20,21,21,21,21,
+                                      22,22,22,22,22,22,22,22, 23,23,23,23,23,23,23,23, 24,24,24,24,24,24,24,24, 24,24,24,24,24,24,24,24 };
+__constant__ uint8_t c_ML_Code[128] = { 0,1,2,3,4,5,6,7, 8,9,10,11,12,13,14,15, 16,17,18,19,20,21,22,23, 24,25,26,27,28,29,30,31,
+                                       32,32,33,33,34,34,35,35, 36,36,36,36,37,37,37,37, 38,38,38,38,38,38,38,38, 39,39,39,39,39,39,39,39,
+                                       40,40,40,40,40,40,40,40, 40,40,40,40,40,40,40,40, 41,41,41,41,41,41,41,41, 41,41,41,41,41,41,41,41,
+                                       42,42,42,42,42,42,42,42, 42,42,42,42,42,42,42,42, 42,42,42,42,42,42,42,42, 42,42,42,42,42,42,42,42 };
+
+__device__ __forceinline__ uint32_t llCodeOf(uint32_t ll) { return (ll > 63) ? zs_highbit(ll) + 19 : c_LL_Code[ll]; }
+__device__ __forceinline__ uint32_t mlCodeOf(uint32_t mlBase) { return (mlBase > 127) ? zs_highbit(mlBase) + 36 : c_ML_Code[mlBase]; }
+
+// ---------------------------------------------------------------------------------------------
+// per-wavefront LDS workspace
+// ---------------------------------------------------------------------------------------------
+struct FseCT {                       // encoding table of one symbol type
+    uint16_t stateTable[512];
+    int32_t  deltaFindState[64];
+    uint32_t deltaNbBits[64];
+    uint32_t tableLog;
+    uint32_t rle;
+};
+struct K3Lds {
+    uint32_t count[256];             // literal histogram, later sequence-code counts (3 x 64)
+    uint8_t  nbBits[256];
+    uint16_t code[256];
+    uint32_t leafW[256];
+    uint16_t leafSym[256];
+    uint8_t  lenOfRank[256];
+    uint8_t  weights[256];
+    union {
+        struct { uint32_t pkg[10][256]; uint32_t S[512]; uint32_t npk[12]; } pm;      // package-merge (levels 2..11)
+        struct { FseCT ct[3]; int16_t norm[64]; uint8_t tableSymbol[512]; uint32_t cumul[66];
+                 uint8_t tileCode[3][64]; uint32_t tileState[3][64]; } fse;
+    } u;
+    uint32_t tile[208];              // bit-packing tile
+    uint32_t misc[16];
+    uint32_t rngN[8], rngCarry[8], rngStart[9];
+};
+
+// ---------------------------------------------------------------------------------------------
+// wave helpers
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
+{
+    const int lane = zs_lane();
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)v, d); if (lane >= d) v += t; }
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
+{
+    #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+    return v;
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v)
+{
+    #pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
+    return v;
+}
+
+// Wave-cooperative forward bit writer.  Each put() appends, lane 0 first, up to 96 bits per lane.
+// out32 must be 4-byte aligned; bits are packed little-endian (bit k of the stream = bit k%8 of byte k/8).
+struct BitSink {
+    uint32_t *out32;
+    uint32_t *tile;       // LDS, >= 200 words
+    uint32_t bitpos;
+};
+__device__ __forceinline__ void sink_init(BitSink &b, void *out, uint32_t *tile)
+{
+    b.out32 = (uint32_t *)out; b.tile = tile; b.bitpos = 0;
+    if (zs_lane() == 0) tile[0] = 0;
+    __syncthreads();
+}
+__device__ __forceinline__ void sink_put(BitSink &b, uint64_t lo, uint32_t hi, uint32_t nb)
+{
+    const uint32_t lane = (uint32_t)zs_lane();
+    const uint32_t incl = wave_incl_scan(nb);
+    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    const uint32_t base = b.bitpos & 31u;
+    const uint32_t nwords = (base + total + 31u) >> 5;
+    for (uint32_t i = 1 + lane; i <= nwords; i += 64) b.tile[i] = 0;
+    __syncthreads();
+    if (nb) {
+        const uint32_t bit = base + incl - nb;
+        const uint32_t w = bit >> 5, sh = bit & 31u;
+        // 96-bit value shifted left by sh (< 32) -> up to 4 words
+        const uint32_t v0 = (uint32_t)lo, v1 = (uint32_t)(lo >> 32), v2 = hi;
+        const uint32_t w0 = v0 << sh;
+        const uint32_t w1 = sh ? ((v1 << sh) | (v0 >> (32 - sh))) : v1;
+        const uint32_t w2 = sh ? ((v2 << sh) | (v1 >> (32 - sh))) : v2;
+        const uint32_t w3 = sh ? (v2 >> (32 - sh)) : 0u;
+        if (w0) atomicOr(&b.tile[w], w0);
+        if (w1) atomicOr(&b.tile[w + 1], w1);
+        if (w2) atomicOr(&b.tile[w + 2], w2);
+        if (w3) atomicOr(&b.tile[w + 3], w3);
+    }
+    __syncthreads();
+    const uint32_t nfull = (base + total) >> 5;
+    uint32_t *dst = b.out32 + (b.bitpos >> 5);
+    for (uint32_t i = lane; i < nfull; i += 64) dst[i] = b.tile[i];
+    const uint32_t carry = b.tile[nfull];
+    __syncthreads();
+    if (lane == 0) b.tile[0] = ((base + total) & 31u) ? carry : 0u;
+    __syncthreads();
+    b.bitpos += total;
+}
+// adds the end mark (one 1 bit), flushes; returns the stream size in bytes
+__device__ __forceinline__ uint32_t sink_close(BitSink &b)
+{
+    const uint32_t lane = (uint32_t)zs_lane();
+    sink_put(b, lane == 0 ? 1ull : 0ull, 0u, lane == 0 ? 1u : 0u);
+    if (lane == 0 && (b.bitpos & 31u)) b.out32[b.bitpos >> 5] = b.tile[0];
+    __syncthreads();
+    return (b.bitpos + 7u) >> 3;
+}
+
+// ---------------------------------------------------------------------------------------------
+// lane-0 sequential pieces (small tables; scalar statement in oracle/zso_encoder.c)
+// ---------------------------------------------------------------------------------------------
+struct BitW { uint64_t acc; uint32_t nbits; uint8_t *ptr, *start, *end; int overflow; };
+__device__ static void bw_init(BitW &b, uint8_t *dst, uint32_t cap) { b.acc = 0; b.nbits = 0; b.ptr = b.start = dst; b.end = dst + cap; b.overflow = 0; }
+__device__ static void bw_add(BitW &b, uint32_t value, uint32_t nb)
+{
+    if (!nb) return;
+    b.acc |= (uint64_t)(value & ((nb >= 32) ? 0xFFFFFFFFu : ((1u << nb) - 1))) << b.nbits;
+    b.nbits += nb;
+    while (b.nbits >= 8) { if (b.ptr < b.end) *b.ptr++ = (uint8_t)b.acc; else b.overflow = 1; b.acc >>= 8; b.nbits -= 8; }
+}
+__device__ static uint32_t bw_close(BitW &b)
+{
+    bw_add(b, 1, 1);
+    if (b.nbits) { if (b.ptr < b.end) *b.ptr++ = (uint8_t)b.acc; else b.overflow = 1; b.nbits = 0; }
+    return b.overflow ? 0u : (uint32_t)(b.ptr - b.start);
+}
+
+__device__ static void normalizeCounts(int16_t *norm, uint32_t tableLog, const uint32_t *count, uint32_t total, uint32_t maxSym)
+{
+    const uint32_t tableSize = 1u << tableLog;
+    int still = (int)tableSize;
+    uint32_t largest = 0;
+    for (uint32_t s = 0; s <= maxSym; s++) {
+        if (!count[s]) { norm[s] = 0; continue; }
+        const uint64_t scaled = (uint64_t)count[s] * tableSize;
+        uint32_t p = (uint32_t)(scaled / total);
+        const uint32_t rem = (uint32_t)(scaled % total);
+        if (2 * (uint64_t)rem >= total) p++;
+        if (p == 0) p = 1;
+        norm[s] = (int16_t)p;
+        still -= (int)p;
+        if (norm[s] > norm[largest] || !count[largest]) largest = s;
+    }
+    if (still > 0) norm[largest] = (int16_t)(norm[largest] + still);
+    while (still < 0) {
+        uint32_t best = 0; int found = 0;
+        for (uint32_t s = 0; s <= maxSym; s++) if (norm[s] > 1 && (!found || norm[s] > norm[best])) { best = s; found = 1; }
+        norm[best]--; still++;
+    }
+}
+
+__device__ static uint32_t writeNCount(uint8_t *dst, uint32_t cap, const int16_t *norm, uint32_t maxSym, uint32_t tableLog)
+{
+    uint8_t *out = dst; uint8_t *const oend = dst + cap;
+    const int tableSize = 1 << tableLog;
+    int remaining = tableSize + 1, threshold = tableSize, nbBits = (int)tableLog + 1;
+    uint32_t bitStream = 0; int bitCount = 0; uint32_t charnum = 0; int previous0 = 0;
+    bitStream += (tableLog - 5) << bitCount; bitCount += 4;
+    while (remaining > 1) {
+        if (previous0) {
+            uint32_t start = charnum;
+            while (charnum <= maxSym && !norm[charnum]) charnum++;
+            while (charnum >= start + 24) {
+                start += 24; bitStream += 0xFFFFu << bitCount;
+                if (out + 2 > oend) return 0;
+                out[0] = (uint8_t)bitStream; out[1] = (uint8_t)(bitStream >> 8); out += 2; bitStream >>= 16;
+            }
+            while (charnum >= start + 3) { start += 3; bitStream += 3u << bitCount; bitCount += 2; }
+            bitStream += (charnum - start) << bitCount; bitCount += 2;
+            if (bitCount > 16) {
+                if (out + 2 > oend) return 0;
+                out[0] = (uint8_t)bitStream; out[1] = (uint8_t)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16;
+            }
+        }
+        {
+            int count = norm[charnum++];
+            const int max = (2 * threshold - 1) - remaining;
+            remaining -= count < 0 ? -count : count;
+            count++;
+            if (count >= threshold) count += max;
+            bitStream += (uint32_t)count << bitCount;
+            bitCount += nbBits;
+            bitCount -= (count < max);
+            previous0 = (count == 1);
+            while (remaining < threshold) { nbBits--; threshold >>= 1; }
+        }
+        if (bitCount > 16) {
+            if (out + 2 > oend) return 0;
+            out[0] = (uint8_t)bitStream; out[1] = (uint8_t)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16;
+        }
+    }
+    if (out + 2 > oend) return 0;
+    out[0] = (uint8_t)bitStream; out[1] = (uint8_t)(bitStream >> 8);
+    out += (bitCount + 7) / 8;
+    return (uint32_t)(out - dst);
+}
+
+// cell order is the decoder's (ZStdDecompress.cs:993-1013): spread with the same step and low-probability area
+__device__ static void buildCTable(FseCT &ct, uint8_t *tableSymbol, uint32_t *cumul, const int16_t *norm, uint32_t maxSym, uint32_t tableLog)
+{
+    const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    uint32_t highThreshold = tableSize - 1, position = 0;
+    ct.tableLog = tableLog; ct.rle = 0;
+    cumul[0] = 0;
+    for (uint32_t s = 1; s <= maxSym + 1; s++) {
+        if (norm[s - 1] == -1) { cumul[s] = cumul[s - 1] + 1; tableSymbol[highThreshold--] = (uint8_t)(s - 1); }
+        else cumul[s] = cumul[s - 1] + (uint32_t)norm[s - 1];
+    }
+    for (uint32_t s = 0; s <= maxSym; s++)
+        for (int i = 0; i < norm[s]; i++) {
+            tableSymbol[position] = (uint8_t)s;
+            position = (position + step) & tableMask;
+            while (position > highThreshold) position = (position + step) & tableMask;
+        }
+    for (uint32_t u = 0; u < tableSize; u++) { const uint8_t sym = tableSymbol[u]; ct.stateTable[cumul[sym]++] = (uint16_t)(tableSize + u); }
+    uint32_t total = 0;
+    for (uint32_t s = 0; s <= maxSym; s++) {
+        const int nv = norm[s];
+        if (nv == 0) { ct.deltaNbBits[s] = ((tableLog + 1) << 16) - (1u << tableLog); ct.deltaFindState[s] = 0; }
+        else if (nv == 1 || nv == -1) { ct.deltaNbBits[s] = (tableLog << 16) - (1u << tableLog); ct.deltaFindState[s] = (int)total - 1; total++; }
+        else {
+            const uint32_t maxBitsOut = tableLog - zs_highbit((uint32_t)nv - 1);
+            const uint32_t minStatePlus = (uint32_t)nv << maxBitsOut;
+            ct.deltaNbBits[s] = (maxBitsOut << 16) - minStatePlus;
+            ct.deltaFindState[s] = (int)total - nv;
+            total += (uint32_t)nv;
+        }
+    }
+}
+__device__ __forceinline__ uint32_t cstate_init(const FseCT &ct, uint32_t symbol)
+{
+    const uint32_t dnb = ct.deltaNbBits[symbol];
+    const uint32_t nbBitsOut = (dnb + (1u << 15)) >> 16;
+    const uint32_t v = (nbBitsOut << 16) - dnb;
+    return ct.stateTable[(v >> nbBitsOut) + ct.deltaFindState[symbol]];
+}
+
+// weights -> FSE (inverse of FSE_decompress_wksp as used by ReadStats, EntropyCommon.cs:226-231). lane 0 only.
+__device__ static uint32_t fseCompressWeights(K3Lds &L, uint8_t *dst, uint32_t cap, const uint8_t *weights, uint32_t nw)
+{
+    uint32_t count[16]; int16_t norm[16];
+    uint32_t maxSym = 0, tableLog;
+    for (int i = 0; i < 16; i++) count[i] = 0;
+    if (nw <= 1) return 0;
+    for (uint32_t i = 0; i < nw; i++) { count[weights[i]]++; if (weights[i] > maxSym) maxSym = weights[i]; }
+    for (uint32_t i = 0; i <= maxSym; i++) if (count[i] == nw) return 0;
+    tableLog = 6;
+    while (tableLog > 5 && (1u << (tableLog - 1)) >= nw) tableLog--;
+    { uint32_t present = 0; for (uint32_t i = 0; i <= maxSym; i++) present += count[i] != 0; if (present > (1u << tableLog)) return 0; }
+    normalizeCounts(norm, tableLog, count, nw, maxSym);
+    const uint32_t hsize = writeNCount(dst, cap, norm, maxSym, tableLog);
+    if (!hsize) return 0;
+    FseCT &ct = L.u.fse.ct[0];
+    buildCTable(ct, L.u.fse.tableSymbol, L.u.fse.cumul, norm, maxSym, tableLog);
+    BitW b; bw_init(b, dst + hsize, cap - hsize);
+    {
+        uint32_t st1, st2; int n = (int)nw; const uint8_t *ip = weights + nw;
+        #define ENC(st, sym) { const uint32_t s_ = (sym); const uint32_t nbo = ((st) + ct.deltaNbBits[s_]) >> 16; bw_add(b, (st), nbo); (st) = ct.stateTable[((st) >> nbo) + ct.deltaFindState[s_]]; }
+        if (n & 1) { st1 = cstate_init(ct, *--ip); st2 = cstate_init(ct, *--ip); ENC(st1, *--ip); n -= 3; }
+        else { st2 = cstate_init(ct, *--ip); st1 = cstate_init(ct, *--ip); n -= 2; }
+        while (n > 0) { ENC(st2, *--ip); ENC(st1, *--ip); n -= 2; }
+        #undef ENC
+        bw_add(b, st2, tableLog);
+        bw_add(b, st1, tableLog);
+    }
+    const uint32_t s = bw_close(b);
+    if (!s) return 0;
+    return hsize + s;
+}
+
+// Huffman table description (inverse of ReadStats, EntropyCommon.cs:198-269). lane 0 only.
+__device__ static uint32_t writeHuffHeader(K3Lds &L, uint8_t *dst, uint32_t cap, uint32_t maxSym, uint32_t tableLog)
+{
+    uint8_t *weights = L.weights;
+    for (uint32_t s = 0; s < maxSym; s++) weights[s] = L.nbBits[s] ? (uint8_t)(tableLog + 1 - L.nbBits[s]) : 0;
+    if (maxSym >= 2 && cap > 1) {
+        const uint32_t h = fseCompressWeights(L, dst + 1, cap - 1 < 127 ? cap - 1 : 127, weights, maxSym);
+        if (h > 1 && h < maxSym / 2 && h < 128) { dst[0] = (uint8_t)h; return h + 1; }
+    }
+    if (maxSym > 128) return 0;
+    if ((maxSym + 1) / 2 + 1 > cap) return 0;
+    dst[0] = (uint8_t)(128 + (maxSym - 1));
+    weights[maxSym] = 0;
+    for (uint32_t s = 0; s < maxSym; s += 2) dst[s / 2 + 1] = (uint8_t)((weights[s] << 4) + weights[s + 1]);
+    return (maxSym + 1) / 2 + 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// package-merge code lengths, wave-parallel (scalar statement: huffLengths in oracle/zso_encoder.c)
+// returns the longest code length (= Huffman tableLog)
+// ---------------------------------------------------------------------------------------------
+__device__ static uint32_t lowerBound(const uint32_t *a, uint32_t n, uint32_t key)   // #elements < key
+{ uint32_t lo = 0, hi = n; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] < key) lo = mid + 1; else hi = mid; } return lo; }
+__device__ static uint32_t upperBound(const uint32_t *a, uint32_t n, uint32_t key)   // #elements <= key
+{ uint32_t lo = 0, hi = n; while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (a[mid] <= key) lo = mid + 1; else hi = mid; } return lo; }
+
+__device__ static uint32_t huffLengths(K3Lds &L, uint32_t maxSym, uint32_t maxBits)
+{
+    const uint32_t lane = (uint32_t)zs_lane();
+    // present symbols, rank-sorted by (count, symbol)
+    uint32_t n = 0;
+    for (uint32_t b = 0; b < 256; b += 64) { const uint32_t s = b + lane; n += (uint32_t)__popcll(__ballot(s <= maxSym && L.count[s] != 0)); }
+    for (uint32_t b = 0; b < 256; b += 64) {
+        const uint32_t s = b + lane;
+        L.nbBits[s] = 0;
+        const uint32_t c = (s <= maxSym) ? L.count[s] : 0;
+        if (c) {
+            uint32_t rank = 0;
+            for (uint32_t t = 0; t <= maxSym; t++) { const uint32_t ct = L.count[t]; rank += (ct && (ct < c || (ct == c && t < s))) ? 1u : 0u; }
+            L.leafW[rank] = c; L.leafSym[rank] = (uint16_t)s;
+        }
+    }
+    __syncthreads();
+    if (n == 1) { if (lane == 0) L.nbBits[L.leafSym[0]] = 1; __syncthreads(); return 1; }
+    uint32_t (*pkg)[256] = L.u.pm.pkg;         // pkg[level - 2]
+    uint32_t *S = L.u.pm.S;
+    uint32_t *npk = L.u.pm.npk;                // npk[level]
+    if (lane == 0) npk[1] = 0;
+    __syncthreads();
+    for (uint32_t level = 2; level <= maxBits; level++) {
+        const uint32_t np = npk[level - 1];
+        const uint32_t *prev = (level >= 3) ? pkg[level - 3] : nullptr;
+        for (uint32_t r = lane; r < n; r += 64) { const uint32_t w = L.leafW[r]; S[r + (np ? lowerBound(prev, np, w) : 0u)] = w; }
+        for (uint32_t k = lane; k < np; k += 64) { const uint32_t w = prev[k]; S[k + upperBound(L.leafW, n, w)] = w; }
+        __syncthreads();
+        const uint32_t have = (n + np) >> 1;
+        for (uint32_t i = lane; i < have; i += 64) pkg[level - 2][i] = S[2 * i] + S[2 * i + 1];
+        if (lane == 0) npk[level] = have;
+        __syncthreads();
+    }
+    for (uint32_t r = lane; r < 256; r += 64) L.lenOfRank[r] = 0;
+    __syncthreads();
+    uint32_t m = 2 * n - 2;
+    for (uint32_t level = maxBits; level >= 1; level--) {
+        const uint32_t np = npk[level];
+        const uint32_t *cur = (level >= 2) ? pkg[level - 2] : nullptr;
+        if (m > n + np) m = n + np;
+        uint32_t li = 0;
+        for (uint32_t b = 0; b < n; b += 64) {
+            const uint32_t r = b + lane;
+            bool in = false;
+            if (r < n) { const uint32_t pos = r + (np ? lowerBound(cur, np, L.leafW[r]) : 0u); in = pos < m; }
+            li += (uint32_t)__popcll(__ballot(in));
+            if (in) L.lenOfRank[r]++;
+        }
+        const uint32_t pi = m - li;
+        m = 2 * pi;
+        if (!m) break;
+    }
+    __syncthreads();
+    for (uint32_t r = lane; r < n; r += 64) L.nbBits[L.leafSym[r]] = L.lenOfRank[r];
+    __syncthreads();
+    return L.lenOfRank[0];
+}
+
+// code values in the decoder's table order (HufDecompress.cs:148-176). lane 0 only.
+__device__ static void huffCodes(K3Lds &L, uint32_t maxSym, uint32_t tableLog)
+{
+    uint32_t rankStart[ZS_HUF_MAXBITS + 2], rankCount[ZS_HUF_MAXBITS + 2];
+    for (uint32_t w = 0; w < ZS_HUF_MAXBITS + 2; w++) rankCount[w] = 0;
+    for (uint32_t s = 0; s <= maxSym; s++) if (L.nbBits[s]) rankCount[tableLog + 1 - L.nbBits[s]]++;
+    uint32_t next = 0;
+    for (uint32_t w = 1; w <= tableLog; w++) { rankStart[w] = next; next += rankCount[w] << (w - 1); }
+    for (uint32_t s = 0; s <= maxSym; s++) if (L.nbBits[s]) {
+        const uint32_t w = tableLog + 1 - L.nbBits[s];
+        L.code[s] = (uint16_t)(rankStart[w] >> (w - 1));
+        rankStart[w] += 1u << (w - 1);
+    }
+}
+
+// one Huffman stream of lits[from .. from+len) into tmp (4-byte aligned); last symbol first. returns bytes.
+__device__ static uint32_t huffEncodeStream(K3Lds &L, uint8_t *tmp, const uint8_t *lits, uint32_t from, uint32_t len)
+{
+    const uint32_t lane = (uint32_t)zs_lane();
+    BitSink sink; sink_init(sink, tmp, L.tile);
+    uint32_t remaining = len;
+    while (remaining) {
+        const uint32_t T = min(512u, remaining);
+        uint64_t lo = 0; uint32_t hi = 0, nb = 0;
+        #pragma unroll
+        for (uint32_t j = 0; j < 8; j++) {
+            const uint32_t k = lane * 8 + j;
+            if (k < T) {
+                const uint32_t sym = lits[from + remaining - 1 - k];
+                const uint32_t c = L.code[sym], b = L.nbBits[sym];
+                if (nb < 64) { lo |= (uint64_t)c << nb; if (nb + b > 64) hi |= c >> (64 - nb); }
+                else hi |= c << (nb - 64);
+                nb += b;
+            }
+        }
+        sink_put(sink, lo, hi, nb);
+        remaining -= T;
+    }
+    return sink_close(sink);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_encode_block
+// ---------------------------------------------------------------------------------------------
+#define ZS_PAYLOAD_STRIDE (ZS_BLOCK_MAX + 1024u)
+#define ZS_STREAM_STRIDE  (24u * 1024u)          // per Huffman stream scratch: 16384 symbols * 11 bits = 22528 B max
+
+extern "C" __global__ void __launch_bounds__(64)
+k_encode_block(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ blocks,
+               ZsSeqRec *__restrict__ seqAll, const ZsRangeHdr *__restrict__ hdrAll,
+               uint8_t *__restrict__ litsAll, uint8_t *__restrict__ streamAll, uint8_t *__restrict__ payloadAll,
+               ZsBlockResult *__restrict__ results)
+{
+    __shared__ K3Lds L;
+    const uint32_t blk = blockIdx.x;
+    const uint32_t lane = (uint32_t)zs_lane();
+    const ZsBlockDesc bd = blocks[blk];
+    const uint8_t *s = src + bd.srcOff;
+    const uint32_t n = bd.size;
+    ZsSeqRec *seqBase = seqAll + (size_t)blk * ZS_MAX_RANGES * ZS_SEQ_PER_RANGE;
+    const ZsRangeHdr *hdr = hdrAll + (size_t)blk * ZS_MAX_RANGES;
+    uint8_t *lits = litsAll + (size_t)blk * (ZS_BLOCK_MAX + 64);
+    uint8_t *streams = streamAll + (size_t)blk * 4 * ZS_STREAM_STRIDE;
+    uint8_t *payload = payloadAll + (size_t)blk * ZS_PAYLOAD_STRIDE;
+    const uint32_t cap = n + 512;
+
+    #define FINISH(tp, sz, rb) do { if (lane == 0) { ZsBlockResult r_; r_.payloadSize = (sz); r_.type = (tp); r_.rleByte = (rb); r_.pad = 0; results[blk] = r_; } return; } while (0)
+
+    if (n == 0) FINISH(0, 0, 0);
+    {   // RLE block: every byte equal (ZStdDecompress.cs:1945-1950 on the decode side)
+        const uint32_t b0 = s[0];
+        bool diff = false;
+        for (uint32_t i = lane; i < n; i += 64) diff |= (s[i] != b0);
+        if (!__ballot(diff)) FINISH(1, 1, b0);
+    }
+    if (n < 16) FINISH(0, n, 0);
+
+    // ---- sequences of the 8 ranges, carries ----
+    if (lane == 0) {
+        uint32_t carry = 0, tot = 0;
+        for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) {
+            const uint32_t ns = hdr[r].nseq, tr = hdr[r].trailing;
+            L.rngN[r] = ns; L.rngCarry[r] = carry; L.rngStart[r] = tot;
+            carry = ns ? tr : carry + tr;
+            tot += ns;
+        }
+        L.rngStart[8] = tot; L.misc[1] = carry;
+    }
+    __syncthreads();
+    const uint32_t nseq = L.rngStart[8], lastLits = L.misc[1];
+    const uint32_t *rngN = L.rngN, *rngCarry = L.rngCarry;
+
+    // ---- recent-offset codes (inverse of ZStdDecompress.cs:1509-1530): sequential over sequences,
+    //      64 at a time through readlane.  Result (0 = new offset, 1..3 = field value) goes to ml bits 14-15. ----
+    {
+        uint32_t rep0, rep1, rep2;
+        if (bd.firstInChunk) { rep0 = 1; rep1 = 4; rep2 = 8; } else { rep0 = 0xFFFFFFF1u; rep1 = 0xFFFFFFF2u; rep2 = 0xFFFFFFF3u; }
+        #pragma unroll 1
+        for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) {
+            const uint32_t ns = rngN[r];
+            ZsSeqRec *sq = seqBase + (size_t)r * ZS_SEQ_PER_RANGE;
+            for (uint32_t base = 0; base < ns; base += 64) {
+                const uint32_t k = base + lane;
+                uint32_t off = 0, ll = 0, ml = 0;
+                if (k < ns) { const ZsSeqRec rec = sq[k]; off = rec.off; ll = rec.ll; ml = rec.ml; if (k == 0) ll += rngCarry[r]; }
+                uint32_t myval = 0;
+                const uint32_t cnt = min(64u, ns - base);
+                for (uint32_t t = 0; t < cnt; t++) {
+                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)t);
+                    const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)ll, (int)t);
+                    uint32_t val;
+                    if (l) {
+                        if (o == rep0) val = 1;
+                        else if (o == rep1) { val = 2; rep1 = rep0; rep0 = o; }
+                        else if (o == rep2) { val = 3; rep2 = rep1; rep1 = rep0; rep0 = o; }
+                        else { val = 0; rep2 = rep1; rep1 = rep0; rep0 = o; }
+                    } else {
+                        if (o == rep1) { val = 1; rep1 = rep0; rep0 = o; }
+                        else if (o == rep2) { val = 2; rep2 = rep1; rep1 = rep0; rep0 = o; }
+                        else { val = 0; rep2 = rep1; rep1 = rep0; rep0 = o; }
+                    }
+                    if (lane == t) myval = val;
+                }
+                if (k < ns) sq[k].ml = (uint16_t)(ml | (myval << 14));
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- literals: gather into lits[], histogram ----
+    for (uint32_t i = lane; i < 256; i += 64) L.count[i] = 0;
+    __syncthreads();
+    uint32_t nlit = 0;
+    {
+        #pragma unroll 1
+        for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) {
+            const uint32_t ns = rngN[r];
+            const ZsSeqRec *sq = seqBase + (size_t)r * ZS_SEQ_PER_RANGE;
+            for (uint32_t base = 0; base < ns; base += 64) {
+                const uint32_t k = base + lane;
+                uint32_t ll = 0, mpos = 0;
+                if (k < ns) { const ZsSeqRec rec = sq[k]; ll = rec.ll; if (k == 0) ll += rngCarry[r]; mpos = rec.flags; }
+                const uint32_t incl = wave_incl_scan(ll);
+                const uint32_t dstOff = nlit + incl - ll;
+                const uint32_t srcPos = mpos - ll;
+                // short runs by their own lane, long runs by the whole wavefront
+                if (ll && ll <= 16) for (uint32_t j = 0; j < ll; j++) { const uint8_t c = s[srcPos + j]; lits[dstOff + j] = c; atomicAdd(&L.count[c], 1u); }
+                uint64_t longm = __ballot(ll > 16);
+                while (longm) {
+                    const int t = __builtin_ctzll(longm); longm &= longm - 1;
+                    const uint32_t l2 = (uint32_t)__shfl((int)ll, t), d2 = (uint32_t)__shfl((int)dstOff, t), s2 = (uint32_t)__shfl((int)srcPos, t);
+                    for (uint32_t j = lane; j < l2; j += 64) { const uint8_t c = s[s2 + j]; lits[d2 + j] = c; atomicAdd(&L.count[c], 1u); }
+                }
+                nlit += (uint32_t)__shfl((int)incl, 63);
+            }
+        }
+        for (uint32_t j = lane; j < lastLits; j += 64) { const uint8_t c = s[n - lastLits + j]; lits[nlit + j] = c; atomicAdd(&L.count[c], 1u); }
+        nlit += lastLits;
+    }
+    __syncthreads();
+
+    // ---- literals section (inverse of DecodeLiteralsBlock, ZStdDecompress.cs:683-821) ----
+    uint32_t litSecSize = 0;
+    {
+        uint32_t maxSym = 0, largest = 0;
+        for (uint32_t b = 0; b < 256; b += 64) {
+            const uint32_t c = L.count[b + lane];
+            const uint64_t present = __ballot(c != 0);
+            if (present) maxSym = b + 63u - (uint32_t)__builtin_clzll(present);
+            largest = max(largest, wave_max(c));
+        }
+        bool done = false;
+        if (nlit > 0 && largest == nlit && nlit > 4) {
+            if (lane == 0) {
+                const uint8_t b0 = lits[0];
+                if (nlit < 32) { payload[0] = (uint8_t)(1 + (nlit << 3)); payload[1] = b0; }
+                else if (nlit < 4096) { const uint32_t h = 1 + (1 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = b0; }
+                else { const uint32_t h = 1 + (3 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); payload[3] = b0; }
+            }
+            litSecSize = (nlit < 32) ? 2 : (nlit < 4096 ? 3 : 4);
+            done = true;
+        }
+        if (!done && nlit >= 64) {
+            const uint32_t tableLog = huffLengths(L, maxSym, ZS_HUF_MAXBITS);
+            const uint32_t lhSize = 3 + (nlit >= 1024) + (nlit >= 16384);
+            const bool single = nlit < 256;
+            if (lane == 0) { huffCodes(L, maxSym, tableLog); L.misc[0] = writeHuffHeader(L, payload + lhSize, cap - lhSize, maxSym, tableLog); }
+            __syncthreads();
+            const uint32_t hsz = L.misc[0];
+            if (hsz) {
+                bool ok = true;
+                uint32_t ssz[4] = { 0, 0, 0, 0 };
+                if (single) { ssz[0] = huffEncodeStream(L, streams, lits, 0, nlit); }
+                else {
+                    const uint32_t seg = (nlit + 3) / 4;
+                    #pragma unroll 1
+                    for (uint32_t k = 0; k < 4; k++) {
+                        const uint32_t len = (k < 3) ? seg : nlit - 3 * seg;
+                        ssz[k] = huffEncodeStream(L, streams + k * ZS_STREAM_STRIDE, lits, k * seg, len);
+                        if (ssz[k] > 65535) ok = false;
+                    }
+                }
+                const uint32_t csz = hsz + (single ? ssz[0] : 6 + ssz[0] + ssz[1] + ssz[2] + ssz[3]);
+                if (ok && lhSize + csz <= cap && csz + lhSize < nlit + (3 - (nlit < 32) - (nlit < 4096)) && (single || csz >= 10)) {
+                    uint8_t *op = payload + lhSize + hsz;
+                    if (!single) {
+                        if (lane == 0) { op[0] = (uint8_t)ssz[0]; op[1] = (uint8_t)(ssz[0] >> 8); op[2] = (uint8_t)ssz[1]; op[3] = (uint8_t)(ssz[1] >> 8); op[4] = (uint8_t)ssz[2]; op[5] = (uint8_t)(ssz[2] >> 8); }
+                        op += 6;
+                    }
+                    for (uint32_t k = 0; k < (single ? 1u : 4u); k++) {
+                        const uint8_t *from = streams + k * ZS_STREAM_STRIDE;
+                        for (uint32_t j = lane; j < ssz[k]; j += 64) op[j] = from[j];
+                        op += ssz[k];
+                    }
+                    if (lane == 0) {
+                        if (lhSize == 3) { const uint32_t h = 2 + ((single ? 0u : 1u) << 2) + (nlit << 4) + (csz << 14); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); }
+                        else if (lhSize == 4) { const uint32_t h = 2 + (2 << 2) + (nlit << 4) + (csz << 18); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); payload[3] = (uint8_t)(h >> 24); }
+                        else { const uint32_t h = 2 + (3 << 2) + (nlit << 4) + (csz << 22); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); payload[3] = (uint8_t)(h >> 24); payload[4] = (uint8_t)(csz >> 10); }
+                    }
+                    litSecSize = lhSize + csz;
+                    done = true;
+                }
+            }
+        }
+        if (!done) {
+            const uint32_t lh = 1 + (nlit > 31) + (nlit > 4095);
+            if (lh + nlit > cap) FINISH(0, n, 0);
+            if (lane == 0) {
+                if (lh == 1) payload[0] = (uint8_t)(nlit << 3);
+                else if (lh == 2) { const uint32_t h = (1 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); }
+                else { const uint32_t h = (3 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); }
+            }
+            for (uint32_t j = lane; j < nlit; j += 64) payload[lh + j] = lits[j];
+            litSecSize = lh + nlit;
+        }
+    }
+    __syncthreads();
+    if (cap - litSecSize < 4) FINISH(0, n, 0);
+
+    // ---- sequences section header (inverse of DecodeSeqHeaders, ZStdDecompress.cs:1110-1180) ----
+    uint8_t *op = payload + litSecSize;
+    uint8_t *const oend = payload + cap;
+    if (lane == 0) {
+        if (nseq < 128) op[0] = (uint8_t)nseq;
+        else if (nseq < 0x7F00) { op[0] = (uint8_t)((nseq >> 8) + 0x80); op[1] = (uint8_t)nseq; }
+        else { op[0] = 0xFF; op[1] = (uint8_t)(nseq - 0x7F00); op[2] = (uint8_t)((nseq - 0x7F00) >> 8); }
+    }
+    op += (nseq < 128) ? 1 : (nseq < 0x7F00 ? 2 : 3);
+    if (nseq == 0) {
+        const uint32_t total = (uint32_t)(op - payload);
+        __syncthreads();
+        if (total < n) FINISH(2, total, 0); else FINISH(0, n, 0);
+    }
+
+    // ---- code histograms ----
+    uint32_t *cnt = L.count;                     // [0..63] LL, [64..127] OF, [128..191] ML
+    for (uint32_t i = lane; i < 192; i += 64) cnt[i] = 0;
+    __syncthreads();
+    #pragma unroll 1
+    for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) {
+        const uint32_t ns = rngN[r];
+        const ZsSeqRec *sq = seqBase + (size_t)r * ZS_SEQ_PER_RANGE;
+        for (uint32_t k = lane; k < ns; k += 64) {
+            const ZsSeqRec rec = sq[k];
+            uint32_t ll = rec.ll; if (k == 0) ll += rngCarry[r];
+            const uint32_t ml = rec.ml & 0x3FFFu, rep = rec.ml >> 14;
+            const uint32_t val = rep ? rep : (uint32_t)rec.off + 3;
+            atomicAdd(&cnt[llCodeOf(ll)], 1u);
+            atomicAdd(&cnt[64 + zs_highbit(val)], 1u);
+            atomicAdd(&cnt[128 + mlCodeOf(ml - 3)], 1u);
+        }
+    }
+    __syncthreads();
+
+    // ---- modes, tables (lane 0) ----
+    uint8_t *const modes = op; op += 1;
+    if (lane == 0) {
+        uint32_t modeByte = 0; uint8_t *o = op; bool fail = false;
+        for (uint32_t t = 0; t < 3 && !fail; t++) {
+            const uint32_t *count = cnt + 64 * t;
+            const uint32_t maxCode = t == 0 ? MaxLL : (t == 1 ? MaxOff : MaxML);
+            const uint32_t maxLog = t == 1 ? 8 : 9;
+            const int16_t *defNorm = t == 0 ? c_LL_defaultNorm : (t == 1 ? c_OF_defaultNorm : c_ML_defaultNorm);
+            const uint32_t defLog = t == 1 ? 5 : 6, defMax = t == 0 ? MaxLL : (t == 1 ? 28 : MaxML);
+            FseCT &ct = L.u.fse.ct[t];
+            uint32_t maxSym = 0, largest = 0, mode;
+            for (uint32_t i = 0; i <= maxCode; i++) if (count[i]) { maxSym = i; if (count[i] > largest) largest = count[i]; }
+            if (largest == nseq) {
+                mode = 1;
+                if (o >= oend) { fail = true; break; }
+                *o++ = (uint8_t)maxSym; ct.rle = 1; ct.tableLog = 0;
+            } else if (nseq < 64 && maxSym <= defMax) {
+                mode = 0;
+                for (uint32_t i = 0; i <= defMax; i++) L.u.fse.norm[i] = defNorm[i];
+                buildCTable(ct, L.u.fse.tableSymbol, L.u.fse.cumul, L.u.fse.norm, defMax, defLog);
+            } else {
+                uint32_t tableLog = maxLog;
+                { const uint32_t hb = zs_highbit(nseq - 1); const uint32_t want = hb > 2 ? hb - 2 : 5; if (want < tableLog) tableLog = want; }
+                { const uint32_t minBits = zs_highbit(maxSym) + 2; uint32_t present = 0; for (uint32_t i = 0; i <= maxSym; i++) present += count[i] != 0;
+                  if (tableLog < minBits) tableLog = minBits; while ((1u << tableLog) < present) tableLog++; }
+                if (tableLog < 5) tableLog = 5;
+                if (tableLog > maxLog) tableLog = maxLog;
+                normalizeCounts(L.u.fse.norm, tableLog, count, nseq, maxSym);
+                const uint32_t h = writeNCount(o, (uint32_t)(oend - o), L.u.fse.norm, maxSym, tableLog);
+                if (!h) { fail = true; break; }
+                o += h;
+                mode = 2;
+                buildCTable(ct, L.u.fse.tableSymbol, L.u.fse.cumul, L.u.fse.norm, maxSym, tableLog);
+            }
+            modeByte |= mode << (6 - 2 * t);
+        }
+        *modes = (uint8_t)modeByte;
+        L.misc[0] = fail ? 0xFFFFFFFFu : (uint32_t)(o - payload);
+    }
+    __syncthreads();
+    if (L.misc[0] == 0xFFFFFFFFu) FINISH(0, n, 0);
+    const uint32_t bitstreamOff = L.misc[0];
+
+    // ---- sequences bitstream (inverse of ZStdDecompress.cs:1473-1608): last sequence first.
+    //      per tile of 64 sequences: codes (all lanes) -> FSE state chains (lanes 0..2 = LL, OF, ML) -> pack (all lanes) ----
+    uint8_t *bsTmp = streams;                         // reuse the stream scratch (4-byte aligned, 96 KiB)
+    BitSink sink; sink_init(sink, bsTmp, L.tile);
+    const uint32_t bsCap = 4 * ZS_STREAM_STRIDE - 64;
+    uint32_t chainState = 0;                          // lanes 0..2
+    bool overflow = false;
+    {
+        uint32_t remaining = nseq;
+        bool first = true;
+        while (remaining) {
+            const uint32_t T = min(64u, remaining);
+            // lane t takes global sequence index g = remaining-1-t  -> (range, k)
+            uint32_t ll = 0, ml = 0, val = 0;
+            if (lane < T) {
+                const uint32_t g = remaining - 1 - lane;
+                uint32_t rr = 0;
+                #pragma unroll
+                for (uint32_t i = 1; i < ZS_MAX_RANGES; i++) if (g >= L.rngStart[i]) rr = i;
+                const uint32_t k = g - L.rngStart[rr];
+                const ZsSeqRec rec = seqBase[(size_t)rr * ZS_SEQ_PER_RANGE + k];
+                ll = rec.ll; if (k == 0) ll += L.rngCarry[rr];
+                ml = rec.ml & 0x3FFFu; const uint32_t rep = rec.ml >> 14;
+                val = rep ? rep : (uint32_t)rec.off + 3;
+            }
+            const uint32_t llc = (lane < T) ? llCodeOf(ll) : 0, mlc = (lane < T) ? mlCodeOf(ml - 3) : 0, ofc = (lane < T) ? zs_highbit(val) : 0;
+            L.u.fse.tileCode[0][lane] = (uint8_t)llc; L.u.fse.tileCode[1][lane] = (uint8_t)ofc; L.u.fse.tileCode[2][lane] = (uint8_t)mlc;
+            __syncthreads();
+            if (lane < 3) {
+                const FseCT &ct = L.u.fse.ct[lane];
+                for (uint32_t t = 0; t < T; t++) {
+                    const uint32_t sym = L.u.fse.tileCode[lane][t];
+                    uint32_t outv = 0;
+                    if (!ct.rle) {
+                        if (first && t == 0) chainState = cstate_init(ct, sym);
+                        else {
+                            const uint32_t nbo = (chainState + ct.deltaNbBits[sym]) >> 16;
+                            outv = (chainState & ((1u << nbo) - 1)) | (nbo << 16);
+                            chainState = ct.stateTable[(chainState >> nbo) + ct.deltaFindState[sym]];
+                        }
+                    }
+                    L.u.fse.tileState[lane][t] = outv;
+                }
+            }
+            __syncthreads();
+            // pack: OF state, ML state, LL state, LL extra, ML extra, OF extra (ascending bit positions)
+            uint64_t lo = 0; uint32_t hi = 0, nb = 0;
+            if (lane < T) {
+                #define PUTB(v, b) { const uint32_t b_ = (b); if (b_) { const uint64_t v_ = (uint64_t)(v); if (nb < 64) { lo |= v_ << nb; if (nb + b_ > 64) hi |= (uint32_t)(v_ >> (64 - nb)); } else hi |= (uint32_t)(v_ << (nb - 64)); nb += b_; } }
+                const uint32_t sOF = L.u.fse.tileState[1][lane], sML = L.u.fse.tileState[2][lane], sLL = L.u.fse.tileState[0][lane];
+                PUTB(sOF & 0xFFFFu, sOF >> 16);
+                PUTB(sML & 0xFFFFu, sML >> 16);
+                PUTB(sLL & 0xFFFFu, sLL >> 16);
+                PUTB(ll - c_LL_base[llc], c_LL_bits[llc]);
+                PUTB(ml - c_ML_base[mlc], c_ML_bits[mlc]);
+                PUTB(val - (1u << ofc), ofc);
+                #undef PUTB
+            }
+            if (sink.bitpos / 8 + 1024 > bsCap) { overflow = true; break; }
+            sink_put(sink, lo, hi, nb);
+            remaining -= T;
+            first = false;
+        }
+    }
+    if (overflow) FINISH(0, n, 0);
+    {
+        // final states: ML, OF, LL (ZStdDecompress.cs:1578-1580 reads LL, OF, ML)
+        const uint32_t tlLL = L.u.fse.ct[0].rle ? 0 : L.u.fse.ct[0].tableLog;
+        const uint32_t tlOF = L.u.fse.ct[1].rle ? 0 : L.u.fse.ct[1].tableLog;
+        const uint32_t tlML = L.u.fse.ct[2].rle ? 0 : L.u.fse.ct[2].tableLog;
+        const uint32_t stLL = (uint32_t)__shfl((int)chainState, 0), stOF = (uint32_t)__shfl((int)chainState, 1), stML = (uint32_t)__shfl((int)chainState, 2);
+        uint64_t lo = 0; uint32_t nb = 0;
+        if (lane == 0) {
+            if (tlML) { lo |= (uint64_t)(stML & ((1u << tlML) - 1)) << nb; nb += tlML; }
+            if (tlOF) { lo |= (uint64_t)(stOF & ((1u << tlOF) - 1)) << nb; nb += tlOF; }
+            if (tlLL) { lo |= (uint64_t)(stLL & ((1u << tlLL) - 1)) << nb; nb += tlLL; }
+        }
+        sink_put(sink, lo, 0u, nb);
+    }
+    const uint32_t bsSize = sink_close(sink);
+    const uint32_t total = bitstreamOff + bsSize;
+    if (total > cap || total >= n) FINISH(0, n, 0);
+    for (uint32_t j = lane; j < bsSize; j += 64) payload[bitstreamOff + j] = bsTmp[j];
+    __syncthreads();
+    FINISH(2, total, 0);
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_assemble_frames : one workgroup per chunk.  frame = magic + FHD + FCS (single segment)
+// + blocks  (inverse of ZStdDecompress.cs:421-499, 646-659, 2008-2091)
+// ---------------------------------------------------------------------------------------------
+struct ZsChunkDesc { uint64_t srcOff; uint64_t dstOff; uint32_t size; uint32_t firstBlock; uint32_t nBlocks; uint32_t pad; };
+
+extern "C" __global__ void __launch_bounds__(256)
+k_assemble_frames(const uint8_t *__restrict__ src, const ZsChunkDesc *__restrict__ chunks, const ZsBlockDesc *__restrict__ blocks,
+                  const ZsBlockResult *__restrict__ results, const uint8_t *__restrict__ payloadAll,
+                  uint32_t blockBase, uint8_t *__restrict__ dst, uint32_t *__restrict__ dstSizes, uint32_t chunkBase)
+{
+    const ZsChunkDesc cd = chunks[chunkBase + blockIdx.x];
+    uint8_t *out = dst + cd.dstOff;
+    const uint32_t tid = threadIdx.x;
+    uint32_t pos;
+    if (tid == 0) {
+        out[0] = 0x28; out[1] = 0xB5; out[2] = 0x2F; out[3] = 0xFD;
+        if (cd.size < 256) { out[4] = 0x20; out[5] = (uint8_t)cd.size; }
+        else if (cd.size < 65536 + 256) { out[4] = 0x60; const uint32_t v = cd.size - 256; out[5] = (uint8_t)v; out[6] = (uint8_t)(v >> 8); }
+        else { out[4] = 0xA0; out[5] = (uint8_t)cd.size; out[6] = (uint8_t)(cd.size >> 8); out[7] = (uint8_t)(cd.size >> 16); out[8] = (uint8_t)(cd.size >> 24); }
+    }
+    pos = (cd.size < 256) ? 6 : (cd.size < 65536 + 256 ? 7 : 9);
+    for (uint32_t b = 0; b < cd.nBlocks; b++) {
+        const uint32_t gb = cd.firstBlock + b;             // global block index
+        const uint32_t lb = gb - blockBase;                // index inside this sub-batch's scratch
+        const ZsBlockDesc bd = blocks[gb];
+        const ZsBlockResult r = results[lb];
+        const uint32_t last = (b + 1 == cd.nBlocks) ? 1u : 0u;
+        if (r.type == 1) {
+            if (tid == 0) { const uint32_t h = last + (1u << 1) + (bd.size << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); out[pos + 3] = (uint8_t)r.rleByte; }
+            pos += 4;
+        } else if (r.type == 2) {
+            if (tid == 0) { const uint32_t h = last + (2u << 1) + (r.payloadSize << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); }
+            const uint8_t *p = payloadAll + (size_t)lb * ZS_PAYLOAD_STRIDE;
+            for (uint32_t j = tid; j < r.payloadSize; j += blockDim.x) out[pos + 3 + j] = p[j];
+            pos += 3 + r.payloadSize;
+        } else {
+            if (tid == 0) { const uint32_t h = last + (0u << 1) + (bd.size << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); }
+            const uint8_t *p = src + bd.srcOff;
+            for (uint32_t j = tid; j < bd.size; j += blockDim.x) out[pos + 3 + j] = p[j];
+            pos += 3 + bd.size;
+        }
+    }
+    if (tid == 0) dstSizes[chunkBase + blockIdx.x] = pos;
+}

@@ -1,0 +1,429 @@
+// libzsmi.so : C ABI (include/zsmi.h) over the HIP kernels.  Host side of the codec: contexts, device
+// workspaces, block planning, kernel launches, staging for host-buffer calls.  No CPU codec path exists
+// in this library: every compress/decompress call launches the gfx950 kernels or fails.
+//
+// Single translation unit: the kernel sources are included so that launches and kernels share one code object.
+#include "lz_kernels.hip"
+#include "entropy_kernels.hip"
+#include "decode_kernels.hip"
+#include "../../include/zsmi.h"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#define ZSMI_ERR(code) ((size_t)0 - (size_t)(code))
+
+extern "C" unsigned zsmi_isError(size_t code) { return code > ZSMI_ERR(ZSMI_error_maxCode); }     // ZStdErrors.cs:95-98
+extern "C" unsigned zsmi_getErrorCode(size_t code) { return zsmi_isError(code) ? (unsigned)(0 - code) : 0; }
+extern "C" const char *zsmi_getErrorName(size_t code)
+{
+    switch (zsmi_getErrorCode(code)) {
+    case 0: return "No error detected";
+    case ZSMI_error_GENERIC: return "Error (generic)";
+    case ZSMI_error_prefix_unknown: return "Unknown frame descriptor";
+    case ZSMI_error_version_unsupported: return "Version not supported";
+    case ZSMI_error_frameParameter_unsupported: return "Unsupported frame parameter";
+    case ZSMI_error_frameParameter_windowTooLarge: return "Frame requires too much memory for decoding";
+    case ZSMI_error_corruption_detected: return "Corrupted block detected";
+    case ZSMI_error_checksum_wrong: return "Restored data doesn't match checksum";
+    case ZSMI_error_dictionary_corrupted: return "Dictionary is corrupted";
+    case ZSMI_error_dictionary_wrong: return "Dictionary mismatch";
+    case ZSMI_error_parameter_unsupported: return "Unsupported parameter";
+    case ZSMI_error_parameter_outOfBound: return "Parameter is out of bound";
+    case ZSMI_error_tableLog_tooLarge: return "tableLog requires too much memory : unsupported";
+    case ZSMI_error_maxSymbolValue_tooLarge: return "Unsupported max Symbol Value : too large";
+    case ZSMI_error_maxSymbolValue_tooSmall: return "Specified maxSymbolValue is too small";
+    case ZSMI_error_stage_wrong: return "Operation not authorized at current processing stage";
+    case ZSMI_error_init_missing: return "Context should be init first";
+    case ZSMI_error_memory_allocation: return "Allocation error : not enough memory";
+    case ZSMI_error_workSpace_tooSmall: return "workSpace buffer is not large enough";
+    case ZSMI_error_dstSize_tooSmall: return "Destination buffer is too small";
+    case ZSMI_error_srcSize_wrong: return "Src size is incorrect";
+    default: return "Unspecified error code";
+    }
+}
+extern "C" const char *zsmi_versionString(void) { return "zsmi 0.1 (gfx950 HIP kernels; zstd frame format, decoder semantics of epam/Zstandard = zstd v1.3.4)"; }
+
+extern "C" size_t zsmi_compressBound(size_t srcSize)
+{
+    return srcSize + (srcSize >> 8) + ((srcSize < (128u << 10)) ? (((128u << 10) - srcSize) >> 11) : 0) + 3 * (srcSize / ZS_BLOCK_MAX + 1) + 18;
+}
+
+// ---- host-only frame header parse: ZStdDecompress.cs:421-499, 518-532, 617-622 ----
+static uint32_t h_rd32(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[2] << 16) | ((uint32_t)p[3] << 24); }
+extern "C" unsigned long long zsmi_getDecompressedSize(const void *srcv, size_t srcSize)
+{
+    const uint8_t *src = (const uint8_t *)srcv;
+    if (srcSize < 5) return 0;
+    const uint32_t magic = h_rd32(src);
+    if (magic != 0xFD2FB528u) return 0;                    // skippable -> 0, unknown -> 0
+    const uint32_t fhd = src[4];
+    const uint32_t dictIDCode = fhd & 3, singleSegment = (fhd >> 5) & 1, fcsID = fhd >> 6;
+    const size_t didSize = dictIDCode == 3 ? 4 : dictIDCode, fcsSize = fcsID == 0 ? 0 : (fcsID == 1 ? 2 : (fcsID == 2 ? 4 : 8));
+    const size_t fhs = 5 + !singleSegment + didSize + fcsSize + (singleSegment && !fcsID);
+    if (srcSize < fhs) return 0;
+    if (fhd & 0x08) return 0;
+    size_t pos = 5;
+    if (!singleSegment) { const uint32_t wl = src[pos++]; if ((wl >> 3) + 10 > 30) return 0; }
+    pos += didSize;
+    unsigned long long fcs;
+    switch (fcsID) {
+    case 0: if (!singleSegment) return 0; fcs = src[pos]; break;
+    case 1: fcs = ((unsigned long long)src[pos] | ((unsigned long long)src[pos + 1] << 8)) + 256; break;
+    case 2: fcs = h_rd32(src + pos); break;
+    default: fcs = (unsigned long long)h_rd32(src + pos) | ((unsigned long long)h_rd32(src + pos + 4) << 32); break;
+    }
+    return (fcs >= 0xFFFFFFFFFFFFFFFEull) ? 0 : fcs;
+}
+
+// ---------------------------------------------------------------------------------------------
+// context
+// ---------------------------------------------------------------------------------------------
+struct DevBuf {
+    void *p = nullptr; size_t cap = 0;
+    bool reserve(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + (n >> 3) + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; return false; }
+        cap = want; return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+struct PinBuf {
+    void *p = nullptr; size_t cap = 0;
+    bool reserve(size_t n) {
+        if (n <= cap) return true;
+        if (p) (void)hipHostFree(p);
+        p = nullptr; cap = 0;
+        size_t want = n + (n >> 3) + 4096;
+        if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) { p = nullptr; return false; }
+        cap = want; return true;
+    }
+    void release() { if (p) (void)hipHostFree(p); p = nullptr; cap = 0; }
+};
+
+struct TimedLaunch { const char *name; hipEvent_t a, b; };
+
+struct zsmi_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool ownStream = false;
+    uint32_t maxBlocksInFlight = 2048;
+    // compress workspace
+    DevBuf dBlocks, dChunks, dDist, dSeqs, dHdrs, dLits, dStreams, dPayload, dResults;
+    PinBuf hBlocks, hChunks;
+    // decompress workspace
+    DevBuf dItems, dLitScratch;
+    PinBuf hItems;
+    // staging for host-buffer calls
+    DevBuf sSrc, sDst, sSizes;
+    // timing
+    bool timing = false;
+    std::vector<TimedLaunch> launches;
+    std::vector<hipEvent_t> eventPool;
+};
+
+static hipEvent_t getEvent(zsmi_ctx *c)
+{
+    if (!c->eventPool.empty()) { hipEvent_t e = c->eventPool.back(); c->eventPool.pop_back(); return e; }
+    hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+#define LAUNCH(ctx, name, kernel, grid, block, lds, ...) do { \
+        TimedLaunch tl_{name, nullptr, nullptr}; \
+        if ((ctx)->timing) { tl_.a = getEvent(ctx); tl_.b = getEvent(ctx); (void)hipEventRecord(tl_.a, (ctx)->stream); } \
+        hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__); \
+        if ((ctx)->timing) { (void)hipEventRecord(tl_.b, (ctx)->stream); (ctx)->launches.push_back(tl_); } \
+    } while (0)
+
+extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
+{
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) return nullptr;
+    zsmi_ctx *c = new zsmi_ctx();
+    if (device < 0) { if (hipGetDevice(&c->device) != hipSuccess) { delete c; return nullptr; } }
+    else { c->device = device; if (hipSetDevice(device) != hipSuccess) { delete c; return nullptr; } }
+    if (hipStream) { c->stream = (hipStream_t)hipStream; c->ownStream = false; }
+    else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; } c->ownStream = true; }
+    // the candidate kernel uses up to 128 KiB of dynamic LDS
+    (void)hipFuncSetAttribute((const void *)k_lz_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
+    return c;
+}
+extern "C" void zsmi_freeCtx(zsmi_ctx *c)
+{
+    if (!c) return;
+    (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dDist, &c->dSeqs, &c->dHdrs, &c->dLits, &c->dStreams, &c->dPayload, &c->dResults,
+                       &c->dItems, &c->dLitScratch, &c->sSrc, &c->sDst, &c->sSizes }) b->release();
+    for (PinBuf *b : { &c->hBlocks, &c->hChunks, &c->hItems }) b->release();
+    for (auto &tl : c->launches) { (void)hipEventDestroy(tl.a); (void)hipEventDestroy(tl.b); }
+    for (auto e : c->eventPool) (void)hipEventDestroy(e);
+    if (c->ownStream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+extern "C" int zsmi_sync(zsmi_ctx *c)
+{
+    if (!c) return ZSMI_error_init_missing;
+    return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : ZSMI_error_GENERIC;
+}
+extern "C" int zsmi_enableKernelTiming(zsmi_ctx *c, int on)
+{
+    if (!c) return ZSMI_error_init_missing;
+    c->timing = on != 0;
+    for (auto &tl : c->launches) { c->eventPool.push_back(tl.a); c->eventPool.push_back(tl.b); }
+    c->launches.clear();
+    return 0;
+}
+extern "C" int zsmi_getKernelTimes(zsmi_ctx *c, zsmi_kernel_time *out, int maxEntries)
+{
+    if (!c) return 0;
+    (void)hipStreamSynchronize(c->stream);
+    int n = 0;
+    for (auto &tl : c->launches) {
+        float ms = 0; (void)hipEventElapsedTime(&ms, tl.a, tl.b);
+        int k = 0;
+        for (; k < n; k++) if (!strcmp(out[k].name, tl.name)) break;
+        if (k == n) { if (n >= maxEntries) continue; memset(&out[n], 0, sizeof out[n]); strncpy(out[n].name, tl.name, sizeof(out[n].name) - 1); n++; }
+        out[k].seconds += ms * 1e-3; out[k].launches++;
+        c->eventPool.push_back(tl.a); c->eventPool.push_back(tl.b);
+    }
+    c->launches.clear();
+    return n;
+}
+
+// ---------------------------------------------------------------------------------------------
+// compress
+// ---------------------------------------------------------------------------------------------
+extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                                        uint32_t n, void *dDst, const uint64_t *dstOffsets, uint32_t *dDstSizes, int level)
+{
+    if (!c) return ZSMI_error_init_missing;
+    if (n == 0) return 0;
+    if (hipSetDevice(c->device) != hipSuccess) return ZSMI_error_GENERIC;
+    const int hashLog = level <= 2 ? 12 : 13, look = level <= 2 ? 4 : 8;
+    // plan: chunks -> blocks
+    uint64_t nBlocks = 0;
+    for (uint32_t i = 0; i < n; i++) nBlocks += srcSizes[i] ? (srcSizes[i] + ZS_BLOCK_MAX - 1) / ZS_BLOCK_MAX : 1;
+    if (nBlocks > 0x7FFFFFFFull) return ZSMI_error_srcSize_wrong;
+    if (!c->hChunks.reserve(sizeof(ZsChunkDesc) * n) || !c->hBlocks.reserve(sizeof(ZsBlockDesc) * nBlocks)) return ZSMI_error_memory_allocation;
+    if (!c->dChunks.reserve(sizeof(ZsChunkDesc) * n) || !c->dBlocks.reserve(sizeof(ZsBlockDesc) * nBlocks)) return ZSMI_error_memory_allocation;
+    // the pinned plan buffers may still feed a previous asynchronous copy
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    ZsChunkDesc *hc = (ZsChunkDesc *)c->hChunks.p; ZsBlockDesc *hb = (ZsBlockDesc *)c->hBlocks.p;
+    uint32_t b = 0, maxChunkBlocks = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t nb = srcSizes[i] ? (srcSizes[i] + ZS_BLOCK_MAX - 1) / ZS_BLOCK_MAX : 1;
+        hc[i].srcOff = srcOffsets[i]; hc[i].dstOff = dstOffsets[i]; hc[i].size = srcSizes[i]; hc[i].firstBlock = b; hc[i].nBlocks = nb; hc[i].pad = 0;
+        for (uint32_t k = 0; k < nb; k++, b++) {
+            hb[b].srcOff = srcOffsets[i] + (uint64_t)k * ZS_BLOCK_MAX;
+            const uint64_t left = (uint64_t)srcSizes[i] - (uint64_t)k * ZS_BLOCK_MAX;
+            hb[b].size = (uint32_t)(left < ZS_BLOCK_MAX ? left : ZS_BLOCK_MAX);
+            hb[b].chunk = i; hb[b].firstInChunk = (k == 0); hb[b].lastInChunk = (k + 1 == nb);
+        }
+        if (nb > maxChunkBlocks) maxChunkBlocks = nb;
+    }
+    if (hipMemcpyAsync(c->dChunks.p, hc, sizeof(ZsChunkDesc) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    if (hipMemcpyAsync(c->dBlocks.p, hb, sizeof(ZsBlockDesc) * nBlocks, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    // scratch for one sub-batch of whole chunks
+    const uint32_t cap = (uint32_t)std::min<uint64_t>(nBlocks, std::max(c->maxBlocksInFlight, maxChunkBlocks));
+    if (!c->dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2) || !c->dSeqs.reserve((size_t)cap * ZS_MAX_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
+        !c->dHdrs.reserve((size_t)cap * ZS_MAX_RANGES * sizeof(ZsRangeHdr)) || !c->dLits.reserve((size_t)cap * (ZS_BLOCK_MAX + 64)) ||
+        !c->dStreams.reserve((size_t)cap * 4 * ZS_STREAM_STRIDE) || !c->dPayload.reserve((size_t)cap * ZS_PAYLOAD_STRIDE) ||
+        !c->dResults.reserve((size_t)cap * sizeof(ZsBlockResult))) return ZSMI_error_memory_allocation;
+    const size_t lds = (size_t)(ZS_MAX_RANGES << hashLog) * sizeof(uint16_t);
+    uint32_t chunk0 = 0;
+    while (chunk0 < n) {
+        uint32_t chunk1 = chunk0, nb = 0;
+        while (chunk1 < n && (nb == 0 || nb + hc[chunk1].nBlocks <= cap)) { nb += hc[chunk1].nBlocks; chunk1++; }
+        const uint32_t block0 = hc[chunk0].firstBlock;
+        const ZsBlockDesc *dB = (const ZsBlockDesc *)c->dBlocks.p + block0;
+        LAUNCH(c, "k_lz_candidates", k_lz_candidates, dim3(nb), dim3(512), lds, (const uint8_t *)dSrc, dB, (uint16_t *)c->dDist.p, hashLog);
+        LAUNCH(c, "k_lz_walk", k_lz_walk, dim3(nb * ZS_MAX_RANGES), dim3(64), 0, (const uint8_t *)dSrc, dB, (const uint16_t *)c->dDist.p,
+               (ZsSeqRec *)c->dSeqs.p, (ZsRangeHdr *)c->dHdrs.p, look);
+        LAUNCH(c, "k_encode_block", k_encode_block, dim3(nb), dim3(64), 0, (const uint8_t *)dSrc, dB, (ZsSeqRec *)c->dSeqs.p, (const ZsRangeHdr *)c->dHdrs.p,
+               (uint8_t *)c->dLits.p, (uint8_t *)c->dStreams.p, (uint8_t *)c->dPayload.p, (ZsBlockResult *)c->dResults.p);
+        LAUNCH(c, "k_assemble_frames", k_assemble_frames, dim3(chunk1 - chunk0), dim3(256), 0, (const uint8_t *)dSrc, (const ZsChunkDesc *)c->dChunks.p,
+               (const ZsBlockDesc *)c->dBlocks.p, (const ZsBlockResult *)c->dResults.p, (const uint8_t *)c->dPayload.p, block0, (uint8_t *)dDst, dDstSizes, chunk0);
+        chunk0 = chunk1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : ZSMI_error_GENERIC;
+}
+
+// ---------------------------------------------------------------------------------------------
+// decompress
+// ---------------------------------------------------------------------------------------------
+extern "C" int zsmi_decompressBatchDevice(zsmi_ctx *c, const void *dSrc, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                                          uint32_t n, void *dDst, const uint64_t *dstOffsets, const uint32_t *dstCaps, uint32_t *dDstSizes)
+{
+    if (!c) return ZSMI_error_init_missing;
+    if (n == 0) return 0;
+    if (hipSetDevice(c->device) != hipSuccess) return ZSMI_error_GENERIC;
+    if (!c->hItems.reserve(sizeof(ZsDecItem) * n) || !c->dItems.reserve(sizeof(ZsDecItem) * n)) return ZSMI_error_memory_allocation;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    ZsDecItem *hi = (ZsDecItem *)c->hItems.p;
+    for (uint32_t i = 0; i < n; i++) { hi[i].srcOff = srcOffsets[i]; hi[i].dstOff = dstOffsets[i]; hi[i].srcSize = srcSizes[i]; hi[i].dstCap = dstCaps[i]; }
+    if (hipMemcpyAsync(c->dItems.p, hi, sizeof(ZsDecItem) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    const uint32_t cap = std::min<uint32_t>(n, 8192);
+    if (!c->dLitScratch.reserve((size_t)cap * ((1u << 17) + 64))) return ZSMI_error_memory_allocation;
+    for (uint32_t i0 = 0; i0 < n; i0 += cap) {
+        const uint32_t cnt = std::min(cap, n - i0);
+        LAUNCH(c, "k_decode_frames", k_decode_frames, dim3(cnt), dim3(64), 0, (const uint8_t *)dSrc, (const ZsDecItem *)c->dItems.p + i0, (uint8_t *)dDst,
+               dDstSizes + i0, (uint8_t *)c->dLitScratch.p);
+    }
+    return hipGetLastError() == hipSuccess ? 0 : ZSMI_error_GENERIC;
+}
+
+// ---------------------------------------------------------------------------------------------
+// pack frames
+// ---------------------------------------------------------------------------------------------
+__global__ void k_pack_offsets(const uint32_t *sizes, uint32_t n, uint64_t *offsets)
+{
+    // single workgroup exclusive scan over n sizes (errors count as 0 bytes)
+    __shared__ uint64_t part[1024];
+    const uint32_t tid = threadIdx.x, per = (n + blockDim.x - 1) / blockDim.x;
+    const uint32_t lo = min(n, tid * per), hi = min(n, lo + per);
+    uint64_t s = 0;
+    for (uint32_t i = lo; i < hi; i++) { const uint32_t v = sizes[i]; s += (v > 0xFFFFFF88u) ? 0 : v; }
+    part[tid] = s;
+    __syncthreads();
+    if (tid == 0) { uint64_t run = 0; for (uint32_t t = 0; t < blockDim.x; t++) { const uint64_t v = part[t]; part[t] = run; run += v; } offsets[n] = run; }
+    __syncthreads();
+    uint64_t run = part[tid];
+    for (uint32_t i = lo; i < hi; i++) { offsets[i] = run; const uint32_t v = sizes[i]; run += (v > 0xFFFFFF88u) ? 0 : v; }
+}
+__global__ void k_pack_copy(const uint8_t *frames, const uint64_t *srcOffsets, const uint32_t *sizes, const uint64_t *packedOffsets, uint8_t *packed)
+{
+    const uint32_t i = blockIdx.x;
+    const uint32_t sz = sizes[i] > 0xFFFFFF88u ? 0 : sizes[i];
+    const uint8_t *s = frames + srcOffsets[i]; uint8_t *d = packed + packedOffsets[i];
+    for (uint32_t j = threadIdx.x; j < sz; j += blockDim.x) d[j] = s[j];
+}
+extern "C" int zsmi_packFramesDevice(zsmi_ctx *c, const void *dFrames, const uint64_t *dstOffsets, const uint32_t *dSizes,
+                                     uint32_t n, void *dPacked, uint64_t *dPackedOffsets)
+{
+    if (!c) return ZSMI_error_init_missing;
+    if (n == 0) return 0;
+    if (!c->sSizes.reserve(sizeof(uint64_t) * n)) return ZSMI_error_memory_allocation;
+    if (hipMemcpyAsync(c->sSizes.p, dstOffsets, sizeof(uint64_t) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    LAUNCH(c, "k_pack_offsets", k_pack_offsets, dim3(1), dim3(1024), 0, dSizes, n, dPackedOffsets);
+    LAUNCH(c, "k_pack_copy", k_pack_copy, dim3(n), dim3(256), 0, (const uint8_t *)dFrames, (const uint64_t *)c->sSizes.p, dSizes, (const uint64_t *)dPackedOffsets, (uint8_t *)dPacked);
+    return hipGetLastError() == hipSuccess ? 0 : ZSMI_error_GENERIC;
+}
+
+// ---------------------------------------------------------------------------------------------
+// host-buffer forms
+// ---------------------------------------------------------------------------------------------
+static bool spanOf(const uint64_t *off, const uint32_t *sz, const uint32_t *caps, uint32_t n, uint64_t &lo, uint64_t &hi)
+{
+    lo = ~0ull; hi = 0;
+    for (uint32_t i = 0; i < n; i++) { const uint64_t a = off[i], b = off[i] + (caps ? caps[i] : sz[i]); if (a < lo) lo = a; if (b > hi) hi = b; }
+    if (lo == ~0ull) { lo = 0; hi = 0; }
+    return true;
+}
+extern "C" int zsmi_compressBatchHost(zsmi_ctx *c, const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                                      uint32_t n, void *dst, const uint64_t *dstOffsets, uint32_t *dstSizes, int level)
+{
+    if (!c) return ZSMI_error_init_missing;
+    if (n == 0) return 0;
+    uint64_t slo, shi, dlo, dhi;
+    spanOf(srcOffsets, srcSizes, nullptr, n, slo, shi);
+    std::vector<uint32_t> bounds(n);
+    for (uint32_t i = 0; i < n; i++) bounds[i] = (uint32_t)zsmi_compressBound(srcSizes[i]);
+    spanOf(dstOffsets, nullptr, bounds.data(), n, dlo, dhi);
+    if (!c->sSrc.reserve(shi - slo + 64) || !c->sDst.reserve(dhi - dlo + 64) || !c->sSizes.reserve(sizeof(uint32_t) * n + sizeof(uint64_t) * n)) return ZSMI_error_memory_allocation;
+    std::vector<uint64_t> so(n), dof(n);
+    for (uint32_t i = 0; i < n; i++) { so[i] = srcOffsets[i] - slo; dof[i] = dstOffsets[i] - dlo; }
+    if (shi > slo && hipMemcpyAsync(c->sSrc.p, (const uint8_t *)src + slo, shi - slo, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    uint32_t *dSizes = (uint32_t *)((uint8_t *)c->sSizes.p + sizeof(uint64_t) * n);
+    const int rc = zsmi_compressBatchDevice(c, c->sSrc.p, so.data(), srcSizes, n, c->sDst.p, dof.data(), dSizes, level);
+    if (rc) return rc;
+    if (hipMemcpyAsync(dstSizes, dSizes, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    // copy back only what was produced
+    bool contiguous = true;
+    for (uint32_t i = 0; i < n; i++) if (dstSizes[i] > 0xFFFFFF88u) contiguous = false;
+    (void)contiguous;
+    for (uint32_t i = 0; i < n; i++) {
+        if (dstSizes[i] > 0xFFFFFF88u) continue;
+        if (hipMemcpyAsync((uint8_t *)dst + dstOffsets[i], (const uint8_t *)c->sDst.p + dof[i], dstSizes[i], hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    }
+    return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : ZSMI_error_GENERIC;
+}
+extern "C" int zsmi_decompressBatchHost(zsmi_ctx *c, const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                                        uint32_t n, void *dst, const uint64_t *dstOffsets, const uint32_t *dstCaps, uint32_t *dstSizes)
+{
+    if (!c) return ZSMI_error_init_missing;
+    if (n == 0) return 0;
+    uint64_t slo, shi, dlo, dhi;
+    spanOf(srcOffsets, srcSizes, nullptr, n, slo, shi);
+    spanOf(dstOffsets, nullptr, dstCaps, n, dlo, dhi);
+    if (!c->sSrc.reserve(shi - slo + 64) || !c->sDst.reserve(dhi - dlo + 64) || !c->sSizes.reserve(sizeof(uint32_t) * n)) return ZSMI_error_memory_allocation;
+    std::vector<uint64_t> so(n), dof(n);
+    for (uint32_t i = 0; i < n; i++) { so[i] = srcOffsets[i] - slo; dof[i] = dstOffsets[i] - dlo; }
+    if (shi > slo && hipMemcpyAsync(c->sSrc.p, (const uint8_t *)src + slo, shi - slo, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    const int rc = zsmi_decompressBatchDevice(c, c->sSrc.p, so.data(), srcSizes, n, c->sDst.p, dof.data(), dstCaps, (uint32_t *)c->sSizes.p);
+    if (rc) return rc;
+    if (hipMemcpyAsync(dstSizes, c->sSizes.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    for (uint32_t i = 0; i < n; i++) {
+        if (dstSizes[i] > 0xFFFFFF88u || dstSizes[i] == 0) continue;
+        if (hipMemcpyAsync((uint8_t *)dst + dstOffsets[i], (const uint8_t *)c->sDst.p + dof[i], dstSizes[i], hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    }
+    return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : ZSMI_error_GENERIC;
+}
+
+// ---------------------------------------------------------------------------------------------
+// one-shot calls (the reference's public API shape): a process-wide context, serialised
+// ---------------------------------------------------------------------------------------------
+static std::mutex g_mu;
+static zsmi_ctx *g_ctx = nullptr;
+static zsmi_ctx *defaultCtx() { if (!g_ctx) g_ctx = zsmi_createCtx(-1, nullptr); return g_ctx; }
+
+extern "C" size_t zsmi_compress(void *dst, size_t dstCapacity, const void *src, size_t srcSize, int level)
+{
+    if (srcSize > 0xFFFFFFFFull) return ZSMI_ERR(ZSMI_error_srcSize_wrong);
+    std::lock_guard<std::mutex> lk(g_mu);
+    zsmi_ctx *c = defaultCtx();
+    if (!c) return ZSMI_ERR(ZSMI_error_GENERIC);
+    const size_t bound = zsmi_compressBound(srcSize);
+    std::vector<uint8_t> tmp;
+    uint8_t *out = (uint8_t *)dst;
+    if (dstCapacity < bound) { tmp.resize(bound); out = tmp.data(); }     // compress into a bound-sized buffer, then check the fit
+    const uint64_t so = 0, dof = 0; const uint32_t ss = (uint32_t)srcSize; uint32_t ds = 0;
+    const int rc = zsmi_compressBatchHost(c, src, &so, &ss, 1, out, &dof, &ds, level);
+    if (rc) return ZSMI_ERR(rc);
+    if (ds > 0xFFFFFF88u) return ZSMI_ERR(0u - ds);
+    if (ds > dstCapacity) return ZSMI_ERR(ZSMI_error_dstSize_tooSmall);
+    if (out != dst) memcpy(dst, out, ds);
+    return ds;
+}
+extern "C" size_t zsmi_decompress(void *dst, size_t dstCapacity, const void *src, size_t srcSize)
+{
+    if (srcSize > 0xFFFFFFFFull) return ZSMI_ERR(ZSMI_error_srcSize_wrong);
+    std::lock_guard<std::mutex> lk(g_mu);
+    zsmi_ctx *c = defaultCtx();
+    if (!c) return ZSMI_ERR(ZSMI_error_GENERIC);
+    const uint64_t so = 0, dof = 0; const uint32_t ss = (uint32_t)srcSize; uint32_t ds = 0;
+    const uint32_t cap = (uint32_t)std::min<size_t>(dstCapacity, 0xFFFFFF00u);
+    const int rc = zsmi_decompressBatchHost(c, src, &so, &ss, 1, dst, &dof, &cap, &ds);
+    if (rc) return ZSMI_ERR(rc);
+    if (ds > 0xFFFFFF88u) return ZSMI_ERR(0u - ds);
+    return ds;
+}
+
+// ---- test hook (not in include/zsmi.h): copy a scratch buffer of the last compress sub-batch to the host.
+//      which: 0 dist (u16 x 65536 per block), 1 sequences (ZsSeqRec x 8 x 2048 per block), 2 range headers, 3 block results ----
+extern "C" int zsmi_dbg_copyScratch(zsmi_ctx *c, int which, void *hostDst, size_t bytes)
+{
+    if (!c) return -1;
+    (void)hipStreamSynchronize(c->stream);
+    DevBuf *b = which == 0 ? &c->dDist : which == 1 ? &c->dSeqs : which == 2 ? &c->dHdrs : &c->dResults;
+    if (bytes > b->cap) return -2;
+    return hipMemcpy(hostDst, b->p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
+}

@@ -1,0 +1,41 @@
+// Shared definitions for the HIP kernels of the MI355X Zstandard block codec (gfx950 only).
+// Format constants follow the reference decoder: csharp/src/ZStdInternal.cs:109-198, ZStd.cs:386-416.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define ZS_BLOCK_MAX   65536u     // bytes per block; block positions fit 16 bits
+#define ZS_RANGE_LOG   13
+#define ZS_RANGE_SIZE  (1u << ZS_RANGE_LOG)
+#define ZS_MAX_RANGES  8u
+#define ZS_MINMATCH    4u
+#define ZS_WINDOW      64u        // positions looked at per walk step (one wavefront)
+#define ZS_FCAP        64u        // forward bytes compared when scoring a candidate
+#define ZS_BCAP        32u        // backward bytes compared when scoring a candidate
+#define ZS_SEQ_PER_RANGE 2048u    // 8192 / MINMATCH
+#define ZS_HUF_MAXBITS 11u
+
+// one 64 KiB block of one chunk
+struct ZsBlockDesc {
+    uint64_t srcOff;      // byte offset of the block in the source arena
+    uint32_t size;        // 0..65536
+    uint32_t chunk;       // owning chunk (frame)
+    uint32_t firstInChunk;
+    uint32_t lastInChunk;
+};
+
+// one sequence as the walk kernel leaves it (per range) / as the encode kernel consumes it
+struct ZsSeqRec { uint16_t ll, ml, off, flags; };   // flags: block position of the match start; ml bits 14-15: repcode (encode kernel)
+
+struct ZsRangeHdr { uint32_t nseq, trailing; };
+
+// per-block result of the encode kernel
+struct ZsBlockResult { uint32_t payloadSize; uint32_t type; /* 0 raw, 1 rle, 2 compressed */ uint32_t rleByte; uint32_t pad; };
+
+// unaligned loads.  memcpy keeps the alignment-1 fact visible to the compiler: a cast to an over-aligned
+// pointer lets it turn a wave-uniform address into a scalar load, which drops the low address bits.
+__device__ __forceinline__ uint32_t zs_load32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
+__device__ __forceinline__ uint64_t zs_load64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+__device__ __forceinline__ uint32_t zs_hash4(uint32_t v, int hashLog) { return (v * 2654435761u) >> (32 - hashLog); }
+__device__ __forceinline__ uint32_t zs_highbit(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
+__device__ __forceinline__ int zs_lane() { return (int)(threadIdx.x & 63u); }
