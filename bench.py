@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GiB/s compress @ level 3, 64 KiB chunks (BASELINE.json), on N GPUs of one node.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A step = one pass of the compress path (candidates -> walk -> entropy -> frame assembly) over one batch of
+--chunks chunks per GPU, inputs already resident in HBM.  Workload = BASELINE config[1] shape (independent
+64 KiB chunks, level 3); the Silesia corpus is not available offline, so the chunks come from the synthetic
+Zipf-token log stream of SURVEY.md 8(d) unless --corpus PATH is given.  Chunks shard across ranks with no
+data-path collective (weak scaling: every GPU gets its own --chunks chunks).
+Rank 0 prints one JSON line.
+"""
+import argparse, ctypes, json, os, sys, time
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def load_corpus(path, nbytes, rank):
+    data = np.fromfile(path, dtype=np.uint8)
+    if len(data) == 0:
+        raise SystemExit("empty corpus")
+    reps = (nbytes + len(data) - 1) // len(data)
+    return np.tile(data, reps)[:nbytes]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chunks", type=int, default=4096, help="64 KiB chunks per GPU per step")
+    ap.add_argument("--chunk-size", type=int, default=65536)
+    ap.add_argument("--level", type=int, default=3)
+    ap.add_argument("--corpus", type=str, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    distributed = world > 1
+    torch.cuda.set_device(local_rank)
+    if distributed:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    from zstandard_amd import BatchCodec
+    import _data as D
+
+    cs, n = args.chunk_size, args.chunks
+    nbytes = cs * n
+    t0 = time.time()
+    if args.corpus:
+        host = load_corpus(args.corpus, nbytes, rank); data_label = f"corpus:{os.path.basename(args.corpus)}"
+    else:
+        host = D.zipf_log(nbytes, seed_lo=0x5EED + 1000003 * rank, threads=min(32, os.cpu_count() or 1)); data_label = "synthetic"
+    gen_s = time.time() - t0
+
+    stream = torch.cuda.current_stream()
+    bc = BatchCodec(local_rank, stream.cuda_stream)
+    d_src = torch.from_numpy(host).cuda()
+    offs = np.arange(n, dtype=np.uint64) * cs
+    sizes = np.full(n, cs, dtype=np.uint32)
+    bound = int(bc.L.zsmi_compressBound(cs)); stride = (bound + 255) // 256 * 256
+    d_dst = torch.empty(n * stride, dtype=torch.uint8, device="cuda")
+    d_sizes = torch.zeros(n, dtype=torch.int32, device="cuda")
+    doffs = np.arange(n, dtype=np.uint64) * stride
+
+    def step():
+        bc.compress_device(d_src.data_ptr(), offs, sizes, d_dst.data_ptr(), doffs, d_sizes.data_ptr(), args.level)
+
+    def barrier():
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    bc.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    ktimes = bc.kernel_times()
+    bc.enable_timing(False)
+
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    csz = d_sizes.cpu().numpy().astype(np.uint32)
+    assert (csz < 0xFFFFFF88).all(), "a chunk failed to compress"
+    comp_bytes = int(csz.astype(np.uint64).sum())
+    tot = torch.tensor([float(nbytes), float(comp_bytes)], dtype=torch.float64, device="cuda")
+    if distributed:
+        dist.all_reduce(tot, op=dist.ReduceOp.SUM)
+    total_in, total_out = float(tot[0].item()), float(tot[1].item())
+
+    if rank == 0:
+        value = total_in * args.steps / elapsed / (1 << 30)
+        # roofline of the dominant kernel: algorithmic bytes per launch (S + C of the chunks one launch handles,
+        # SURVEY.md 8d) over its average launch duration, HIP events on the launch stream
+        dom = max(ktimes.items(), key=lambda kv: kv[1][0]) if ktimes else None
+        roofline = None
+        if dom:
+            name, (secs, launches) = dom
+            per_launch_bytes = (nbytes + comp_bytes) * args.steps / launches
+            avg = secs / launches
+            achieved = per_launch_bytes / avg / 1e9
+            roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(avg * 1e3, 4),
+                        "kernels_ms_per_step": {k: round(v[0] / args.steps * 1e3, 4) for k, v in ktimes.items()}}
+        # exactness spot check of the timed output + ratio yardstick
+        import _oracle as O
+        sample = list(range(0, n, max(1, n // 16)))[:16]
+        dst_host = d_dst.cpu().numpy()
+        for i in sample:
+            f = dst_host[int(doffs[i]):int(doffs[i]) + int(csz[i])].tobytes()
+            c = host[i * cs:(i + 1) * cs].tobytes()
+            assert O.decompress(f, len(c)) == c, "timed output must decode under the restated reference decoder"
+        ratio = total_in / total_out
+        ratio_vs_zstd = None
+        if O.libzstd():
+            z = sum(len(O.zstd_compress(host[i * cs:(i + 1) * cs].tobytes(), args.level)) for i in sample)
+            e = int(csz[sample].astype(np.uint64).sum())
+            ratio_vs_zstd = round(z / e, 4)          # > 1: smaller than libzstd ; 0.99 = 1 % larger
+        cpu = None
+        if not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            m = min(n, max(256, 8 * cores))                       # bounded sample of the same workload
+            t1 = time.perf_counter()
+            O.compress_batch(host, offs[:m], sizes[:m], args.level, cores)
+            dt = time.perf_counter() - t1
+            cpu = {"value": round(m * cs / dt / (1 << 30), 4), "unit": "GiB/s", "cores": cores, "kind": "port",
+                   "sample": f"{m} x {cs} B chunks of the same batch, oracle E (scalar statement of the HIP encoder), one thread per core"}
+        out = {"metric": "GiB/s compress @ level 3, 64 KiB chunks", "value": round(value, 3), "unit": "GiB/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": data_label,
+               "config": {"workload": f"{n} independent {cs} B chunks per GPU per step, level {args.level}, BASELINE config[1] shape "
+                                      f"(Silesia unavailable offline -> Zipf-token log stream, SURVEY 8d)", "chunks_per_gpu": n,
+                          "chunk_bytes": cs, "level": args.level, "parallelism": f"chunks sharded over {world} GPU(s), no collective in the data path"},
+               "ratio": round(ratio, 4), "ratio_vs_libzstd_same_level": ratio_vs_zstd,
+               "hbm_read_roofline_frac": round(total_in * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
+               "roofline": roofline, "cpu_baseline": cpu, "datagen_s": round(gen_s, 2)}
+        print(json.dumps(out))
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    bc.close()
+
+
+if __name__ == "__main__":
+    main()
