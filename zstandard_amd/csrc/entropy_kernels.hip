@@ -535,7 +535,19 @@ k_encode_block(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ 
                 const uint32_t dstOff = nlit + incl - ll;
                 const uint32_t srcPos = mpos - ll;
                 // short runs by their own lane, long runs by the whole wavefront
-                if (ll && ll <= 16) for (uint32_t j = 0; j < ll; j++) { const uint8_t c = s[srcPos + j]; lits[dstOff + j] = c; atomicAdd(&L.count[c], 1u); }
+                if (ll && ll <= 16) {
+                    // one round of loads for the whole run: 16 bytes ending at the match start (srcPos + 16 <= n is not
+                    // guaranteed, srcPos + ll <= n is: read the 16 bytes that END at srcPos + ll when possible)
+                    const uint32_t endPos = srcPos + ll;
+                    uint64_t w0, w1; uint32_t skip;
+                    if (endPos >= 16) { w0 = zs_load64(s + endPos - 16); w1 = zs_load64(s + endPos - 8); skip = 16 - ll; }
+                    else { w0 = 0; w1 = 0; skip = 16 - ll; for (uint32_t j = 0; j < ll; j++) { const uint64_t c = s[srcPos + j]; const uint32_t bi = skip + j; if (bi < 8) w0 |= c << (8 * bi); else w1 |= c << (8 * (bi - 8)); } }
+                    for (uint32_t j = 0; j < ll; j++) {
+                        const uint32_t bi = skip + j;
+                        const uint8_t c = (uint8_t)((bi < 8 ? w0 >> (8 * bi) : w1 >> (8 * (bi - 8))));
+                        lits[dstOff + j] = c; atomicAdd(&L.count[c], 1u);
+                    }
+                }
                 uint64_t longm = __ballot(ll > 16);
                 while (longm) {
                     const int t = __builtin_ctzll(longm); longm &= longm - 1;

@@ -39,32 +39,48 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__
     const uint32_t end = min(start + ZS_RANGE_SIZE, hashable);
     uint16_t *T = tables + ((size_t)wave << hashLog);
 
-    for (uint32_t base = start; base < end; base += 64) {
-        const uint32_t p = base + lane;
-        if (p < end) {
-            const uint32_t h = zs_hash4(zs_load32(s + p), hashLog);
-            const uint16_t own = T[h];
-            T[h] = (uint16_t)(p + 1);
-            dist[p] = own;
+    // 8 steps per trip: the 8 loads of a trip are issued together, then the table is visited in step order
+    constexpr uint32_t U = 8;
+    for (uint32_t base = start; base < end; base += 64 * U) {
+        uint32_t v[U];
+        #pragma unroll
+        for (uint32_t u = 0; u < U; u++) { const uint32_t p = base + u * 64 + lane; v[u] = (p < end) ? zs_load32(s + p) : 0u; }
+        #pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t p = base + u * 64 + lane;
+            if (p < end) {
+                const uint32_t h = zs_hash4(v[u], hashLog);
+                const uint16_t own = T[h];
+                T[h] = (uint16_t)(p + 1);
+                dist[p] = own;
+            }
         }
     }
     __syncthreads();
 
-    for (uint32_t base = start; base < end; base += 64) {
-        const uint32_t p = base + lane;
-        if (p < end) {
-            const uint32_t v = zs_load32(s + p);
-            const uint32_t h = zs_hash4(v, hashLog);
-            uint32_t cand = dist[p];
-            if (!cand) {
-                for (int q = (int)wave - 1; q >= 0; q--) {
-                    const uint32_t c = tables[((size_t)q << hashLog) + h];
-                    if (c) { cand = c; break; }
-                }
+    for (uint32_t base = start; base < end; base += 64 * U) {
+        uint32_t v[U], cand[U], cv[U];
+        #pragma unroll
+        for (uint32_t u = 0; u < U; u++) { const uint32_t p = base + u * 64 + lane; const bool in = p < end; v[u] = in ? zs_load32(s + p) : 0u; cand[u] = in ? (uint32_t)dist[p] : 0u; }
+        #pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t p = base + u * 64 + lane;
+            if (p < end && !cand[u]) {
+                // all earlier ranges are read at once (independent LDS reads); the nearest one that has the hash wins
+                const uint32_t h = zs_hash4(v[u], hashLog);
+                uint32_t c[ZS_MAX_RANGES - 1];
+                #pragma unroll
+                for (uint32_t q = 0; q < ZS_MAX_RANGES - 1; q++) c[q] = (q < wave) ? (uint32_t)tables[((size_t)q << hashLog) + h] : 0u;
+                #pragma unroll
+                for (uint32_t q = 0; q < ZS_MAX_RANGES - 1; q++) if (c[q]) cand[u] = c[q];
             }
-            uint16_t d = 0;
-            if (cand && zs_load32(s + cand - 1) == v) d = (uint16_t)(p - (cand - 1));
-            dist[p] = d;
+        }
+        #pragma unroll
+        for (uint32_t u = 0; u < U; u++) cv[u] = cand[u] ? zs_load32(s + cand[u] - 1) : 0u;
+        #pragma unroll
+        for (uint32_t u = 0; u < U; u++) {
+            const uint32_t p = base + u * 64 + lane;
+            if (p < end) dist[p] = (cand[u] && cv[u] == v[u]) ? (uint16_t)(p - (cand[u] - 1)) : (uint16_t)0;
         }
     }
     // positions without 4 bytes left: no candidate

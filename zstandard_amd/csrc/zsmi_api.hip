@@ -118,6 +118,8 @@ struct zsmi_ctx {
     // compress workspace
     DevBuf dBlocks, dChunks, dDist, dSeqs, dHdrs, dLits, dStreams, dPayload, dResults;
     PinBuf hBlocks, hChunks;
+    std::vector<uint64_t> planKey;       // copy of (srcOffsets, srcSizes, dstOffsets) the device-side plan was built from
+    uint64_t planBlocks = 0; uint32_t planMaxChunkBlocks = 1;
     // decompress workspace
     DevBuf dItems, dLitScratch;
     PinBuf hItems;
@@ -207,29 +209,38 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
     if (n == 0) return 0;
     if (hipSetDevice(c->device) != hipSuccess) return ZSMI_error_GENERIC;
     const int hashLog = level <= 2 ? 12 : 13, look = level <= 2 ? 4 : 8;
-    // plan: chunks -> blocks
-    uint64_t nBlocks = 0;
-    for (uint32_t i = 0; i < n; i++) nBlocks += srcSizes[i] ? (srcSizes[i] + ZS_BLOCK_MAX - 1) / ZS_BLOCK_MAX : 1;
-    if (nBlocks > 0x7FFFFFFFull) return ZSMI_error_srcSize_wrong;
-    if (!c->hChunks.reserve(sizeof(ZsChunkDesc) * n) || !c->hBlocks.reserve(sizeof(ZsBlockDesc) * nBlocks)) return ZSMI_error_memory_allocation;
-    if (!c->dChunks.reserve(sizeof(ZsChunkDesc) * n) || !c->dBlocks.reserve(sizeof(ZsBlockDesc) * nBlocks)) return ZSMI_error_memory_allocation;
-    // the pinned plan buffers may still feed a previous asynchronous copy
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return ZSMI_error_GENERIC;
-    ZsChunkDesc *hc = (ZsChunkDesc *)c->hChunks.p; ZsBlockDesc *hb = (ZsBlockDesc *)c->hBlocks.p;
-    uint32_t b = 0, maxChunkBlocks = 1;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t nb = srcSizes[i] ? (srcSizes[i] + ZS_BLOCK_MAX - 1) / ZS_BLOCK_MAX : 1;
-        hc[i].srcOff = srcOffsets[i]; hc[i].dstOff = dstOffsets[i]; hc[i].size = srcSizes[i]; hc[i].firstBlock = b; hc[i].nBlocks = nb; hc[i].pad = 0;
-        for (uint32_t k = 0; k < nb; k++, b++) {
-            hb[b].srcOff = srcOffsets[i] + (uint64_t)k * ZS_BLOCK_MAX;
-            const uint64_t left = (uint64_t)srcSizes[i] - (uint64_t)k * ZS_BLOCK_MAX;
-            hb[b].size = (uint32_t)(left < ZS_BLOCK_MAX ? left : ZS_BLOCK_MAX);
-            hb[b].chunk = i; hb[b].firstInChunk = (k == 0); hb[b].lastInChunk = (k + 1 == nb);
+    // plan: chunks -> blocks.  The device-side plan is reused when the chunk layout repeats (steady-state batches).
+    std::vector<uint64_t> key((size_t)n * 3 + 1);
+    key[0] = n;
+    for (uint32_t i = 0; i < n; i++) { key[1 + i] = srcOffsets[i]; key[1 + n + i] = dstOffsets[i]; key[1 + 2 * (size_t)n + i] = srcSizes[i]; }
+    uint64_t nBlocks; uint32_t maxChunkBlocks;
+    if (key == c->planKey) { nBlocks = c->planBlocks; maxChunkBlocks = c->planMaxChunkBlocks; }
+    else {
+        nBlocks = 0;
+        for (uint32_t i = 0; i < n; i++) nBlocks += srcSizes[i] ? (srcSizes[i] + ZS_BLOCK_MAX - 1) / ZS_BLOCK_MAX : 1;
+        if (nBlocks > 0x7FFFFFFFull) return ZSMI_error_srcSize_wrong;
+        if (!c->hChunks.reserve(sizeof(ZsChunkDesc) * n) || !c->hBlocks.reserve(sizeof(ZsBlockDesc) * nBlocks)) return ZSMI_error_memory_allocation;
+        if (!c->dChunks.reserve(sizeof(ZsChunkDesc) * n) || !c->dBlocks.reserve(sizeof(ZsBlockDesc) * nBlocks)) return ZSMI_error_memory_allocation;
+        // the pinned plan buffers may still feed a previous asynchronous copy
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+        ZsChunkDesc *hc0 = (ZsChunkDesc *)c->hChunks.p; ZsBlockDesc *hb = (ZsBlockDesc *)c->hBlocks.p;
+        uint32_t b = 0; maxChunkBlocks = 1;
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t nb = srcSizes[i] ? (srcSizes[i] + ZS_BLOCK_MAX - 1) / ZS_BLOCK_MAX : 1;
+            hc0[i].srcOff = srcOffsets[i]; hc0[i].dstOff = dstOffsets[i]; hc0[i].size = srcSizes[i]; hc0[i].firstBlock = b; hc0[i].nBlocks = nb; hc0[i].pad = 0;
+            for (uint32_t k = 0; k < nb; k++, b++) {
+                hb[b].srcOff = srcOffsets[i] + (uint64_t)k * ZS_BLOCK_MAX;
+                const uint64_t left = (uint64_t)srcSizes[i] - (uint64_t)k * ZS_BLOCK_MAX;
+                hb[b].size = (uint32_t)(left < ZS_BLOCK_MAX ? left : ZS_BLOCK_MAX);
+                hb[b].chunk = i; hb[b].firstInChunk = (k == 0); hb[b].lastInChunk = (k + 1 == nb);
+            }
+            if (nb > maxChunkBlocks) maxChunkBlocks = nb;
         }
-        if (nb > maxChunkBlocks) maxChunkBlocks = nb;
+        if (hipMemcpyAsync(c->dChunks.p, hc0, sizeof(ZsChunkDesc) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+        if (hipMemcpyAsync(c->dBlocks.p, hb, sizeof(ZsBlockDesc) * nBlocks, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+        c->planKey.swap(key); c->planBlocks = nBlocks; c->planMaxChunkBlocks = maxChunkBlocks;
     }
-    if (hipMemcpyAsync(c->dChunks.p, hc, sizeof(ZsChunkDesc) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
-    if (hipMemcpyAsync(c->dBlocks.p, hb, sizeof(ZsBlockDesc) * nBlocks, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    const ZsChunkDesc *hc = (const ZsChunkDesc *)c->hChunks.p;
     // scratch for one sub-batch of whole chunks
     const uint32_t cap = (uint32_t)std::min<uint64_t>(nBlocks, std::max(c->maxBlocksInFlight, maxChunkBlocks));
     if (!c->dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2) || !c->dSeqs.reserve((size_t)cap * ZS_MAX_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
