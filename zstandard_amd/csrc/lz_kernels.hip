@@ -91,150 +91,164 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_lz_walk : one wavefront per range.  Each step the 64 lanes look at dist[ip .. ip+64), the
-// first LOOK positions holding a candidate are handed to groups of 8 lanes; a group compares
-// 64 bytes forward and 32 bytes backward (into the pending literals) in one round of loads,
-// scores its candidate, the best one becomes a sequence.
+// k_lz_walk : one wavefront per block; the 64 lanes are 8 independent walkers of 8 lanes, walker g
+// walks range g.  A walker step: its 8 lanes read dist[ip .. ip+64) (8 positions each), the first
+// LOOK positions holding a candidate go one per lane; a lane compares 64 bytes forward and 32 bytes
+// backward (into the pending literals) for its candidate with one round of loads, scores it, the
+// best one of the walker becomes a sequence (extended by the walker's 8 lanes if it hit the 64-byte
+// cap).  Eight dependent chains per wavefront hide each other's memory latency.
+// Scalar statement: walkRange in oracle/zso_encoder.c.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t load64_clamped(const uint8_t *s, int32_t pos, uint32_t n)
+__device__ __forceinline__ uint64_t load64_fwd(const uint8_t *s, uint32_t pos, uint32_t n)
 {
-    // bytes s[pos .. pos+8) with positions >= n read as 0 (pos >= 0, n >= 8)
-    if ((uint32_t)pos + 8 <= n) return zs_load64(s + pos);
-    if ((uint32_t)pos >= n) return 0;
-    const uint32_t sh = (uint32_t)pos + 8 - n;            // 1..7 bytes beyond the end
-    return zs_load64(s + n - 8) >> (8 * sh);
+    // bytes s[pos .. pos+8), positions >= n read as 0   (n >= 8)
+    const uint32_t a = min(pos, n - 8u);
+    const uint32_t sh = pos - a;
+    const uint64_t w = zs_load64(s + a);
+    return sh >= 8u ? 0ull : (w >> (8u * sh));
 }
-__device__ __forceinline__ uint32_t load32_back(const uint8_t *s, int32_t pos)
+__device__ __forceinline__ uint64_t load64_bwd(const uint8_t *s, int32_t pos)
 {
-    // bytes s[pos .. pos+4) with positions < 0 read as 0 (pos + 4 > 0 is not required)
-    if (pos >= 0) return zs_load32(s + pos);
-    if (pos <= -4) return 0;
-    return zs_load32(s) << (8 * (uint32_t)(-pos));
+    // bytes s[pos .. pos+8), positions < 0 read as 0   (pos + 8 > 0 not required)
+    const int32_t a = max(pos, 0);
+    const uint32_t sh = (uint32_t)(a - pos);
+    const uint64_t w = zs_load64(s + a);
+    return sh >= 8u ? 0ull : (w << (8u * sh));
 }
 
-extern "C" __global__ void __launch_bounds__(64)
+#define ZS_WALK_WAVES 4
+extern "C" __global__ void __launch_bounds__(64 * ZS_WALK_WAVES)
 k_lz_walk(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ blocks,
           const uint16_t *__restrict__ distAll, ZsSeqRec *__restrict__ seqAll, ZsRangeHdr *__restrict__ hdrAll,
-          int look)
+          int look, uint32_t nBlocks)
 {
-    const uint32_t blk = blockIdx.x >> 3, range = blockIdx.x & 7u;
+    __shared__ __attribute__((aligned(16))) uint16_t winDist[ZS_WALK_WAVES][8][64];
+    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t blk = blockIdx.x * ZS_WALK_WAVES + wave;
+    if (blk >= nBlocks) return;                                   // no workgroup barrier is used below
     const ZsBlockDesc bd = blocks[blk];
     const uint8_t *s = src + bd.srcOff;
     const uint32_t n = bd.size;
     const uint16_t *dist = distAll + (size_t)blk * ZS_BLOCK_MAX;
-    ZsSeqRec *seqs = seqAll + ((size_t)blk * ZS_MAX_RANGES + range) * ZS_SEQ_PER_RANGE;
-    const uint32_t lane = threadIdx.x & 63u;
-    const uint32_t start = range << ZS_RANGE_LOG;
-    if (start >= n) { if (lane == 0) { hdrAll[blockIdx.x].nseq = 0; hdrAll[blockIdx.x].trailing = 0; } return; }
+    const uint32_t grp = lane >> 3, sub = lane & 7u;
+    ZsSeqRec *seqs = seqAll + ((size_t)blk * ZS_MAX_RANGES + grp) * ZS_SEQ_PER_RANGE;
+    uint16_t *win = winDist[wave][grp];
+    const uint32_t start = grp << ZS_RANGE_LOG;
+    const bool alive = (start < n) && (n >= 16);
     const uint32_t end = min(start + ZS_RANGE_SIZE, n);
     const uint32_t hashable = (n >= 4) ? n - 3 : 0;
-    const uint32_t scanEnd = min(end, hashable);
-    const uint32_t grp = lane >> 3, sub = lane & 7u;
+    const uint32_t scanEnd = alive ? min(end, hashable) : 0;
 
     uint32_t ip = start, anchor = start, nseq = 0;
-    while (ip < scanEnd) {
+    for (;;) {
+        const bool run = ip < scanEnd;
+        if (!__any(run)) break;
         const uint32_t wend = min(ip + ZS_WINDOW, scanEnd);
-        const uint32_t q0 = ip + lane;
-        const uint32_t d = (q0 < wend) ? dist[q0] : 0;
-        uint64_t m = __ballot(d != 0);
-        if (m == 0) { ip = wend; continue; }
-        // lane index of the grp-th candidate
-        uint32_t ncand = (uint32_t)__popcll(m);
-        if (ncand > (uint32_t)look) ncand = (uint32_t)look;
-        uint32_t selLane = 0;
-        {
-            uint64_t mm = m;
-            #pragma unroll
-            for (uint32_t g = 0; g < 8; g++) {
-                const uint32_t l = mm ? (uint32_t)__builtin_ctzll(mm) : 0;
-                if (g == grp) selLane = l;
-                mm &= mm - 1;
-            }
+        // ---- window: 8 positions per lane ----
+        uint64_t w0 = 0, w1 = 0;
+        if (run) { const uint8_t *dp = reinterpret_cast<const uint8_t *>(dist + ip + 8 * sub); w0 = zs_load64(dp); w1 = zs_load64(dp + 8); }
+        uint32_t mask8 = 0;
+        #pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t dk = (uint32_t)((k < 4 ? (w0 >> (16 * k)) : (w1 >> (16 * (k - 4)))) & 0xFFFFu);
+            if (dk && (ip + 8 * sub + k) < wend) mask8 |= 1u << k;
         }
-        const bool active = grp < ncand;
-        const uint32_t off = (uint32_t)__shfl((int)d, (int)selLane);
-        const uint32_t q = ip + selLane;
-        // one round of loads: 8 bytes forward per lane, 4 bytes backward per lane
-        uint32_t nbF = 0, nbB = 0;
+        *reinterpret_cast<uint64_t *>(win + 8 * sub) = w0;
+        *reinterpret_cast<uint64_t *>(win + 8 * sub + 4) = w1;
+        uint64_t m64 = run ? ((uint64_t)mask8 << (8 * sub)) : 0ull;
+        m64 |= (uint64_t)__shfl_xor((long long)m64, 1);
+        m64 |= (uint64_t)__shfl_xor((long long)m64, 2);
+        m64 |= (uint64_t)__shfl_xor((long long)m64, 4);
+        const uint32_t ncand = min((uint32_t)__popcll(m64), (uint32_t)look);
+        const bool active = run && sub < ncand;
+        uint32_t idx = 0;
+        { uint64_t mm = m64; for (uint32_t t = 0; t < sub; t++) mm &= mm - 1; idx = mm ? (uint32_t)__builtin_ctzll(mm) : 0u; }
+        const uint32_t off = active ? (uint32_t)win[idx] : 0u;
+        const uint32_t q = ip + idx;
+        // ---- one round of loads: 64 bytes forward, 32 bytes backward, both sides ----
+        uint32_t fwd = 0, back = 0;
+        int key = 0;
         if (active) {
+            uint64_t fa[8], fb[8], ba[4], bb[4];
+            #pragma unroll
+            for (uint32_t k = 0; k < 8; k++) { fa[k] = load64_fwd(s, q + 8 * k, n); fb[k] = load64_fwd(s, q - off + 8 * k, n); }
+            #pragma unroll
+            for (uint32_t k = 0; k < 4; k++) { ba[k] = load64_bwd(s, (int32_t)q - 8 * (int32_t)(k + 1)); bb[k] = load64_bwd(s, (int32_t)(q - off) - 8 * (int32_t)(k + 1)); }
             const uint32_t cap = min(end - q, ZS_FCAP);
-            const int32_t fo = (int32_t)(8 * sub);
-            if ((uint32_t)fo < cap) {
-                const uint64_t a = load64_clamped(s, (int32_t)q + fo, n);
-                const uint64_t b = load64_clamped(s, (int32_t)(q - off) + fo, n);
-                const uint64_t x = a ^ b;
-                nbF = x ? ((uint32_t)__builtin_ctzll(x) >> 3) : 8u;
-                nbF = min(nbF, cap - (uint32_t)fo);
+            bool stop = false;
+            #pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint64_t x = fa[k] ^ fb[k];
+                uint32_t nb = x ? ((uint32_t)__builtin_ctzll(x) >> 3) : 8u;
+                const uint32_t room = (8 * k < cap) ? cap - 8 * k : 0u;
+                nb = min(nb, room);
+                if (!stop) fwd += nb;
+                if (nb < 8u) stop = true;
             }
             const uint32_t maxBack = min(min(q - anchor, q - off), ZS_BCAP);
-            const uint32_t bo = 4 * sub;                                   // this lane covers back distances bo+1 .. bo+4
-            if (bo < maxBack) {
-                const uint32_t a = load32_back(s, (int32_t)q - (int32_t)bo - 4);
-                const uint32_t b = load32_back(s, (int32_t)(q - off) - (int32_t)bo - 4);
-                const uint32_t x = a ^ b;
-                nbB = x ? ((uint32_t)__builtin_clz(x) >> 3) : 4u;
-                nbB = min(nbB, maxBack - bo);
+            stop = false;
+            #pragma unroll
+            for (uint32_t k = 0; k < 4; k++) {
+                const uint64_t x = ba[k] ^ bb[k];
+                uint32_t nb = x ? ((uint32_t)__builtin_clzll(x) >> 3) : 8u;
+                const uint32_t room = (8 * k < maxBack) ? maxBack - 8 * k : 0u;
+                nb = min(nb, room);
+                if (!stop) back += nb;
+                if (nb < 8u) stop = true;
+            }
+            if (fwd >= ZS_MINMATCH) {
+                const int gain = (int)(fwd + back) * 4 - (int)zs_highbit(off + 1) - 4 * ((int)(q - back) - (int)ip) - (int)(q - ip);
+                key = ((gain + 2048) << 3) | (int)(7u - sub);
             }
         }
-        // group reductions through ballots: first lane of the group that stopped early
-        const uint64_t stopF = __ballot(nbF < 8u);
-        const uint64_t stopB = __ballot(nbB < 4u);
-        const uint32_t gF = (uint32_t)((stopF >> (8 * grp)) & 0xFFu);
-        const uint32_t gB = (uint32_t)((stopB >> (8 * grp)) & 0xFFu);
-        const uint32_t fF = gF ? (uint32_t)__builtin_ctz(gF) : 8u;
-        const uint32_t fB = gB ? (uint32_t)__builtin_ctz(gB) : 8u;
-        const uint32_t partF = (uint32_t)__shfl((int)nbF, (int)(8 * grp + (fF & 7u)));
-        const uint32_t partB = (uint32_t)__shfl((int)nbB, (int)(8 * grp + (fB & 7u)));
-        const uint32_t fwd = (fF < 8u) ? 8u * fF + partF : ZS_FCAP;
-        const uint32_t back = (fB < 8u) ? 4u * fB + partB : ZS_BCAP;
-        // note: lanes beyond cap / maxBack report nb == 0 < 8/4, so they stop the count where the limit is
-        int key = 0;
-        if (active && fwd >= ZS_MINMATCH) {
-            const int gain = (int)(fwd + back) * 4 - (int)zs_highbit(off + 1) - 4 * ((int)(q - back) - (int)ip) - (int)(q - ip);
-            key = ((gain + 2048) << 3) | (int)(7u - grp);
-        }
-        // wave max over groups (all lanes of a group hold the same key)
         int best = key;
-        best = max(best, __shfl_xor(best, 8));
-        best = max(best, __shfl_xor(best, 16));
-        best = max(best, __shfl_xor(best, 32));
-        if (best == 0) { ip = wend; continue; }
-        const uint32_t bg = 7u - (uint32_t)(best & 7);
-        const uint32_t bq = (uint32_t)__shfl((int)q, (int)(8 * bg));
-        const uint32_t boff = (uint32_t)__shfl((int)off, (int)(8 * bg));
-        uint32_t bfwd = (uint32_t)__shfl((int)fwd, (int)(8 * bg));
-        const uint32_t bback = (uint32_t)__shfl((int)back, (int)(8 * bg));
-        if (bfwd == ZS_FCAP) {
-            // long match: the whole wavefront extends it, 512 bytes per round
-            uint32_t pos = bq + ZS_FCAP;
-            while (pos < end) {
-                const uint32_t cap = end - pos;
-                const uint32_t fo = 8 * lane;
-                uint32_t nb = 0;
-                if (fo < cap) {
-                    const uint64_t a = load64_clamped(s, (int32_t)(pos + fo), n);
-                    const uint64_t b = load64_clamped(s, (int32_t)(pos - boff + fo), n);
-                    const uint64_t x = a ^ b;
-                    nb = x ? ((uint32_t)__builtin_ctzll(x) >> 3) : 8u;
-                    nb = min(nb, cap - fo);
+        best = max(best, __shfl_xor(best, 1));
+        best = max(best, __shfl_xor(best, 2));
+        best = max(best, __shfl_xor(best, 4));
+        const uint32_t bl = (lane & ~7u) + (7u - (uint32_t)(best & 7));      // lane holding the best candidate
+        const uint32_t bq = (uint32_t)__shfl((int)q, (int)bl);
+        const uint32_t boff = (uint32_t)__shfl((int)off, (int)bl);
+        uint32_t bfwd = (uint32_t)__shfl((int)fwd, (int)bl);
+        const uint32_t bback = (uint32_t)__shfl((int)back, (int)bl);
+        const bool took = run && best != 0;
+        // ---- long match: the walker's 8 lanes extend it, 128 bytes per round ----
+        bool need = took && bfwd == ZS_FCAP;
+        uint32_t pos = bq + ZS_FCAP;
+        while (__any(need)) {
+            uint32_t nb = 0;
+            if (need) {
+                const uint32_t cap = end - pos;            // pos < end while need
+                #pragma unroll
+                for (uint32_t h = 0; h < 2; h++) {
+                    const uint32_t fo = 16 * sub + 8 * h;
+                    uint32_t m = 0;
+                    if (fo < cap) {
+                        const uint64_t x = load64_fwd(s, pos + fo, n) ^ load64_fwd(s, pos - boff + fo, n);
+                        m = x ? ((uint32_t)__builtin_ctzll(x) >> 3) : 8u;
+                        m = min(m, cap - fo);
+                    }
+                    if (h == 0) nb = m; else if (nb == 8u) nb += m;
                 }
-                const uint64_t stop = __ballot(nb < 8u);
-                if (stop) {
-                    const uint32_t f = (uint32_t)__builtin_ctzll(stop);
-                    pos += 8 * f + (uint32_t)__shfl((int)nb, (int)f);
-                    break;
-                }
-                pos += 512;
             }
-            bfwd = pos - bq;
+            const uint64_t stopm = __ballot(nb < 16u);
+            const uint32_t g8 = (uint32_t)((stopm >> (8 * grp)) & 0xFFu);
+            const uint32_t f = g8 ? (uint32_t)__builtin_ctz(g8) : 0u;
+            const uint32_t part = (uint32_t)__shfl((int)nb, (int)((lane & ~7u) + f));
+            if (need) {
+                if (g8) { pos += 16 * f + part; need = false; }
+                else { pos += 128; if (pos >= end) { pos = end; need = false; } }
+            }
         }
-        if (lane == 0) {
-            ZsSeqRec r;
-            r.ll = (uint16_t)(bq - bback - anchor); r.ml = (uint16_t)(bback + bfwd); r.off = (uint16_t)boff; r.flags = (uint16_t)(bq - bback);   // flags: position of the match start
-            seqs[nseq] = r;
-        }
-        nseq++;
-        ip = bq + bfwd; anchor = ip;
+        if (took && bfwd == ZS_FCAP) bfwd = pos - bq;
+        if (took) {
+            if (sub == 0) {
+                ZsSeqRec r;
+                r.ll = (uint16_t)(bq - bback - anchor); r.ml = (uint16_t)(bback + bfwd); r.off = (uint16_t)boff; r.flags = (uint16_t)(bq - bback);   // flags: position of the match start
+                seqs[nseq] = r;
+            }
+            nseq++;
+            ip = bq + bfwd; anchor = ip;
+        } else if (run) ip = wend;
     }
-    if (lane == 0) { hdrAll[blockIdx.x].nseq = nseq; hdrAll[blockIdx.x].trailing = end - anchor; }
+    if (sub == 0) { ZsRangeHdr h; h.nseq = nseq; h.trailing = alive ? end - anchor : ((start < n) ? end - start : 0u); hdrAll[(size_t)blk * ZS_MAX_RANGES + grp] = h; }
 }

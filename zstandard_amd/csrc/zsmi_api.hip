@@ -114,7 +114,7 @@ struct zsmi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;
-    uint32_t maxBlocksInFlight = 2048;
+    uint32_t maxBlocksInFlight = 8192;
     // compress workspace
     DevBuf dBlocks, dChunks, dDist, dSeqs, dHdrs, dLits, dStreams, dPayload, dResults;
     PinBuf hBlocks, hChunks;
@@ -255,8 +255,8 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         const uint32_t block0 = hc[chunk0].firstBlock;
         const ZsBlockDesc *dB = (const ZsBlockDesc *)c->dBlocks.p + block0;
         LAUNCH(c, "k_lz_candidates", k_lz_candidates, dim3(nb), dim3(512), lds, (const uint8_t *)dSrc, dB, (uint16_t *)c->dDist.p, hashLog);
-        LAUNCH(c, "k_lz_walk", k_lz_walk, dim3(nb * ZS_MAX_RANGES), dim3(64), 0, (const uint8_t *)dSrc, dB, (const uint16_t *)c->dDist.p,
-               (ZsSeqRec *)c->dSeqs.p, (ZsRangeHdr *)c->dHdrs.p, look);
+        LAUNCH(c, "k_lz_walk", k_lz_walk, dim3((nb + ZS_WALK_WAVES - 1) / ZS_WALK_WAVES), dim3(64 * ZS_WALK_WAVES), 0, (const uint8_t *)dSrc, dB, (const uint16_t *)c->dDist.p,
+               (ZsSeqRec *)c->dSeqs.p, (ZsRangeHdr *)c->dHdrs.p, look, nb);
         LAUNCH(c, "k_encode_block", k_encode_block, dim3(nb), dim3(64), 0, (const uint8_t *)dSrc, dB, (ZsSeqRec *)c->dSeqs.p, (const ZsRangeHdr *)c->dHdrs.p,
                (uint8_t *)c->dLits.p, (uint8_t *)c->dStreams.p, (uint8_t *)c->dPayload.p, (ZsBlockResult *)c->dResults.p);
         LAUNCH(c, "k_assemble_frames", k_assemble_frames, dim3(chunk1 - chunk0), dim3(256), 0, (const uint8_t *)dSrc, (const ZsChunkDesc *)c->dChunks.p,
