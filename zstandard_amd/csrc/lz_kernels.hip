@@ -94,7 +94,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__
 // k_lz_walk : one wavefront per block; the 64 lanes are 8 independent walkers of 8 lanes, walker g
 // walks range g.  A walker step: its 8 lanes read dist[ip .. ip+64) (8 positions each), the first
 // LOOK positions holding a candidate go one per lane; a lane compares 64 bytes forward and 32 bytes
-// backward (into the pending literals) for its candidate with one round of loads, scores it, the
+// backward (into the pending literals) for its candidate with one round of loads (ZS_FCAP / ZS_BCAP bytes), scores it, the
 // best one of the walker becomes a sequence (extended by the walker's 8 lanes if it hit the 64-byte
 // cap).  Eight dependent chains per wavefront hide each other's memory latency.
 // Scalar statement: walkRange in oracle/zso_encoder.c.
@@ -169,32 +169,21 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ block
         uint32_t fwd = 0, back = 0;
         int key = 0;
         if (active) {
-            uint64_t fa[8], fb[8], ba[4], bb[4];
-            #pragma unroll
-            for (uint32_t k = 0; k < 8; k++) { fa[k] = load64_fwd(s, q + 8 * k, n); fb[k] = load64_fwd(s, q - off + 8 * k, n); }
-            #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) { ba[k] = load64_bwd(s, (int32_t)q - 8 * (int32_t)(k + 1)); bb[k] = load64_bwd(s, (int32_t)(q - off) - 8 * (int32_t)(k + 1)); }
+            // 16 bytes forward, 8 bytes backward, both sides: 6 loads
+            const uint64_t fa0 = load64_fwd(s, q, n), fa1 = load64_fwd(s, q + 8, n);
+            const uint64_t fb0 = load64_fwd(s, q - off, n), fb1 = load64_fwd(s, q - off + 8, n);
+            const uint64_t ba = load64_bwd(s, (int32_t)q - 8), bb = load64_bwd(s, (int32_t)(q - off) - 8);
             const uint32_t cap = min(end - q, ZS_FCAP);
-            bool stop = false;
-            #pragma unroll
-            for (uint32_t k = 0; k < 8; k++) {
-                const uint64_t x = fa[k] ^ fb[k];
-                uint32_t nb = x ? ((uint32_t)__builtin_ctzll(x) >> 3) : 8u;
-                const uint32_t room = (8 * k < cap) ? cap - 8 * k : 0u;
-                nb = min(nb, room);
-                if (!stop) fwd += nb;
-                if (nb < 8u) stop = true;
+            {
+                const uint64_t x0 = fa0 ^ fb0, x1 = fa1 ^ fb1;
+                const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
+                const uint32_t n1 = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u;
+                fwd = min((n0 < 8u) ? n0 : 8u + n1, cap);
             }
-            const uint32_t maxBack = min(min(q - anchor, q - off), ZS_BCAP);
-            stop = false;
-            #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) {
-                const uint64_t x = ba[k] ^ bb[k];
-                uint32_t nb = x ? ((uint32_t)__builtin_clzll(x) >> 3) : 8u;
-                const uint32_t room = (8 * k < maxBack) ? maxBack - 8 * k : 0u;
-                nb = min(nb, room);
-                if (!stop) back += nb;
-                if (nb < 8u) stop = true;
+            {
+                const uint32_t maxBack = min(min(q - anchor, q - off), ZS_BCAP);
+                const uint64_t x = ba ^ bb;
+                back = min(x ? ((uint32_t)__builtin_clzll(x) >> 3) : 8u, maxBack);
             }
             if (fwd >= ZS_MINMATCH) {
                 const int gain = (int)(fwd + back) * 4 - (int)zs_highbit(off + 1) - 4 * ((int)(q - back) - (int)ip) - (int)(q - ip);
