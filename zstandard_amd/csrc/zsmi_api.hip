@@ -115,8 +115,13 @@ struct zsmi_ctx {
     hipStream_t stream = nullptr;
     bool ownStream = false;
     uint32_t maxBlocksInFlight = 8192;
-    // compress workspace
-    DevBuf dBlocks, dChunks, dDist, dSeqs, dHdrs, dLits, dStreams, dPayload, dResults;
+    // compress workspace: plan (shared) + one scratch set per internal stream ("lane")
+    DevBuf dBlocks, dChunks;
+    struct Scratch { DevBuf dDist, dSeqs, dHdrs, dLits, dStreams, dPayload, dResults; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
+    static const int kMaxLanes = 8;
+    Scratch lanes[kMaxLanes];
+    int nLanes = 1;
+    hipEvent_t evStart = nullptr;
     PinBuf hBlocks, hChunks;
     std::vector<uint64_t> planKey;       // copy of (srcOffsets, srcSizes, dstOffsets) the device-side plan was built from
     uint64_t planBlocks = 0; uint32_t planMaxChunkBlocks = 1;
@@ -136,12 +141,13 @@ static hipEvent_t getEvent(zsmi_ctx *c)
     if (!c->eventPool.empty()) { hipEvent_t e = c->eventPool.back(); c->eventPool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
-#define LAUNCH(ctx, name, kernel, grid, block, lds, ...) do { \
+#define LAUNCH_ON(ctx, strm, name, kernel, grid, block, lds, ...) do { \
         TimedLaunch tl_{name, nullptr, nullptr}; \
-        if ((ctx)->timing) { tl_.a = getEvent(ctx); tl_.b = getEvent(ctx); (void)hipEventRecord(tl_.a, (ctx)->stream); } \
-        hipLaunchKernelGGL(kernel, grid, block, lds, (ctx)->stream, __VA_ARGS__); \
-        if ((ctx)->timing) { (void)hipEventRecord(tl_.b, (ctx)->stream); (ctx)->launches.push_back(tl_); } \
+        if ((ctx)->timing) { tl_.a = getEvent(ctx); tl_.b = getEvent(ctx); (void)hipEventRecord(tl_.a, (strm)); } \
+        hipLaunchKernelGGL(kernel, grid, block, lds, (strm), __VA_ARGS__); \
+        if ((ctx)->timing) { (void)hipEventRecord(tl_.b, (strm)); (ctx)->launches.push_back(tl_); } \
     } while (0)
+#define LAUNCH(ctx, name, kernel, grid, block, lds, ...) LAUNCH_ON(ctx, (ctx)->stream, name, kernel, grid, block, lds, __VA_ARGS__)
 
 extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
 {
@@ -155,20 +161,34 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     // the candidate kernel uses up to 128 KiB of dynamic LDS
     (void)hipFuncSetAttribute((const void *)k_lz_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
+    if (const char *e = getenv("ZSMI_LANES")) { long v = atol(e); if (v >= 1 && v <= zsmi_ctx::kMaxLanes) c->nLanes = (int)v; }
+    // sub-batches of one call run on internal streams so that the latency-bound kernels of different sub-batches overlap
+    for (int i = 0; i < c->nLanes; i++) {
+        if (hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->lanes[i].done, hipEventDisableTiming) != hipSuccess) { c->nLanes = i; break; }
+    }
+    if (c->nLanes == 0 || hipEventCreateWithFlags(&c->evStart, hipEventDisableTiming) != hipSuccess) { zsmi_freeCtx(c); return nullptr; }
     return c;
 }
 extern "C" void zsmi_freeCtx(zsmi_ctx *c)
 {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dDist, &c->dSeqs, &c->dHdrs, &c->dLits, &c->dStreams, &c->dPayload, &c->dResults,
-                       &c->dItems, &c->dLitScratch, &c->sSrc, &c->sDst, &c->sSizes }) b->release();
+    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dItems, &c->dLitScratch, &c->sSrc, &c->sDst, &c->sSizes }) b->release();
+    for (int i = 0; i < zsmi_ctx::kMaxLanes; i++) {
+        zsmi_ctx::Scratch &L = c->lanes[i];
+        if (L.stream) (void)hipStreamSynchronize(L.stream);
+        for (DevBuf *b : { &L.dDist, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dPayload, &L.dResults }) b->release();
+        if (L.done) (void)hipEventDestroy(L.done);
+        if (L.stream) (void)hipStreamDestroy(L.stream);
+    }
+    if (c->evStart) (void)hipEventDestroy(c->evStart);
     for (PinBuf *b : { &c->hBlocks, &c->hChunks, &c->hItems }) b->release();
     for (auto &tl : c->launches) { (void)hipEventDestroy(tl.a); (void)hipEventDestroy(tl.b); }
     for (auto e : c->eventPool) (void)hipEventDestroy(e);
     if (c->ownStream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
+extern "C" void zsmi_freeCtx(zsmi_ctx *c);
 extern "C" int zsmi_sync(zsmi_ctx *c)
 {
     if (!c) return ZSMI_error_init_missing;
@@ -241,27 +261,40 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         c->planKey.swap(key); c->planBlocks = nBlocks; c->planMaxChunkBlocks = maxChunkBlocks;
     }
     const ZsChunkDesc *hc = (const ZsChunkDesc *)c->hChunks.p;
-    // scratch for one sub-batch of whole chunks
-    const uint32_t cap = (uint32_t)std::min<uint64_t>(nBlocks, std::max(c->maxBlocksInFlight, maxChunkBlocks));
-    if (!c->dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2) || !c->dSeqs.reserve((size_t)cap * ZS_MAX_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
-        !c->dHdrs.reserve((size_t)cap * ZS_MAX_RANGES * sizeof(ZsRangeHdr)) || !c->dLits.reserve((size_t)cap * (ZS_BLOCK_MAX + 64)) ||
-        !c->dStreams.reserve((size_t)cap * 4 * ZS_STREAM_STRIDE) || !c->dPayload.reserve((size_t)cap * ZS_PAYLOAD_STRIDE) ||
-        !c->dResults.reserve((size_t)cap * sizeof(ZsBlockResult))) return ZSMI_error_memory_allocation;
+    // sub-batches of whole chunks, dealt round-robin to the internal streams; each stream owns a scratch set
+    const int nLanes = (int)std::min<uint64_t>((uint64_t)c->nLanes, std::max<uint64_t>(1, nBlocks / 256));
+    uint32_t cap = (uint32_t)std::min<uint64_t>((nBlocks + nLanes - 1) / nLanes, std::max<uint32_t>(64, c->maxBlocksInFlight / (uint32_t)nLanes));
+    if (cap < maxChunkBlocks) cap = maxChunkBlocks;
+    for (int i = 0; i < nLanes; i++) {
+        zsmi_ctx::Scratch &L = c->lanes[i];
+        if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2) || !L.dSeqs.reserve((size_t)cap * ZS_MAX_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
+            !L.dHdrs.reserve((size_t)cap * ZS_MAX_RANGES * sizeof(ZsRangeHdr)) || !L.dLits.reserve((size_t)cap * (ZS_BLOCK_MAX + 64)) ||
+            !L.dStreams.reserve((size_t)cap * 4 * ZS_STREAM_STRIDE) || !L.dPayload.reserve((size_t)cap * ZS_PAYLOAD_STRIDE) ||
+            !L.dResults.reserve((size_t)cap * sizeof(ZsBlockResult))) return ZSMI_error_memory_allocation;
+    }
+    if (hipEventRecord(c->evStart, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    for (int i = 0; i < nLanes; i++) if (hipStreamWaitEvent(c->lanes[i].stream, c->evStart, 0) != hipSuccess) return ZSMI_error_GENERIC;
     const size_t lds = (size_t)(ZS_MAX_RANGES << hashLog) * sizeof(uint16_t);
-    uint32_t chunk0 = 0;
+    uint32_t chunk0 = 0; int turn = 0;
     while (chunk0 < n) {
         uint32_t chunk1 = chunk0, nb = 0;
         while (chunk1 < n && (nb == 0 || nb + hc[chunk1].nBlocks <= cap)) { nb += hc[chunk1].nBlocks; chunk1++; }
         const uint32_t block0 = hc[chunk0].firstBlock;
         const ZsBlockDesc *dB = (const ZsBlockDesc *)c->dBlocks.p + block0;
-        LAUNCH(c, "k_lz_candidates", k_lz_candidates, dim3(nb), dim3(512), lds, (const uint8_t *)dSrc, dB, (uint16_t *)c->dDist.p, hashLog);
-        LAUNCH(c, "k_lz_walk", k_lz_walk, dim3((nb + ZS_WALK_WAVES - 1) / ZS_WALK_WAVES), dim3(64 * ZS_WALK_WAVES), 0, (const uint8_t *)dSrc, dB, (const uint16_t *)c->dDist.p,
-               (ZsSeqRec *)c->dSeqs.p, (ZsRangeHdr *)c->dHdrs.p, look, nb);
-        LAUNCH(c, "k_encode_block", k_encode_block, dim3(nb), dim3(64), 0, (const uint8_t *)dSrc, dB, (ZsSeqRec *)c->dSeqs.p, (const ZsRangeHdr *)c->dHdrs.p,
-               (uint8_t *)c->dLits.p, (uint8_t *)c->dStreams.p, (uint8_t *)c->dPayload.p, (ZsBlockResult *)c->dResults.p);
-        LAUNCH(c, "k_assemble_frames", k_assemble_frames, dim3(chunk1 - chunk0), dim3(256), 0, (const uint8_t *)dSrc, (const ZsChunkDesc *)c->dChunks.p,
-               (const ZsBlockDesc *)c->dBlocks.p, (const ZsBlockResult *)c->dResults.p, (const uint8_t *)c->dPayload.p, block0, (uint8_t *)dDst, dDstSizes, chunk0);
+        zsmi_ctx::Scratch &L = c->lanes[turn % nLanes]; turn++;
+        hipStream_t st = L.stream;
+        LAUNCH_ON(c, st, "k_lz_candidates", k_lz_candidates, dim3(nb), dim3(512), lds, (const uint8_t *)dSrc, dB, (uint16_t *)L.dDist.p, hashLog);
+        LAUNCH_ON(c, st, "k_lz_walk", k_lz_walk, dim3((nb + ZS_WALK_WAVES - 1) / ZS_WALK_WAVES), dim3(64 * ZS_WALK_WAVES), 0, (const uint8_t *)dSrc, dB, (const uint16_t *)L.dDist.p,
+                  (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look, nb);
+        LAUNCH_ON(c, st, "k_encode_block", k_encode_block, dim3(nb), dim3(64), 0, (const uint8_t *)dSrc, dB, (ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
+                  (uint8_t *)L.dLits.p, (uint8_t *)L.dStreams.p, (uint8_t *)L.dPayload.p, (ZsBlockResult *)L.dResults.p);
+        LAUNCH_ON(c, st, "k_assemble_frames", k_assemble_frames, dim3(chunk1 - chunk0), dim3(256), 0, (const uint8_t *)dSrc, (const ZsChunkDesc *)c->dChunks.p,
+                  (const ZsBlockDesc *)c->dBlocks.p, (const ZsBlockResult *)L.dResults.p, (const uint8_t *)L.dPayload.p, block0, (uint8_t *)dDst, dDstSizes, chunk0);
         chunk0 = chunk1;
+    }
+    for (int i = 0; i < nLanes; i++) {
+        if (hipEventRecord(c->lanes[i].done, c->lanes[i].stream) != hipSuccess) return ZSMI_error_GENERIC;
+        if (hipStreamWaitEvent(c->stream, c->lanes[i].done, 0) != hipSuccess) return ZSMI_error_GENERIC;
     }
     return hipGetLastError() == hipSuccess ? 0 : ZSMI_error_GENERIC;
 }
@@ -434,7 +467,8 @@ extern "C" int zsmi_dbg_copyScratch(zsmi_ctx *c, int which, void *hostDst, size_
 {
     if (!c) return -1;
     (void)hipStreamSynchronize(c->stream);
-    DevBuf *b = which == 0 ? &c->dDist : which == 1 ? &c->dSeqs : which == 2 ? &c->dHdrs : &c->dResults;
+    zsmi_ctx::Scratch &L0 = c->lanes[0];
+    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : &L0.dResults;
     if (bytes > b->cap) return -2;
     return hipMemcpy(hostDst, b->p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
