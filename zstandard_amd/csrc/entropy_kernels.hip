@@ -45,8 +45,8 @@ struct FseCT {                       // encoding table of one symbol type
     uint32_t tableLog;
     uint32_t rle;
 };
-struct K3Lds {
-    uint32_t count[256];             // literal histogram, later sequence-code counts (3 x 64)
+struct K3Lds {                       // literals kernel
+    uint32_t count[256];             // literal histogram
     uint8_t  nbBits[256];
     uint16_t code[256];
     uint32_t leafW[256];
@@ -55,9 +55,22 @@ struct K3Lds {
     uint8_t  weights[256];
     union {
         struct { uint32_t pkg[10][256]; uint32_t S[512]; uint32_t npk[12]; } pm;      // package-merge (levels 2..11)
-        struct { FseCT ct[3]; int16_t norm[64]; uint8_t tableSymbol[512]; uint32_t cumul[66];
-                 uint8_t tileCode[3][64]; uint32_t tileState[3][64]; } fse;
+        struct { FseCT ct[1]; int16_t norm[64]; uint8_t tableSymbol[512]; uint32_t cumul[66]; } fse;   // weights table
     } u;
+    uint32_t tile[208];              // bit-packing tile
+    uint32_t misc[16];
+    uint32_t rngN[8], rngCarry[8], rngStart[9];
+};
+struct SeqLds {                      // sequences kernel
+    uint32_t count[192];             // code counts: [0..63] LL, [64..127] OF, [128..191] ML
+    FseCT ct[3];                     // LL, OF, ML
+    int16_t norm[64];
+    uint8_t tableSymbol[512];
+    uint32_t cumul[66];
+    uint32_t symCount[64];           // per-symbol running cell counter (table build)
+    uint32_t opNb[3][64];            // per tile: deltaNbBits of each sequence's code
+    int32_t  opFind[3][64];          // per tile: deltaFindState
+    uint32_t tileState[3][64];       // per tile: state bits out (value | nbBits << 16)
     uint32_t tile[208];              // bit-packing tile
     uint32_t misc[16];
     uint32_t rngN[8], rngCarry[8], rngStart[9];
@@ -431,16 +444,35 @@ __device__ static uint32_t huffEncodeStream(K3Lds &L, uint8_t *tmp, const uint8_
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_encode_block
+// per-block result of the two encode kernels, consumed by k_assemble_frames
 // ---------------------------------------------------------------------------------------------
-#define ZS_PAYLOAD_STRIDE (ZS_BLOCK_MAX + 1024u)
+struct ZsBlockMeta { uint32_t type;       // 0 raw, 1 rle, 2 literal + sequence sections present
+                     uint32_t rleByte; uint32_t litSecSize; uint32_t seqSecSize; };   // seqSecSize 0xFFFFFFFF: section failed / overflowed
+#define ZS_LITSEC_STRIDE  (ZS_BLOCK_MAX + 1024u)
+#define ZS_SEQSEC_STRIDE  (ZS_BLOCK_MAX + 4096u)
 #define ZS_STREAM_STRIDE  (24u * 1024u)          // per Huffman stream scratch: 16384 symbols * 11 bits = 22528 B max
 
+__device__ __forceinline__ void loadRanges(const ZsRangeHdr *hdr, uint32_t *rngN, uint32_t *rngCarry, uint32_t *rngStart, uint32_t *lastLits)
+{
+    uint32_t carry = 0, tot = 0;
+    for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) {
+        const uint32_t ns = hdr[r].nseq, tr = hdr[r].trailing;
+        rngN[r] = ns; rngCarry[r] = carry; rngStart[r] = tot;
+        carry = ns ? tr : carry + tr;
+        tot += ns;
+    }
+    rngStart[8] = tot; *lastLits = carry;
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_encode_literals : one wavefront per block.  Block type (raw for tiny blocks, RLE block), literal
+// gather + histogram, Huffman (package-merge), literals section  -> litSec[], meta.{type, rleByte, litSecSize}
+// ---------------------------------------------------------------------------------------------
 extern "C" __global__ void __launch_bounds__(64)
-k_encode_block(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ blocks,
-               ZsSeqRec *__restrict__ seqAll, const ZsRangeHdr *__restrict__ hdrAll,
-               uint8_t *__restrict__ litsAll, uint8_t *__restrict__ streamAll, uint8_t *__restrict__ payloadAll,
-               ZsBlockResult *__restrict__ results)
+k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ blocks,
+                  const ZsSeqRec *__restrict__ seqAll, const ZsRangeHdr *__restrict__ hdrAll,
+                  uint8_t *__restrict__ litsAll, uint8_t *__restrict__ streamAll, uint8_t *__restrict__ litSecAll,
+                  ZsBlockMeta *__restrict__ metas)
 {
     __shared__ K3Lds L;
     const uint32_t blk = blockIdx.x;
@@ -448,75 +480,28 @@ k_encode_block(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ 
     const ZsBlockDesc bd = blocks[blk];
     const uint8_t *s = src + bd.srcOff;
     const uint32_t n = bd.size;
-    ZsSeqRec *seqBase = seqAll + (size_t)blk * ZS_MAX_RANGES * ZS_SEQ_PER_RANGE;
+    const ZsSeqRec *seqBase = seqAll + (size_t)blk * ZS_MAX_RANGES * ZS_SEQ_PER_RANGE;
     const ZsRangeHdr *hdr = hdrAll + (size_t)blk * ZS_MAX_RANGES;
     uint8_t *lits = litsAll + (size_t)blk * (ZS_BLOCK_MAX + 64);
     uint8_t *streams = streamAll + (size_t)blk * 4 * ZS_STREAM_STRIDE;
-    uint8_t *payload = payloadAll + (size_t)blk * ZS_PAYLOAD_STRIDE;
+    uint8_t *payload = litSecAll + (size_t)blk * ZS_LITSEC_STRIDE;
     const uint32_t cap = n + 512;
 
-    #define FINISH(tp, sz, rb) do { if (lane == 0) { ZsBlockResult r_; r_.payloadSize = (sz); r_.type = (tp); r_.rleByte = (rb); r_.pad = 0; results[blk] = r_; } return; } while (0)
+    #define FINISH(tp, lsz, rb) do { if (lane == 0) { metas[blk].type = (tp); metas[blk].rleByte = (rb); metas[blk].litSecSize = (lsz); } return; } while (0)
 
     if (n == 0) FINISH(0, 0, 0);
     {   // RLE block: every byte equal (ZStdDecompress.cs:1945-1950 on the decode side)
         const uint32_t b0 = s[0];
         bool diff = false;
         for (uint32_t i = lane; i < n; i += 64) diff |= (s[i] != b0);
-        if (!__ballot(diff)) FINISH(1, 1, b0);
+        if (!__ballot(diff)) FINISH(1, 0, b0);
     }
-    if (n < 16) FINISH(0, n, 0);
+    if (n < 16) FINISH(0, 0, 0);
 
-    // ---- sequences of the 8 ranges, carries ----
-    if (lane == 0) {
-        uint32_t carry = 0, tot = 0;
-        for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) {
-            const uint32_t ns = hdr[r].nseq, tr = hdr[r].trailing;
-            L.rngN[r] = ns; L.rngCarry[r] = carry; L.rngStart[r] = tot;
-            carry = ns ? tr : carry + tr;
-            tot += ns;
-        }
-        L.rngStart[8] = tot; L.misc[1] = carry;
-    }
+    if (lane == 0) loadRanges(hdr, L.rngN, L.rngCarry, L.rngStart, &L.misc[1]);
     __syncthreads();
-    const uint32_t nseq = L.rngStart[8], lastLits = L.misc[1];
+    const uint32_t lastLits = L.misc[1];
     const uint32_t *rngN = L.rngN, *rngCarry = L.rngCarry;
-
-    // ---- recent-offset codes (inverse of ZStdDecompress.cs:1509-1530): sequential over sequences,
-    //      64 at a time through readlane.  Result (0 = new offset, 1..3 = field value) goes to ml bits 14-15. ----
-    {
-        uint32_t rep0, rep1, rep2;
-        if (bd.firstInChunk) { rep0 = 1; rep1 = 4; rep2 = 8; } else { rep0 = 0xFFFFFFF1u; rep1 = 0xFFFFFFF2u; rep2 = 0xFFFFFFF3u; }
-        #pragma unroll 1
-        for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) {
-            const uint32_t ns = rngN[r];
-            ZsSeqRec *sq = seqBase + (size_t)r * ZS_SEQ_PER_RANGE;
-            for (uint32_t base = 0; base < ns; base += 64) {
-                const uint32_t k = base + lane;
-                uint32_t off = 0, ll = 0, ml = 0;
-                if (k < ns) { const ZsSeqRec rec = sq[k]; off = rec.off; ll = rec.ll; ml = rec.ml; if (k == 0) ll += rngCarry[r]; }
-                uint32_t myval = 0;
-                const uint32_t cnt = min(64u, ns - base);
-                for (uint32_t t = 0; t < cnt; t++) {
-                    const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)off, (int)t);
-                    const uint32_t l = (uint32_t)__builtin_amdgcn_readlane((int)ll, (int)t);
-                    uint32_t val;
-                    if (l) {
-                        if (o == rep0) val = 1;
-                        else if (o == rep1) { val = 2; rep1 = rep0; rep0 = o; }
-                        else if (o == rep2) { val = 3; rep2 = rep1; rep1 = rep0; rep0 = o; }
-                        else { val = 0; rep2 = rep1; rep1 = rep0; rep0 = o; }
-                    } else {
-                        if (o == rep1) { val = 1; rep1 = rep0; rep0 = o; }
-                        else if (o == rep2) { val = 2; rep2 = rep1; rep1 = rep0; rep0 = o; }
-                        else { val = 0; rep2 = rep1; rep1 = rep0; rep0 = o; }
-                    }
-                    if (lane == t) myval = val;
-                }
-                if (k < ns) sq[k].ml = (uint16_t)(ml | (myval << 14));
-            }
-        }
-    }
-    __syncthreads();
 
     // ---- literals: gather into lits[], histogram ----
     for (uint32_t i = lane; i < 256; i += 64) L.count[i] = 0;
@@ -534,14 +519,13 @@ k_encode_block(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ 
                 const uint32_t incl = wave_incl_scan(ll);
                 const uint32_t dstOff = nlit + incl - ll;
                 const uint32_t srcPos = mpos - ll;
-                // short runs by their own lane, long runs by the whole wavefront
+                // short runs by their own lane (one round of loads), long runs by the whole wavefront
                 if (ll && ll <= 16) {
-                    // one round of loads for the whole run: 16 bytes ending at the match start (srcPos + 16 <= n is not
-                    // guaranteed, srcPos + ll <= n is: read the 16 bytes that END at srcPos + ll when possible)
                     const uint32_t endPos = srcPos + ll;
-                    uint64_t w0, w1; uint32_t skip;
-                    if (endPos >= 16) { w0 = zs_load64(s + endPos - 16); w1 = zs_load64(s + endPos - 8); skip = 16 - ll; }
-                    else { w0 = 0; w1 = 0; skip = 16 - ll; for (uint32_t j = 0; j < ll; j++) { const uint64_t c = s[srcPos + j]; const uint32_t bi = skip + j; if (bi < 8) w0 |= c << (8 * bi); else w1 |= c << (8 * (bi - 8)); } }
+                    const uint32_t skip = 16 - ll;
+                    uint64_t w0 = 0, w1 = 0;
+                    if (endPos >= 16) { w0 = zs_load64(s + endPos - 16); w1 = zs_load64(s + endPos - 8); }
+                    else for (uint32_t j = 0; j < ll; j++) { const uint64_t c = s[srcPos + j]; const uint32_t bi = skip + j; if (bi < 8) w0 |= c << (8 * bi); else w1 |= c << (8 * (bi - 8)); }
                     for (uint32_t j = 0; j < ll; j++) {
                         const uint32_t bi = skip + j;
                         const uint8_t c = (uint8_t)((bi < 8 ? w0 >> (8 * bi) : w1 >> (8 * (bi - 8))));
@@ -627,7 +611,6 @@ k_encode_block(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ 
         }
         if (!done) {
             const uint32_t lh = 1 + (nlit > 31) + (nlit > 4095);
-            if (lh + nlit > cap) FINISH(0, n, 0);
             if (lane == 0) {
                 if (lh == 1) payload[0] = (uint8_t)(nlit << 3);
                 else if (lh == 2) { const uint32_t h = (1 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); }
@@ -638,92 +621,238 @@ k_encode_block(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ 
         }
     }
     __syncthreads();
-    if (cap - litSecSize < 4) FINISH(0, n, 0);
+    FINISH(2, litSecSize, 0);
+    #undef FINISH
+}
+
+// ---------------------------------------------------------------------------------------------
+// k_encode_sequences : one wavefront per block.  Repcodes (parallel: two last-index scans), code
+// histograms, tables (normalisation and encoding tables built by all lanes), bitstream
+// -> seqSec[], meta.seqSecSize
+// ---------------------------------------------------------------------------------------------
+// exclusive "last lane below me with flag" : returns lane index or -1
+__device__ __forceinline__ int lastFlagBelow(bool flag)
+{
+    const uint64_t m = __ballot(flag);
+    const uint32_t lane = (uint32_t)zs_lane();
+    const uint64_t below = lane ? (m & ((1ull << lane) - 1)) : 0ull;
+    return below ? 63 - __builtin_clzll(below) : -1;
+}
+
+// normalise counts to 2^tableLog, all lanes (lane s owns symbol s); scalar statement: normalizeCounts in the oracle
+__device__ static void normalizeCountsWave(int16_t *norm, uint32_t tableLog, const uint32_t *count, uint32_t total, uint32_t maxSym)
+{
+    const uint32_t lane = (uint32_t)zs_lane();
+    const uint32_t tableSize = 1u << tableLog;
+    const uint32_t c = (lane <= maxSym) ? count[lane] : 0u;
+    uint32_t p = 0;
+    if (c) {
+        const uint64_t scaled = (uint64_t)c * tableSize;
+        p = (uint32_t)(scaled / total);
+        const uint32_t rem = (uint32_t)(scaled % total);
+        if (2 * (uint64_t)rem >= total) p++;
+        if (p == 0) p = 1;
+    }
+    int still = (int)tableSize - (int)wave_sum(p);
+    // largest: first symbol holding the maximum
+    { const uint32_t key = (p << 6) | (63u - lane); const uint32_t best = wave_max(key); const uint32_t li = 63u - (best & 63u);
+      if (still > 0 && lane == li) p += (uint32_t)still; }
+    while (still < 0) {
+        const uint32_t key = (p > 1) ? ((p << 6) | (63u - lane)) : 0u;
+        const uint32_t best = wave_max(key);
+        const uint32_t li = 63u - (best & 63u);
+        if (lane == li) p--;
+        still++;
+    }
+    if (lane <= maxSym) norm[lane] = (int16_t)p;
+    __syncthreads();
+}
+
+// encoding table from a distribution without -1 entries, all lanes.  Cell order is the decoder's
+// (ZStdDecompress.cs:993-1013): with no low-probability area the j-th laid cell is (j * step) mod size.
+__device__ static void buildCTableWave(SeqLds &L, FseCT &ct, const int16_t *norm, uint32_t maxSym, uint32_t tableLog)
+{
+    const uint32_t lane = (uint32_t)zs_lane();
+    const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    const uint32_t nv = (lane <= maxSym) ? (uint32_t)norm[lane] : 0u;
+    const uint32_t incl = wave_incl_scan(nv);
+    const uint32_t excl = incl - nv;
+    L.cumul[lane] = excl; if (lane == 63) L.cumul[64] = incl;
+    L.symCount[lane] = excl;
+    if (lane <= maxSym) {
+        if (nv == 0) { ct.deltaNbBits[lane] = ((tableLog + 1) << 16) - (1u << tableLog); ct.deltaFindState[lane] = 0; }
+        else if (nv == 1) { ct.deltaNbBits[lane] = (tableLog << 16) - (1u << tableLog); ct.deltaFindState[lane] = (int)excl - 1; }
+        else { const uint32_t maxBitsOut = tableLog - zs_highbit(nv - 1); ct.deltaNbBits[lane] = (maxBitsOut << 16) - (nv << maxBitsOut); ct.deltaFindState[lane] = (int)excl - (int)nv; }
+    }
+    if (lane == 0) { ct.tableLog = tableLog; ct.rle = 0; }
+    __syncthreads();
+    for (uint32_t j = lane; j < tableSize; j += 64) {
+        // symbol owning slot j : last s with cumul[s] <= j
+        uint32_t lo = 0, hi = maxSym + 1;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.cumul[mid] <= j) lo = mid; else hi = mid; }
+        L.tableSymbol[(j * step) & tableMask] = (uint8_t)lo;
+    }
+    __syncthreads();
+    // stateTable[cumul[sym] + (rank of cell u among the cells of sym)] = tableSize + u, cells taken in ascending u
+    for (uint32_t base = 0; base < tableSize; base += 64) {
+        const uint32_t u = base + lane;
+        const bool in = u < tableSize;
+        const uint32_t sym = in ? L.tableSymbol[u] : 0xFFFFu;
+        uint64_t todo = __ballot(in);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t ls = (uint32_t)__shfl((int)sym, leader);
+            const uint64_t same = __ballot(in && sym == ls);
+            if (in && sym == ls) {
+                const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1));
+                ct.stateTable[L.symCount[ls] + rank] = (uint16_t)(tableSize + u);
+            }
+            __syncthreads();
+            if (lane == (uint32_t)leader) L.symCount[ls] += (uint32_t)__popcll(same);
+            __syncthreads();
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+}
+
+extern "C" __global__ void __launch_bounds__(64)
+k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict__ seqAll, const ZsRangeHdr *__restrict__ hdrAll,
+                   uint8_t *__restrict__ seqSecAll, ZsBlockMeta *__restrict__ metas)
+{
+    __shared__ SeqLds L;
+    const uint32_t blk = blockIdx.x;
+    const uint32_t lane = (uint32_t)zs_lane();
+    const ZsBlockDesc bd = blocks[blk];
+    const uint32_t n = bd.size;
+    ZsSeqRec *seqBase = seqAll + (size_t)blk * ZS_MAX_RANGES * ZS_SEQ_PER_RANGE;
+    const ZsRangeHdr *hdr = hdrAll + (size_t)blk * ZS_MAX_RANGES;
+    uint8_t *out = seqSecAll + (size_t)blk * ZS_SEQSEC_STRIDE;         // 4-byte aligned
+    const uint32_t cap = n + 512;
+
+    #define FINISH(sz) do { if (lane == 0) metas[blk].seqSecSize = (sz); return; } while (0)
+    if (n < 16) FINISH(0xFFFFFFFFu);
+
+    if (lane == 0) loadRanges(hdr, L.rngN, L.rngCarry, L.rngStart, &L.misc[1]);
+    for (uint32_t i = lane; i < 192; i += 64) L.count[i] = 0;
+    __syncthreads();
+    const uint32_t nseq = L.rngStart[8];
+    const uint32_t *rngN = L.rngN, *rngCarry = L.rngCarry;
 
     // ---- sequences section header (inverse of DecodeSeqHeaders, ZStdDecompress.cs:1110-1180) ----
-    uint8_t *op = payload + litSecSize;
-    uint8_t *const oend = payload + cap;
+    uint32_t hdrBytes = (nseq < 128) ? 1 : (nseq < 0x7F00 ? 2 : 3);
     if (lane == 0) {
-        if (nseq < 128) op[0] = (uint8_t)nseq;
-        else if (nseq < 0x7F00) { op[0] = (uint8_t)((nseq >> 8) + 0x80); op[1] = (uint8_t)nseq; }
-        else { op[0] = 0xFF; op[1] = (uint8_t)(nseq - 0x7F00); op[2] = (uint8_t)((nseq - 0x7F00) >> 8); }
+        if (nseq < 128) out[0] = (uint8_t)nseq;
+        else if (nseq < 0x7F00) { out[0] = (uint8_t)((nseq >> 8) + 0x80); out[1] = (uint8_t)nseq; }
+        else { out[0] = 0xFF; out[1] = (uint8_t)(nseq - 0x7F00); out[2] = (uint8_t)((nseq - 0x7F00) >> 8); }
     }
-    op += (nseq < 128) ? 1 : (nseq < 0x7F00 ? 2 : 3);
-    if (nseq == 0) {
-        const uint32_t total = (uint32_t)(op - payload);
-        __syncthreads();
-        if (total < n) FINISH(2, total, 0); else FINISH(0, n, 0);
-    }
+    if (nseq == 0) FINISH(hdrBytes);
 
-    // ---- code histograms ----
-    uint32_t *cnt = L.count;                     // [0..63] LL, [64..127] OF, [128..191] ML
-    for (uint32_t i = lane; i < 192; i += 64) cnt[i] = 0;
-    __syncthreads();
-    #pragma unroll 1
-    for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) {
-        const uint32_t ns = rngN[r];
-        const ZsSeqRec *sq = seqBase + (size_t)r * ZS_SEQ_PER_RANGE;
-        for (uint32_t k = lane; k < ns; k += 64) {
-            const ZsSeqRec rec = sq[k];
-            uint32_t ll = rec.ll; if (k == 0) ll += rngCarry[r];
-            const uint32_t ml = rec.ml & 0x3FFFu, rep = rec.ml >> 14;
-            const uint32_t val = rep ? rep : (uint32_t)rec.off + 3;
-            atomicAdd(&cnt[llCodeOf(ll)], 1u);
-            atomicAdd(&cnt[64 + zs_highbit(val)], 1u);
-            atomicAdd(&cnt[128 + mlCodeOf(ml - 3)], 1u);
-        }
-    }
-    __syncthreads();
-
-    // ---- modes, tables (lane 0) ----
-    uint8_t *const modes = op; op += 1;
-    if (lane == 0) {
-        uint32_t modeByte = 0; uint8_t *o = op; bool fail = false;
-        for (uint32_t t = 0; t < 3 && !fail; t++) {
-            const uint32_t *count = cnt + 64 * t;
-            const uint32_t maxCode = t == 0 ? MaxLL : (t == 1 ? MaxOff : MaxML);
-            const uint32_t maxLog = t == 1 ? 8 : 9;
-            const int16_t *defNorm = t == 0 ? c_LL_defaultNorm : (t == 1 ? c_OF_defaultNorm : c_ML_defaultNorm);
-            const uint32_t defLog = t == 1 ? 5 : 6, defMax = t == 0 ? MaxLL : (t == 1 ? 28 : MaxML);
-            FseCT &ct = L.u.fse.ct[t];
-            uint32_t maxSym = 0, largest = 0, mode;
-            for (uint32_t i = 0; i <= maxCode; i++) if (count[i]) { maxSym = i; if (count[i] > largest) largest = count[i]; }
-            if (largest == nseq) {
-                mode = 1;
-                if (o >= oend) { fail = true; break; }
-                *o++ = (uint8_t)maxSym; ct.rle = 1; ct.tableLog = 0;
-            } else if (nseq < 64 && maxSym <= defMax) {
-                mode = 0;
-                for (uint32_t i = 0; i <= defMax; i++) L.u.fse.norm[i] = defNorm[i];
-                buildCTable(ct, L.u.fse.tableSymbol, L.u.fse.cumul, L.u.fse.norm, defMax, defLog);
-            } else {
-                uint32_t tableLog = maxLog;
-                { const uint32_t hb = zs_highbit(nseq - 1); const uint32_t want = hb > 2 ? hb - 2 : 5; if (want < tableLog) tableLog = want; }
-                { const uint32_t minBits = zs_highbit(maxSym) + 2; uint32_t present = 0; for (uint32_t i = 0; i <= maxSym; i++) present += count[i] != 0;
-                  if (tableLog < minBits) tableLog = minBits; while ((1u << tableLog) < present) tableLog++; }
-                if (tableLog < 5) tableLog = 5;
-                if (tableLog > maxLog) tableLog = maxLog;
-                normalizeCounts(L.u.fse.norm, tableLog, count, nseq, maxSym);
-                const uint32_t h = writeNCount(o, (uint32_t)(oend - o), L.u.fse.norm, maxSym, tableLog);
-                if (!h) { fail = true; break; }
-                o += h;
-                mode = 2;
-                buildCTable(ct, L.u.fse.tableSymbol, L.u.fse.cumul, L.u.fse.norm, maxSym, tableLog);
+    // ---- pass 1: recent-offset codes + code histograms.  Rules (inverse of ZStdDecompress.cs:1509-1530):
+    //   the state changes unless (ll > 0 and off == rep0); a change gives [off, rep0, off == rep1 ? rep2 : rep1].
+    //   rep0 before a sequence is always the previous sequence's offset, so
+    //   rep1 = previous offset of the last changing sequence, rep2 = rep1 as seen by the last changing sequence
+    //   whose offset differed from its rep1: two "last index below me" scans per 64 sequences. ----
+    {
+        uint32_t cPrev, cA, cB;                       // carried: previous offset (= rep0), rep1, rep2
+        if (bd.firstInChunk) { cPrev = 1; cA = 4; cB = 8; } else { cPrev = 0xFFFFFFF1u; cA = 0xFFFFFFF2u; cB = 0xFFFFFFF3u; }
+        #pragma unroll 1
+        for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) {
+            const uint32_t ns = rngN[r];
+            ZsSeqRec *sq = seqBase + (size_t)r * ZS_SEQ_PER_RANGE;
+            for (uint32_t base = 0; base < ns; base += 64) {
+                const uint32_t k = base + lane;
+                const bool in = k < ns;
+                uint32_t off = 0, ll = 0, ml = 0;
+                if (in) { const ZsSeqRec rec = sq[k]; off = rec.off; ll = rec.ll; ml = rec.ml & 0x3FFFu; if (k == 0) ll += rngCarry[r]; }
+                uint32_t prev = (uint32_t)__shfl_up((int)off, 1); if (lane == 0) prev = cPrev;        // rep0 before me
+                const bool change = in && !(ll > 0 && off == prev);
+                const int j = lastFlagBelow(change);                                                  // last changing sequence before me
+                const uint32_t aSh = (uint32_t)__shfl((int)prev, max(j, 0));                          // every lane takes part: a source lane must be active
+                const uint32_t a = (j >= 0) ? aSh : cA;                                               // rep1 before me
+                const bool reset = change && (off != a);                                              // sequences after which rep2 = their rep1
+                const int kk = lastFlagBelow(reset);
+                const uint32_t bSh = (uint32_t)__shfl((int)a, max(kk, 0));
+                const uint32_t b = (kk >= 0) ? bSh : cB;                                              // rep2 before me
+                uint32_t val = 0;
+                if (in) {
+                    if (ll) { val = (off == prev) ? 1u : (off == a) ? 2u : (off == b) ? 3u : 0u; }
+                    else    { val = (off == a) ? 1u : (off == b) ? 2u : 0u; }
+                    sq[k].ml = (uint16_t)(ml | (val << 14));
+                    const uint32_t v = val ? val : off + 3;
+                    atomicAdd(&L.count[llCodeOf(ll)], 1u);
+                    atomicAdd(&L.count[64 + zs_highbit(v)], 1u);
+                    atomicAdd(&L.count[128 + mlCodeOf(ml - 3)], 1u);
+                }
+                // carries for the next 64: state after the last sequence of this batch
+                const uint32_t cnt = min(64u, ns - base);
+                const uint64_t chm = __ballot(change), rsm = __ballot(reset);
+                const uint32_t lastOff = (uint32_t)__shfl((int)off, (int)(cnt - 1));
+                if (chm) { const int jl = 63 - __builtin_clzll(chm); cA = (uint32_t)__shfl((int)prev, jl); }
+                if (rsm) { const int kl = 63 - __builtin_clzll(rsm); cB = (uint32_t)__shfl((int)a, kl); }
+                cPrev = lastOff;
             }
-            modeByte |= mode << (6 - 2 * t);
         }
-        *modes = (uint8_t)modeByte;
-        L.misc[0] = fail ? 0xFFFFFFFFu : (uint32_t)(o - payload);
     }
     __syncthreads();
-    if (L.misc[0] == 0xFFFFFFFFu) FINISH(0, n, 0);
-    const uint32_t bitstreamOff = L.misc[0];
 
-    // ---- sequences bitstream (inverse of ZStdDecompress.cs:1473-1608): last sequence first.
-    //      per tile of 64 sequences: codes (all lanes) -> FSE state chains (lanes 0..2 = LL, OF, ML) -> pack (all lanes) ----
-    uint8_t *bsTmp = streams;                         // reuse the stream scratch (4-byte aligned, 96 KiB)
+    // ---- modes and tables ----
+    uint32_t pos = hdrBytes + 1;                        // after nbSeq and the modes byte
+    uint32_t modeByte = 0;
+    bool fail = false;
+    #pragma unroll 1
+    for (uint32_t t = 0; t < 3; t++) {
+        const uint32_t *count = L.count + 64 * t;
+        const uint32_t maxCode = t == 0 ? MaxLL : (t == 1 ? MaxOff : MaxML);
+        const uint32_t maxLog = t == 1 ? 8 : 9;
+        const uint32_t defLog = t == 1 ? 5 : 6, defMax = t == 0 ? MaxLL : (t == 1 ? 28 : MaxML);
+        FseCT &ct = L.ct[t];
+        const uint32_t c = (lane <= maxCode) ? count[lane] : 0u;
+        const uint64_t present = __ballot(c != 0);
+        const uint32_t maxSym = 63u - (uint32_t)__builtin_clzll(present);       // nseq > 0: at least one symbol
+        const uint32_t largest = wave_max(c);
+        uint32_t mode;
+        if (largest == nseq) {
+            mode = 1;
+            if (pos >= cap) { fail = true; break; }
+            if (lane == 0) { out[pos] = (uint8_t)maxSym; ct.rle = 1; ct.tableLog = 0; }
+            pos += 1;
+        } else if (nseq < 64 && maxSym <= defMax) {
+            mode = 0;
+            if (lane == 0) {
+                const int16_t *defNorm = t == 0 ? c_LL_defaultNorm : (t == 1 ? c_OF_defaultNorm : c_ML_defaultNorm);
+                for (uint32_t i = 0; i <= defMax; i++) L.norm[i] = defNorm[i];
+                buildCTable(ct, L.tableSymbol, L.cumul, L.norm, defMax, defLog);
+            }
+        } else {
+            uint32_t tableLog = maxLog;
+            { const uint32_t hb = zs_highbit(nseq - 1); const uint32_t want = hb > 2 ? hb - 2 : 5; if (want < tableLog) tableLog = want; }
+            { const uint32_t minBits = zs_highbit(maxSym) + 2; const uint32_t npresent = (uint32_t)__popcll(present);
+              if (tableLog < minBits) tableLog = minBits; while ((1u << tableLog) < npresent) tableLog++; }
+            if (tableLog < 5) tableLog = 5;
+            if (tableLog > maxLog) tableLog = maxLog;
+            normalizeCountsWave(L.norm, tableLog, count, nseq, maxSym);
+            if (lane == 0) L.misc[0] = writeNCount(out + pos, cap - pos, L.norm, maxSym, tableLog);
+            __syncthreads();
+            const uint32_t h = L.misc[0];
+            if (!h) { fail = true; break; }
+            pos += h;
+            mode = 2;
+            buildCTableWave(L, ct, L.norm, maxSym, tableLog);
+        }
+        modeByte |= mode << (6 - 2 * t);
+        __syncthreads();
+    }
+    if (fail) FINISH(0xFFFFFFFFu);
+    if (lane == 0) out[hdrBytes] = (uint8_t)modeByte;
+    const uint32_t bitstreamOff = pos;
+
+    // ---- sequences bitstream (inverse of ZStdDecompress.cs:1473-1608): last sequence first.  Per tile of 64:
+    //      codes + table operands (all lanes) -> FSE state chains (lanes 0..2 = LL, OF, ML) -> pack (all lanes).
+    //      The stream is built 4-byte aligned at out + 4096-slack... it is written in place after an aligned gap and moved. ----
+    uint8_t *bsTmp = out + ((bitstreamOff + 3u) & ~3u);                // aligned start inside the section buffer
     BitSink sink; sink_init(sink, bsTmp, L.tile);
-    const uint32_t bsCap = 4 * ZS_STREAM_STRIDE - 64;
+    const uint32_t bsCap = ZS_SEQSEC_STRIDE - ((bitstreamOff + 3u) & ~3u) - 1024u;
     uint32_t chainState = 0;                          // lanes 0..2
     bool overflow = false;
     {
@@ -731,8 +860,7 @@ k_encode_block(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ 
         bool first = true;
         while (remaining) {
             const uint32_t T = min(64u, remaining);
-            // lane t takes global sequence index g = remaining-1-t  -> (range, k)
-            uint32_t ll = 0, ml = 0, val = 0;
+            uint32_t ll = 0, ml = 0, val = 0, llc = 0, mlc = 0, ofc = 0;
             if (lane < T) {
                 const uint32_t g = remaining - 1 - lane;
                 uint32_t rr = 0;
@@ -743,32 +871,41 @@ k_encode_block(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ 
                 ll = rec.ll; if (k == 0) ll += L.rngCarry[rr];
                 ml = rec.ml & 0x3FFFu; const uint32_t rep = rec.ml >> 14;
                 val = rep ? rep : (uint32_t)rec.off + 3;
+                llc = llCodeOf(ll); mlc = mlCodeOf(ml - 3); ofc = zs_highbit(val);
+                L.opNb[0][lane] = L.ct[0].deltaNbBits[llc]; L.opFind[0][lane] = L.ct[0].deltaFindState[llc];
+                L.opNb[1][lane] = L.ct[1].deltaNbBits[ofc]; L.opFind[1][lane] = L.ct[1].deltaFindState[ofc];
+                L.opNb[2][lane] = L.ct[2].deltaNbBits[mlc]; L.opFind[2][lane] = L.ct[2].deltaFindState[mlc];
             }
-            const uint32_t llc = (lane < T) ? llCodeOf(ll) : 0, mlc = (lane < T) ? mlCodeOf(ml - 3) : 0, ofc = (lane < T) ? zs_highbit(val) : 0;
-            L.u.fse.tileCode[0][lane] = (uint8_t)llc; L.u.fse.tileCode[1][lane] = (uint8_t)ofc; L.u.fse.tileCode[2][lane] = (uint8_t)mlc;
             __syncthreads();
             if (lane < 3) {
-                const FseCT &ct = L.u.fse.ct[lane];
-                for (uint32_t t = 0; t < T; t++) {
-                    const uint32_t sym = L.u.fse.tileCode[lane][t];
-                    uint32_t outv = 0;
-                    if (!ct.rle) {
-                        if (first && t == 0) chainState = cstate_init(ct, sym);
-                        else {
-                            const uint32_t nbo = (chainState + ct.deltaNbBits[sym]) >> 16;
-                            outv = (chainState & ((1u << nbo) - 1)) | (nbo << 16);
-                            chainState = ct.stateTable[(chainState >> nbo) + ct.deltaFindState[sym]];
-                        }
+                const FseCT &ct = L.ct[lane];
+                if (!ct.rle) {
+                    uint32_t t = 0;
+                    if (first) {
+                        const uint32_t dnb = L.opNb[lane][0];
+                        const uint32_t nbo = (dnb + (1u << 15)) >> 16;
+                        const uint32_t v = (nbo << 16) - dnb;
+                        chainState = ct.stateTable[(v >> nbo) + L.opFind[lane][0]];
+                        L.tileState[lane][0] = 0;
+                        t = 1;
                     }
-                    L.u.fse.tileState[lane][t] = outv;
+                    uint32_t dnb = (t < T) ? L.opNb[lane][t] : 0; int dfs = (t < T) ? L.opFind[lane][t] : 0;
+                    for (; t < T; t++) {
+                        const uint32_t dnbN = (t + 1 < T) ? L.opNb[lane][t + 1] : 0; const int dfsN = (t + 1 < T) ? L.opFind[lane][t + 1] : 0;   // operands of the next step, ahead of the dependent lookup
+                        const uint32_t nbo = (chainState + dnb) >> 16;
+                        L.tileState[lane][t] = (chainState & ((1u << nbo) - 1)) | (nbo << 16);
+                        chainState = ct.stateTable[(chainState >> nbo) + dfs];
+                        dnb = dnbN; dfs = dfsN;
+                    }
+                } else {
+                    for (uint32_t t = 0; t < T; t++) L.tileState[lane][t] = 0;
                 }
             }
             __syncthreads();
-            // pack: OF state, ML state, LL state, LL extra, ML extra, OF extra (ascending bit positions)
             uint64_t lo = 0; uint32_t hi = 0, nb = 0;
             if (lane < T) {
                 #define PUTB(v, b) { const uint32_t b_ = (b); if (b_) { const uint64_t v_ = (uint64_t)(v); if (nb < 64) { lo |= v_ << nb; if (nb + b_ > 64) hi |= (uint32_t)(v_ >> (64 - nb)); } else hi |= (uint32_t)(v_ << (nb - 64)); nb += b_; } }
-                const uint32_t sOF = L.u.fse.tileState[1][lane], sML = L.u.fse.tileState[2][lane], sLL = L.u.fse.tileState[0][lane];
+                const uint32_t sOF = L.tileState[1][lane], sML = L.tileState[2][lane], sLL = L.tileState[0][lane];
                 PUTB(sOF & 0xFFFFu, sOF >> 16);
                 PUTB(sML & 0xFFFFu, sML >> 16);
                 PUTB(sLL & 0xFFFFu, sLL >> 16);
@@ -783,12 +920,12 @@ k_encode_block(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ 
             first = false;
         }
     }
-    if (overflow) FINISH(0, n, 0);
+    if (overflow) FINISH(0xFFFFFFFFu);
     {
         // final states: ML, OF, LL (ZStdDecompress.cs:1578-1580 reads LL, OF, ML)
-        const uint32_t tlLL = L.u.fse.ct[0].rle ? 0 : L.u.fse.ct[0].tableLog;
-        const uint32_t tlOF = L.u.fse.ct[1].rle ? 0 : L.u.fse.ct[1].tableLog;
-        const uint32_t tlML = L.u.fse.ct[2].rle ? 0 : L.u.fse.ct[2].tableLog;
+        const uint32_t tlLL = L.ct[0].rle ? 0 : L.ct[0].tableLog;
+        const uint32_t tlOF = L.ct[1].rle ? 0 : L.ct[1].tableLog;
+        const uint32_t tlML = L.ct[2].rle ? 0 : L.ct[2].tableLog;
         const uint32_t stLL = (uint32_t)__shfl((int)chainState, 0), stOF = (uint32_t)__shfl((int)chainState, 1), stML = (uint32_t)__shfl((int)chainState, 2);
         uint64_t lo = 0; uint32_t nb = 0;
         if (lane == 0) {
@@ -799,22 +936,32 @@ k_encode_block(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ 
         sink_put(sink, lo, 0u, nb);
     }
     const uint32_t bsSize = sink_close(sink);
+    // move the stream down to its unaligned place (gap <= 3 bytes; lanes move ascending chunks, reads of a round precede its writes)
+    const uint32_t gap = (uint32_t)(bsTmp - (out + bitstreamOff));
+    if (gap) {
+        for (uint32_t base = 0; base < bsSize; base += 64) {
+            const uint32_t j = base + lane;
+            const uint8_t v = (j < bsSize) ? bsTmp[j] : 0;
+            __syncthreads();
+            if (j < bsSize) out[bitstreamOff + j] = v;
+            __syncthreads();
+        }
+    }
     const uint32_t total = bitstreamOff + bsSize;
-    if (total > cap || total >= n) FINISH(0, n, 0);
-    for (uint32_t j = lane; j < bsSize; j += 64) payload[bitstreamOff + j] = bsTmp[j];
-    __syncthreads();
-    FINISH(2, total, 0);
+    FINISH(total > cap ? 0xFFFFFFFFu : total);
+    #undef FINISH
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_assemble_frames : one workgroup per chunk.  frame = magic + FHD + FCS (single segment)
-// + blocks  (inverse of ZStdDecompress.cs:421-499, 646-659, 2008-2091)
+// + blocks  (inverse of ZStdDecompress.cs:421-499, 646-659, 2008-2091).  A block is emitted compressed
+// iff both sections exist and literal section + sequence section < block size (else raw; RLE if flagged).
 // ---------------------------------------------------------------------------------------------
 struct ZsChunkDesc { uint64_t srcOff; uint64_t dstOff; uint32_t size; uint32_t firstBlock; uint32_t nBlocks; uint32_t pad; };
 
 extern "C" __global__ void __launch_bounds__(256)
 k_assemble_frames(const uint8_t *__restrict__ src, const ZsChunkDesc *__restrict__ chunks, const ZsBlockDesc *__restrict__ blocks,
-                  const ZsBlockResult *__restrict__ results, const uint8_t *__restrict__ payloadAll,
+                  const ZsBlockMeta *__restrict__ metas, const uint8_t *__restrict__ litSecAll, const uint8_t *__restrict__ seqSecAll,
                   uint32_t blockBase, uint8_t *__restrict__ dst, uint32_t *__restrict__ dstSizes, uint32_t chunkBase)
 {
     const ZsChunkDesc cd = chunks[chunkBase + blockIdx.x];
@@ -832,21 +979,31 @@ k_assemble_frames(const uint8_t *__restrict__ src, const ZsChunkDesc *__restrict
         const uint32_t gb = cd.firstBlock + b;             // global block index
         const uint32_t lb = gb - blockBase;                // index inside this sub-batch's scratch
         const ZsBlockDesc bd = blocks[gb];
-        const ZsBlockResult r = results[lb];
+        const ZsBlockMeta m = metas[lb];
         const uint32_t last = (b + 1 == cd.nBlocks) ? 1u : 0u;
-        if (r.type == 1) {
-            if (tid == 0) { const uint32_t h = last + (1u << 1) + (bd.size << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); out[pos + 3] = (uint8_t)r.rleByte; }
+        const uint32_t n = bd.size;
+        uint32_t type = m.type;
+        uint32_t total = 0;
+        if (type == 2) {
+            // same decisions as the scalar statement: room left after the literals, section failures, final size test
+            if (m.seqSecSize == 0xFFFFFFFFu || m.litSecSize + 4 > n + 512) type = 0;
+            else { total = m.litSecSize + m.seqSecSize; if (total > n + 512 || total >= n) type = 0; }
+        }
+        if (type == 1) {
+            if (tid == 0) { const uint32_t h = last + (1u << 1) + (n << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); out[pos + 3] = (uint8_t)m.rleByte; }
             pos += 4;
-        } else if (r.type == 2) {
-            if (tid == 0) { const uint32_t h = last + (2u << 1) + (r.payloadSize << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); }
-            const uint8_t *p = payloadAll + (size_t)lb * ZS_PAYLOAD_STRIDE;
-            for (uint32_t j = tid; j < r.payloadSize; j += blockDim.x) out[pos + 3 + j] = p[j];
-            pos += 3 + r.payloadSize;
+        } else if (type == 2) {
+            if (tid == 0) { const uint32_t h = last + (2u << 1) + (total << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); }
+            const uint8_t *p1 = litSecAll + (size_t)lb * ZS_LITSEC_STRIDE;
+            const uint8_t *p2 = seqSecAll + (size_t)lb * ZS_SEQSEC_STRIDE;
+            for (uint32_t j = tid; j < m.litSecSize; j += blockDim.x) out[pos + 3 + j] = p1[j];
+            for (uint32_t j = tid; j < m.seqSecSize; j += blockDim.x) out[pos + 3 + m.litSecSize + j] = p2[j];
+            pos += 3 + total;
         } else {
-            if (tid == 0) { const uint32_t h = last + (0u << 1) + (bd.size << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); }
+            if (tid == 0) { const uint32_t h = last + (0u << 1) + (n << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); }
             const uint8_t *p = src + bd.srcOff;
-            for (uint32_t j = tid; j < bd.size; j += blockDim.x) out[pos + 3 + j] = p[j];
-            pos += 3 + bd.size;
+            for (uint32_t j = tid; j < n; j += blockDim.x) out[pos + 3 + j] = p[j];
+            pos += 3 + n;
         }
     }
     if (tid == 0) dstSizes[chunkBase + blockIdx.x] = pos;

@@ -117,7 +117,7 @@ struct zsmi_ctx {
     uint32_t maxBlocksInFlight = 8192;
     // compress workspace: plan (shared) + one scratch set per internal stream ("lane")
     DevBuf dBlocks, dChunks;
-    struct Scratch { DevBuf dDist, dSeqs, dHdrs, dLits, dStreams, dPayload, dResults; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
+    struct Scratch { DevBuf dDist, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
     static const int kMaxLanes = 8;
     Scratch lanes[kMaxLanes];
     int nLanes = 1;
@@ -177,7 +177,7 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
     for (int i = 0; i < zsmi_ctx::kMaxLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
         if (L.stream) (void)hipStreamSynchronize(L.stream);
-        for (DevBuf *b : { &L.dDist, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dPayload, &L.dResults }) b->release();
+        for (DevBuf *b : { &L.dDist, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dLitSec, &L.dSeqSec, &L.dMetas }) b->release();
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
@@ -269,8 +269,8 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         zsmi_ctx::Scratch &L = c->lanes[i];
         if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2) || !L.dSeqs.reserve((size_t)cap * ZS_MAX_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
             !L.dHdrs.reserve((size_t)cap * ZS_MAX_RANGES * sizeof(ZsRangeHdr)) || !L.dLits.reserve((size_t)cap * (ZS_BLOCK_MAX + 64)) ||
-            !L.dStreams.reserve((size_t)cap * 4 * ZS_STREAM_STRIDE) || !L.dPayload.reserve((size_t)cap * ZS_PAYLOAD_STRIDE) ||
-            !L.dResults.reserve((size_t)cap * sizeof(ZsBlockResult))) return ZSMI_error_memory_allocation;
+            !L.dStreams.reserve((size_t)cap * 4 * ZS_STREAM_STRIDE) || !L.dLitSec.reserve((size_t)cap * ZS_LITSEC_STRIDE) ||
+            !L.dSeqSec.reserve((size_t)cap * ZS_SEQSEC_STRIDE) || !L.dMetas.reserve((size_t)cap * sizeof(ZsBlockMeta))) return ZSMI_error_memory_allocation;
     }
     if (hipEventRecord(c->evStart, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
     for (int i = 0; i < nLanes; i++) if (hipStreamWaitEvent(c->lanes[i].stream, c->evStart, 0) != hipSuccess) return ZSMI_error_GENERIC;
@@ -286,10 +286,12 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         LAUNCH_ON(c, st, "k_lz_candidates", k_lz_candidates, dim3(nb), dim3(512), lds, (const uint8_t *)dSrc, dB, (uint16_t *)L.dDist.p, hashLog);
         LAUNCH_ON(c, st, "k_lz_walk", k_lz_walk, dim3((nb + ZS_WALK_WAVES - 1) / ZS_WALK_WAVES), dim3(64 * ZS_WALK_WAVES), 0, (const uint8_t *)dSrc, dB, (const uint16_t *)L.dDist.p,
                   (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look, nb);
-        LAUNCH_ON(c, st, "k_encode_block", k_encode_block, dim3(nb), dim3(64), 0, (const uint8_t *)dSrc, dB, (ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
-                  (uint8_t *)L.dLits.p, (uint8_t *)L.dStreams.p, (uint8_t *)L.dPayload.p, (ZsBlockResult *)L.dResults.p);
+        LAUNCH_ON(c, st, "k_encode_literals", k_encode_literals, dim3(nb), dim3(64), 0, (const uint8_t *)dSrc, dB, (const ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
+                  (uint8_t *)L.dLits.p, (uint8_t *)L.dStreams.p, (uint8_t *)L.dLitSec.p, (ZsBlockMeta *)L.dMetas.p);
+        LAUNCH_ON(c, st, "k_encode_sequences", k_encode_sequences, dim3(nb), dim3(64), 0, dB, (ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
+                  (uint8_t *)L.dSeqSec.p, (ZsBlockMeta *)L.dMetas.p);
         LAUNCH_ON(c, st, "k_assemble_frames", k_assemble_frames, dim3(chunk1 - chunk0), dim3(256), 0, (const uint8_t *)dSrc, (const ZsChunkDesc *)c->dChunks.p,
-                  (const ZsBlockDesc *)c->dBlocks.p, (const ZsBlockResult *)L.dResults.p, (const uint8_t *)L.dPayload.p, block0, (uint8_t *)dDst, dDstSizes, chunk0);
+                  (const ZsBlockDesc *)c->dBlocks.p, (const ZsBlockMeta *)L.dMetas.p, (const uint8_t *)L.dLitSec.p, (const uint8_t *)L.dSeqSec.p, block0, (uint8_t *)dDst, dDstSizes, chunk0);
         chunk0 = chunk1;
     }
     for (int i = 0; i < nLanes; i++) {
@@ -468,7 +470,7 @@ extern "C" int zsmi_dbg_copyScratch(zsmi_ctx *c, int which, void *hostDst, size_
     if (!c) return -1;
     (void)hipStreamSynchronize(c->stream);
     zsmi_ctx::Scratch &L0 = c->lanes[0];
-    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : &L0.dResults;
+    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : &L0.dMetas;
     if (bytes > b->cap) return -2;
     return hipMemcpy(hostDst, b->p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
