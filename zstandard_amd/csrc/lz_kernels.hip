@@ -39,48 +39,77 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__
     const uint32_t end = min(start + ZS_RANGE_SIZE, hashable);
     uint16_t *T = tables + ((size_t)wave << hashLog);
 
-    // 8 steps per trip: the 8 loads of a trip are issued together, then the table is visited in step order
+    // 8 steps per trip.  The loads of trip t+1 are issued before trip t is worked on (registers double-buffered),
+    // so the table walk of a trip runs under the memory latency of the next one.
     constexpr uint32_t U = 8;
-    for (uint32_t base = start; base < end; base += 64 * U) {
-        uint32_t v[U];
+    {
+        uint32_t v[U], vn[U];
         #pragma unroll
-        for (uint32_t u = 0; u < U; u++) { const uint32_t p = base + u * 64 + lane; v[u] = (p < end) ? zs_load32(s + p) : 0u; }
-        #pragma unroll
-        for (uint32_t u = 0; u < U; u++) {
-            const uint32_t p = base + u * 64 + lane;
-            if (p < end) {
-                const uint32_t h = zs_hash4(v[u], hashLog);
-                const uint16_t own = T[h];
-                T[h] = (uint16_t)(p + 1);
-                dist[p] = own;
+        for (uint32_t u = 0; u < U; u++) { const uint32_t p = start + u * 64 + lane; v[u] = (p < end) ? zs_load32(s + p) : 0u; }
+        for (uint32_t base = start; base < end; base += 64 * U) {
+            const uint32_t nbase = base + 64 * U;
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) { const uint32_t p = nbase + u * 64 + lane; vn[u] = (p < end) ? zs_load32(s + p) : 0u; }
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t p = base + u * 64 + lane;
+                if (p < end) {
+                    const uint32_t h = zs_hash4(v[u], hashLog);
+                    const uint16_t own = T[h];
+                    T[h] = (uint16_t)(p + 1);
+                    dist[p] = own;
+                }
             }
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) v[u] = vn[u];
         }
     }
     __syncthreads();
 
-    for (uint32_t base = start; base < end; base += 64 * U) {
-        uint32_t v[U], cand[U], cv[U];
+    {
+        // trip t: (v, own candidate) loaded one trip ahead; its verification gathers are issued, then trip t-1's
+        // gathers (issued one trip earlier) are compared and stored.
+        uint32_t v[U], cand[U], vn[U], candn[U], pv[U], pcand[U], pcv[U];
+        uint32_t pbase = 0; bool havePrev = false;
         #pragma unroll
-        for (uint32_t u = 0; u < U; u++) { const uint32_t p = base + u * 64 + lane; const bool in = p < end; v[u] = in ? zs_load32(s + p) : 0u; cand[u] = in ? (uint32_t)dist[p] : 0u; }
-        #pragma unroll
-        for (uint32_t u = 0; u < U; u++) {
-            const uint32_t p = base + u * 64 + lane;
-            if (p < end && !cand[u]) {
-                // all earlier ranges are read at once (independent LDS reads); the nearest one that has the hash wins
-                const uint32_t h = zs_hash4(v[u], hashLog);
-                uint32_t c[ZS_MAX_RANGES - 1];
-                #pragma unroll
-                for (uint32_t q = 0; q < ZS_MAX_RANGES - 1; q++) c[q] = (q < wave) ? (uint32_t)tables[((size_t)q << hashLog) + h] : 0u;
-                #pragma unroll
-                for (uint32_t q = 0; q < ZS_MAX_RANGES - 1; q++) if (c[q]) cand[u] = c[q];
+        for (uint32_t u = 0; u < U; u++) { const uint32_t p = start + u * 64 + lane; const bool in = p < end; v[u] = in ? zs_load32(s + p) : 0u; cand[u] = in ? (uint32_t)dist[p] : 0u; }
+        for (uint32_t base = start; base < end; base += 64 * U) {
+            const uint32_t nbase = base + 64 * U;
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) { const uint32_t p = nbase + u * 64 + lane; const bool in = p < end; vn[u] = in ? zs_load32(s + p) : 0u; candn[u] = in ? (uint32_t)dist[p] : 0u; }
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t p = base + u * 64 + lane;
+                if (p < end && !cand[u]) {
+                    // all earlier ranges are read at once (independent LDS reads); the nearest one that has the hash wins
+                    const uint32_t h = zs_hash4(v[u], hashLog);
+                    uint32_t c[ZS_MAX_RANGES - 1];
+                    #pragma unroll
+                    for (uint32_t q = 0; q < ZS_MAX_RANGES - 1; q++) c[q] = (q < wave) ? (uint32_t)tables[((size_t)q << hashLog) + h] : 0u;
+                    #pragma unroll
+                    for (uint32_t q = 0; q < ZS_MAX_RANGES - 1; q++) if (c[q]) cand[u] = c[q];
+                }
             }
+            uint32_t cv[U];
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) cv[u] = cand[u] ? zs_load32(s + cand[u] - 1) : 0u;
+            if (havePrev) {
+                #pragma unroll
+                for (uint32_t u = 0; u < U; u++) {
+                    const uint32_t p = pbase + u * 64 + lane;
+                    if (p < end) dist[p] = (pcand[u] && pcv[u] == pv[u]) ? (uint16_t)(p - (pcand[u] - 1)) : (uint16_t)0;
+                }
+            }
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) { pv[u] = v[u]; pcand[u] = cand[u]; pcv[u] = cv[u]; v[u] = vn[u]; cand[u] = candn[u]; }
+            pbase = base; havePrev = true;
         }
-        #pragma unroll
-        for (uint32_t u = 0; u < U; u++) cv[u] = cand[u] ? zs_load32(s + cand[u] - 1) : 0u;
-        #pragma unroll
-        for (uint32_t u = 0; u < U; u++) {
-            const uint32_t p = base + u * 64 + lane;
-            if (p < end) dist[p] = (cand[u] && cv[u] == v[u]) ? (uint16_t)(p - (cand[u] - 1)) : (uint16_t)0;
+        if (havePrev) {
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t p = pbase + u * 64 + lane;
+                if (p < end) dist[p] = (pcand[u] && pcv[u] == pv[u]) ? (uint16_t)(p - (pcand[u] - 1)) : (uint16_t)0;
+            }
         }
     }
     // positions without 4 bytes left: no candidate
