@@ -561,7 +561,7 @@ static U32 matchLen(const BYTE *src, U32 a, U32 b, U32 limit)   /* common prefix
  * The best one becomes a sequence; if its forward compare hit FCAP it is then extended in full.
  * Matches stop at the range end. */
 #define WINDOW 64u
-#define FCAP 16u
+#define FCAP 8u
 #define BCAP 8u
 static U32 walkRange(Work *w, const BYTE *src, U32 n, U32 start, U32 end, const EParams *prm, Seq *out, U32 *trailingLits)
 {

@@ -198,17 +198,11 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ block
         uint32_t fwd = 0, back = 0;
         int key = 0;
         if (active) {
-            // 16 bytes forward, 8 bytes backward, both sides: 6 loads
-            const uint64_t fa0 = load64_fwd(s, q, n), fa1 = load64_fwd(s, q + 8, n);
-            const uint64_t fb0 = load64_fwd(s, q - off, n), fb1 = load64_fwd(s, q - off + 8, n);
+            // 8 bytes forward, 8 bytes backward, both sides: 4 loads (one 16-byte span per side)
+            const uint64_t fa0 = load64_fwd(s, q, n), fb0 = load64_fwd(s, q - off, n);
             const uint64_t ba = load64_bwd(s, (int32_t)q - 8), bb = load64_bwd(s, (int32_t)(q - off) - 8);
             const uint32_t cap = min(end - q, ZS_FCAP);
-            {
-                const uint64_t x0 = fa0 ^ fb0, x1 = fa1 ^ fb1;
-                const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
-                const uint32_t n1 = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u;
-                fwd = min((n0 < 8u) ? n0 : 8u + n1, cap);
-            }
+            { const uint64_t x0 = fa0 ^ fb0; fwd = min(x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u, cap); }
             {
                 const uint32_t maxBack = min(min(q - anchor, q - off), ZS_BCAP);
                 const uint64_t x = ba ^ bb;

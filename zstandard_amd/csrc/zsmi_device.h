@@ -10,7 +10,7 @@
 #define ZS_MAX_RANGES  8u
 #define ZS_MINMATCH    4u
 #define ZS_WINDOW      64u        // positions looked at per walk step (one wavefront)
-#define ZS_FCAP        16u        // forward bytes compared when scoring a candidate
+#define ZS_FCAP        8u         // forward bytes compared when scoring a candidate
 #define ZS_BCAP        8u         // backward bytes compared when scoring a candidate
 #define ZS_SEQ_PER_RANGE 2048u    // 8192 / MINMATCH
 #define ZS_HUF_MAXBITS 11u
