@@ -198,18 +198,25 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ block
         uint32_t fwd = 0, back = 0;
         int key = 0;
         if (active) {
-            // 8 bytes forward, 8 bytes backward, both sides: 4 loads (one 16-byte span per side)
-            const uint64_t fa0 = load64_fwd(s, q, n), fb0 = load64_fwd(s, q - off, n);
+            // 16 bytes forward (the score only counts ZS_FCAP of them; the rest saves most extension rounds),
+            // 8 bytes backward, both sides: 6 loads
+            const uint64_t fa0 = load64_fwd(s, q, n), fa1 = load64_fwd(s, q + 8, n);
+            const uint64_t fb0 = load64_fwd(s, q - off, n), fb1 = load64_fwd(s, q - off + 8, n);
             const uint64_t ba = load64_bwd(s, (int32_t)q - 8), bb = load64_bwd(s, (int32_t)(q - off) - 8);
-            const uint32_t cap = min(end - q, ZS_FCAP);
-            { const uint64_t x0 = fa0 ^ fb0; fwd = min(x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u, cap); }
+            const uint32_t cap = min(end - q, ZS_LCAP);
+            {
+                const uint64_t x0 = fa0 ^ fb0, x1 = fa1 ^ fb1;
+                const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
+                const uint32_t n1 = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u;
+                fwd = min((n0 < 8u) ? n0 : 8u + n1, cap);
+            }
             {
                 const uint32_t maxBack = min(min(q - anchor, q - off), ZS_BCAP);
                 const uint64_t x = ba ^ bb;
                 back = min(x ? ((uint32_t)__builtin_clzll(x) >> 3) : 8u, maxBack);
             }
             if (fwd >= ZS_MINMATCH) {
-                const int gain = (int)(fwd + back) * 4 - (int)zs_highbit(off + 1) - 4 * ((int)(q - back) - (int)ip) - (int)(q - ip);
+                const int gain = (int)(min(fwd, ZS_FCAP) + back) * 4 - (int)zs_highbit(off + 1) - 4 * ((int)(q - back) - (int)ip) - (int)(q - ip);
                 key = ((gain + 2048) << 3) | (int)(7u - sub);
             }
         }
@@ -224,8 +231,9 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ block
         const uint32_t bback = (uint32_t)__shfl((int)back, (int)bl);
         const bool took = run && best != 0;
         // ---- long match: the walker's 8 lanes extend it, 128 bytes per round ----
-        bool need = took && bfwd == ZS_FCAP;
-        uint32_t pos = bq + ZS_FCAP;
+        bool need = took && bfwd == ZS_LCAP && (end - bq) > ZS_LCAP;
+        const bool extended = need;
+        uint32_t pos = bq + ZS_LCAP;
         while (__any(need)) {
             uint32_t nb = 0;
             if (need) {
@@ -251,7 +259,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ block
                 else { pos += 128; if (pos >= end) { pos = end; need = false; } }
             }
         }
-        if (took && bfwd == ZS_FCAP) bfwd = pos - bq;
+        if (extended) bfwd = pos - bq;
         if (took) {
             if (sub == 0) {
                 ZsSeqRec r;

@@ -12,6 +12,7 @@
 #define ZS_WINDOW      64u        // positions looked at per walk step (one wavefront)
 #define ZS_FCAP        8u         // forward bytes compared when scoring a candidate
 #define ZS_BCAP        8u         // backward bytes compared when scoring a candidate
+#define ZS_LCAP        16u        // forward bytes a walker lane compares in its one round of loads; longer matches are extended
 #define ZS_SEQ_PER_RANGE 2048u    // 8192 / MINMATCH
 #define ZS_HUF_MAXBITS 11u
 
