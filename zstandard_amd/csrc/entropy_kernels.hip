@@ -57,9 +57,10 @@ struct K3Lds {                       // literals kernel
         struct { uint32_t pkg[10][256]; uint32_t S[512]; uint32_t npk[12]; } pm;      // package-merge (levels 2..11)
         struct { FseCT ct[1]; int16_t norm[64]; uint8_t tableSymbol[512]; uint32_t cumul[66]; } fse;   // weights table
     } u;
-    uint32_t tile[208];              // bit-packing tile
+    uint32_t tile[4][208];           // bit-packing tiles, one per wavefront
     uint32_t misc[16];
-    uint32_t rngN[8], rngCarry[8], rngStart[9];
+    uint32_t rngN[8], rngCarry[8], rngStart[9], litBase[8];
+    uint32_t wcount[16]; int16_t wnorm[16]; uint32_t rankStart[16], rankCount[16];   // small tables kept out of scratch memory
 };
 struct SeqLds {                      // sequences kernel
     uint32_t count[192];             // code counts: [0..63] LL, [64..127] OF, [128..191] ML
@@ -99,6 +100,10 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v)
     return v;
 }
 
+// ordering point between LDS accesses of different lanes of ONE wavefront: LDS instructions of a wave execute in issue
+// order, so only the compiler has to be kept from moving them across
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
 // Wave-cooperative forward bit writer.  Each put() appends, lane 0 first, up to 96 bits per lane.
 // out32 must be 4-byte aligned; bits are packed little-endian (bit k of the stream = bit k%8 of byte k/8).
 struct BitSink {
@@ -110,7 +115,7 @@ __device__ __forceinline__ void sink_init(BitSink &b, void *out, uint32_t *tile)
 {
     b.out32 = (uint32_t *)out; b.tile = tile; b.bitpos = 0;
     if (zs_lane() == 0) tile[0] = 0;
-    __syncthreads();
+    wave_sync();
 }
 __device__ __forceinline__ void sink_put(BitSink &b, uint64_t lo, uint32_t hi, uint32_t nb)
 {
@@ -120,7 +125,7 @@ __device__ __forceinline__ void sink_put(BitSink &b, uint64_t lo, uint32_t hi, u
     const uint32_t base = b.bitpos & 31u;
     const uint32_t nwords = (base + total + 31u) >> 5;
     for (uint32_t i = 1 + lane; i <= nwords; i += 64) b.tile[i] = 0;
-    __syncthreads();
+    wave_sync();
     if (nb) {
         const uint32_t bit = base + incl - nb;
         const uint32_t w = bit >> 5, sh = bit & 31u;
@@ -135,14 +140,14 @@ __device__ __forceinline__ void sink_put(BitSink &b, uint64_t lo, uint32_t hi, u
         if (w2) atomicOr(&b.tile[w + 2], w2);
         if (w3) atomicOr(&b.tile[w + 3], w3);
     }
-    __syncthreads();
+    wave_sync();
     const uint32_t nfull = (base + total) >> 5;
     uint32_t *dst = b.out32 + (b.bitpos >> 5);
     for (uint32_t i = lane; i < nfull; i += 64) dst[i] = b.tile[i];
     const uint32_t carry = b.tile[nfull];
-    __syncthreads();
+    wave_sync();
     if (lane == 0) b.tile[0] = ((base + total) & 31u) ? carry : 0u;
-    __syncthreads();
+    wave_sync();
     b.bitpos += total;
 }
 // adds the end mark (one 1 bit), flushes; returns the stream size in bytes
@@ -151,7 +156,7 @@ __device__ __forceinline__ uint32_t sink_close(BitSink &b)
     const uint32_t lane = (uint32_t)zs_lane();
     sink_put(b, lane == 0 ? 1ull : 0ull, 0u, lane == 0 ? 1u : 0u);
     if (lane == 0 && (b.bitpos & 31u)) b.out32[b.bitpos >> 5] = b.tile[0];
-    __syncthreads();
+    wave_sync();
     return (b.bitpos + 7u) >> 3;
 }
 
@@ -284,14 +289,14 @@ __device__ __forceinline__ uint32_t cstate_init(const FseCT &ct, uint32_t symbol
     return ct.stateTable[(v >> nbBitsOut) + ct.deltaFindState[symbol]];
 }
 
-// weights -> FSE (inverse of FSE_decompress_wksp as used by ReadStats, EntropyCommon.cs:226-231). lane 0 only.
+// weights -> FSE (inverse of FSE_decompress_wksp as used by ReadStats, EntropyCommon.cs:226-231).  One lane; the weight
+// histogram L.wcount[] (all 16 entries) is already filled.
 __device__ static uint32_t fseCompressWeights(K3Lds &L, uint8_t *dst, uint32_t cap, const uint8_t *weights, uint32_t nw)
 {
-    uint32_t count[16]; int16_t norm[16];
+    uint32_t *count = L.wcount; int16_t *norm = L.wnorm;
     uint32_t maxSym = 0, tableLog;
-    for (int i = 0; i < 16; i++) count[i] = 0;
     if (nw <= 1) return 0;
-    for (uint32_t i = 0; i < nw; i++) { count[weights[i]]++; if (weights[i] > maxSym) maxSym = weights[i]; }
+    for (uint32_t i = 0; i < 16; i++) if (count[i]) maxSym = i;
     for (uint32_t i = 0; i <= maxSym; i++) if (count[i] == nw) return 0;
     tableLog = 6;
     while (tableLog > 5 && (1u << (tableLog - 1)) >= nw) tableLog--;
@@ -317,11 +322,11 @@ __device__ static uint32_t fseCompressWeights(K3Lds &L, uint8_t *dst, uint32_t c
     return hsize + s;
 }
 
-// Huffman table description (inverse of ReadStats, EntropyCommon.cs:198-269). lane 0 only.
+// Huffman table description (inverse of ReadStats, EntropyCommon.cs:198-269).  One lane; L.weights[0..maxSym) and the
+// histogram of those weights are already filled.
 __device__ static uint32_t writeHuffHeader(K3Lds &L, uint8_t *dst, uint32_t cap, uint32_t maxSym, uint32_t tableLog)
 {
     uint8_t *weights = L.weights;
-    for (uint32_t s = 0; s < maxSym; s++) weights[s] = L.nbBits[s] ? (uint8_t)(tableLog + 1 - L.nbBits[s]) : 0;
     if (maxSym >= 2 && cap > 1) {
         const uint32_t h = fseCompressWeights(L, dst + 1, cap - 1 < 127 ? cap - 1 : 127, weights, maxSym);
         if (h > 1 && h < maxSym / 2 && h < 128) { dst[0] = (uint8_t)h; return h + 1; }
@@ -345,83 +350,88 @@ __device__ static uint32_t upperBound(const uint32_t *a, uint32_t n, uint32_t ke
 
 __device__ static uint32_t huffLengths(K3Lds &L, uint32_t maxSym, uint32_t maxBits)
 {
-    const uint32_t lane = (uint32_t)zs_lane();
-    // present symbols, rank-sorted by (count, symbol)
-    uint32_t n = 0;
-    for (uint32_t b = 0; b < 256; b += 64) { const uint32_t s = b + lane; n += (uint32_t)__popcll(__ballot(s <= maxSym && L.count[s] != 0)); }
-    for (uint32_t b = 0; b < 256; b += 64) {
-        const uint32_t s = b + lane;
-        L.nbBits[s] = 0;
-        const uint32_t c = (s <= maxSym) ? L.count[s] : 0;
-        if (c) {
-            uint32_t rank = 0;
-            for (uint32_t t = 0; t <= maxSym; t++) { const uint32_t ct = L.count[t]; rank += (ct && (ct < c || (ct == c && t < s))) ? 1u : 0u; }
-            L.leafW[rank] = c; L.leafSym[rank] = (uint16_t)s;
-        }
+    // 256 threads: thread s owns symbol s, later leaf rank s / package index s
+    const uint32_t tid = threadIdx.x;
+    const uint32_t c = (tid <= maxSym) ? L.count[tid] : 0u;
+    const uint32_t n = (uint32_t)__syncthreads_count(c != 0);
+    L.nbBits[tid] = 0;
+    if (c) {
+        uint32_t rank = 0;
+        for (uint32_t t = 0; t <= maxSym; t++) { const uint32_t ct = L.count[t]; rank += (ct && (ct < c || (ct == c && t < tid))) ? 1u : 0u; }
+        L.leafW[rank] = c; L.leafSym[rank] = (uint16_t)tid;
     }
     __syncthreads();
-    if (n == 1) { if (lane == 0) L.nbBits[L.leafSym[0]] = 1; __syncthreads(); return 1; }
+    if (n == 1) { if (tid == 0) L.nbBits[L.leafSym[0]] = 1; __syncthreads(); return 1; }
     uint32_t (*pkg)[256] = L.u.pm.pkg;         // pkg[level - 2]
     uint32_t *S = L.u.pm.S;
     uint32_t *npk = L.u.pm.npk;                // npk[level]
-    if (lane == 0) npk[1] = 0;
+    if (tid == 0) npk[1] = 0;
     __syncthreads();
     for (uint32_t level = 2; level <= maxBits; level++) {
         const uint32_t np = npk[level - 1];
         const uint32_t *prev = (level >= 3) ? pkg[level - 3] : nullptr;
-        for (uint32_t r = lane; r < n; r += 64) { const uint32_t w = L.leafW[r]; S[r + (np ? lowerBound(prev, np, w) : 0u)] = w; }
-        for (uint32_t k = lane; k < np; k += 64) { const uint32_t w = prev[k]; S[k + upperBound(L.leafW, n, w)] = w; }
+        if (tid < n) { const uint32_t w = L.leafW[tid]; S[tid + (np ? lowerBound(prev, np, w) : 0u)] = w; }
+        if (tid < np) { const uint32_t w = prev[tid]; S[tid + upperBound(L.leafW, n, w)] = w; }
         __syncthreads();
         const uint32_t have = (n + np) >> 1;
-        for (uint32_t i = lane; i < have; i += 64) pkg[level - 2][i] = S[2 * i] + S[2 * i + 1];
-        if (lane == 0) npk[level] = have;
+        if (tid < have) pkg[level - 2][tid] = S[2 * tid] + S[2 * tid + 1];
+        if (tid == 0) npk[level] = have;
         __syncthreads();
     }
-    for (uint32_t r = lane; r < 256; r += 64) L.lenOfRank[r] = 0;
+    L.lenOfRank[tid] = 0;
     __syncthreads();
     uint32_t m = 2 * n - 2;
     for (uint32_t level = maxBits; level >= 1; level--) {
         const uint32_t np = npk[level];
         const uint32_t *cur = (level >= 2) ? pkg[level - 2] : nullptr;
         if (m > n + np) m = n + np;
-        uint32_t li = 0;
-        for (uint32_t b = 0; b < n; b += 64) {
-            const uint32_t r = b + lane;
-            bool in = false;
-            if (r < n) { const uint32_t pos = r + (np ? lowerBound(cur, np, L.leafW[r]) : 0u); in = pos < m; }
-            li += (uint32_t)__popcll(__ballot(in));
-            if (in) L.lenOfRank[r]++;
-        }
+        bool in = false;
+        if (tid < n) { const uint32_t pos = tid + (np ? lowerBound(cur, np, L.leafW[tid]) : 0u); in = pos < m; }
+        const uint32_t li = (uint32_t)__syncthreads_count(in);
+        if (in) L.lenOfRank[tid]++;
         const uint32_t pi = m - li;
         m = 2 * pi;
         if (!m) break;
     }
     __syncthreads();
-    for (uint32_t r = lane; r < n; r += 64) L.nbBits[L.leafSym[r]] = L.lenOfRank[r];
+    if (tid < n) L.nbBits[L.leafSym[tid]] = L.lenOfRank[tid];
     __syncthreads();
     return L.lenOfRank[0];
 }
 
-// code values in the decoder's table order (HufDecompress.cs:148-176). lane 0 only.
-__device__ static void huffCodes(K3Lds &L, uint32_t maxSym, uint32_t tableLog)
+// code values in the decoder's table order (HufDecompress.cs:148-176), weights and their histogram; 256 threads
+// (thread s owns symbol s).  code[s] = rankStart[w] / 2^(w-1) + (number of lower symbols with the same weight).
+__device__ static void huffCodesAndWeights(K3Lds &L, uint32_t maxSym, uint32_t tableLog)
 {
-    uint32_t rankStart[ZS_HUF_MAXBITS + 2], rankCount[ZS_HUF_MAXBITS + 2];
-    for (uint32_t w = 0; w < ZS_HUF_MAXBITS + 2; w++) rankCount[w] = 0;
-    for (uint32_t s = 0; s <= maxSym; s++) if (L.nbBits[s]) rankCount[tableLog + 1 - L.nbBits[s]]++;
-    uint32_t next = 0;
-    for (uint32_t w = 1; w <= tableLog; w++) { rankStart[w] = next; next += rankCount[w] << (w - 1); }
-    for (uint32_t s = 0; s <= maxSym; s++) if (L.nbBits[s]) {
-        const uint32_t w = tableLog + 1 - L.nbBits[s];
-        L.code[s] = (uint16_t)(rankStart[w] >> (w - 1));
-        rankStart[w] += 1u << (w - 1);
+    const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const uint32_t nb = (tid <= maxSym) ? L.nbBits[tid] : 0u;
+    const uint32_t w = nb ? tableLog + 1 - nb : 0u;
+    if (tid < 16) { L.rankCount[tid] = 0; L.wcount[tid] = 0; }
+    __syncthreads();
+    if (nb) atomicAdd(&L.rankCount[w], 1u);
+    if (tid < maxSym) { L.weights[tid] = (uint8_t)w; atomicAdd(&L.wcount[w], 1u); }       // the last symbol's weight is implied
+    __syncthreads();
+    if (tid == 0) { uint32_t next = 0; for (uint32_t k = 1; k <= tableLog; k++) { L.rankStart[k] = next; next += L.rankCount[k] << (k - 1); } }
+    // index among the symbols of equal weight: lower lanes of my wavefront + whole lower wavefronts (counted per weight)
+    uint32_t idx = 0;
+    for (uint32_t k = 1; k <= tableLog; k++) {
+        const uint64_t m = __ballot(w == k);
+        if (w == k) idx = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (lane == 0) L.u.pm.S[wave * 16 + k] = (uint32_t)__popcll(m);                    // S is free again after the code lengths
     }
+    __syncthreads();
+    if (nb) {
+        for (uint32_t v = 0; v < wave; v++) idx += L.u.pm.S[v * 16 + w];
+        L.code[tid] = (uint16_t)((L.rankStart[w] >> (w - 1)) + idx);
+    }
+    __syncthreads();
 }
 
 // one Huffman stream of lits[from .. from+len) into tmp (4-byte aligned); last symbol first. returns bytes.
-__device__ static uint32_t huffEncodeStream(K3Lds &L, uint8_t *tmp, const uint8_t *lits, uint32_t from, uint32_t len)
+__device__ static uint32_t huffEncodeStream(K3Lds &L, uint32_t *tile, uint8_t *tmp, const uint8_t *lits, uint32_t from, uint32_t len)
 {
     const uint32_t lane = (uint32_t)zs_lane();
-    BitSink sink; sink_init(sink, tmp, L.tile);
+    BitSink sink; sink_init(sink, tmp, tile);
     uint32_t remaining = len;
     while (remaining) {
         const uint32_t T = min(512u, remaining);
@@ -465,18 +475,19 @@ __device__ __forceinline__ void loadRanges(const ZsRangeHdr *hdr, uint32_t *rngN
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_encode_literals : one wavefront per block.  Block type (raw for tiny blocks, RLE block), literal
-// gather + histogram, Huffman (package-merge), literals section  -> litSec[], meta.{type, rleByte, litSecSize}
+// k_encode_literals : one workgroup of 4 wavefronts per block.  Block type (raw for tiny blocks, RLE block),
+// literal gather + histogram (wavefront w takes ranges w and w+4), Huffman lengths by package-merge (256 threads),
+// table description (one lane), the 4 Huffman streams (one wavefront each)  -> litSec[], meta.{type, rleByte, litSecSize}
 // ---------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(64)
+extern "C" __global__ void __launch_bounds__(256)
 k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ blocks,
                   const ZsSeqRec *__restrict__ seqAll, const ZsRangeHdr *__restrict__ hdrAll,
                   uint8_t *__restrict__ litsAll, uint8_t *__restrict__ streamAll, uint8_t *__restrict__ litSecAll,
-                  ZsBlockMeta *__restrict__ metas)
+                  ZsBlockMeta *__restrict__ metas, int stopAt)
 {
     __shared__ K3Lds L;
     const uint32_t blk = blockIdx.x;
-    const uint32_t lane = (uint32_t)zs_lane();
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const ZsBlockDesc bd = blocks[blk];
     const uint8_t *s = src + bd.srcOff;
     const uint32_t n = bd.size;
@@ -487,68 +498,76 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     uint8_t *payload = litSecAll + (size_t)blk * ZS_LITSEC_STRIDE;
     const uint32_t cap = n + 512;
 
-    #define FINISH(tp, lsz, rb) do { if (lane == 0) { metas[blk].type = (tp); metas[blk].rleByte = (rb); metas[blk].litSecSize = (lsz); } return; } while (0)
+    #define FINISH(tp, lsz, rb) do { if (tid == 0) { metas[blk].type = (tp); metas[blk].rleByte = (rb); metas[blk].litSecSize = (lsz); } return; } while (0)
 
     if (n == 0) FINISH(0, 0, 0);
     {   // RLE block: every byte equal (ZStdDecompress.cs:1945-1950 on the decode side)
+        // 16 bytes per thread and load; most blocks fail within the first 4 KiB
         const uint32_t b0 = s[0];
+        const uint64_t rep = 0x0101010101010101ull * b0;
         bool diff = false;
-        for (uint32_t i = lane; i < n; i += 64) diff |= (s[i] != b0);
-        if (!__ballot(diff)) FINISH(1, 0, b0);
+        for (uint32_t base = 0; base < n; base += 256 * 16) {
+            const uint32_t i = base + tid * 16;
+            if (i + 16 <= n) { const uint64_t a = zs_load64(s + i), b = zs_load64(s + i + 8); diff |= (a != rep) | (b != rep); }
+            else for (uint32_t j = i; j < n; j++) diff |= (s[j] != b0);
+            if (__syncthreads_or(diff)) { diff = true; break; }
+        }
+        if (!diff) FINISH(1, 0, b0);
     }
     if (n < 16) FINISH(0, 0, 0);
 
-    if (lane == 0) loadRanges(hdr, L.rngN, L.rngCarry, L.rngStart, &L.misc[1]);
+    if (tid == 0) {
+        loadRanges(hdr, L.rngN, L.rngCarry, L.rngStart, &L.misc[1]);
+        uint32_t base = 0;
+        for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) { L.litBase[r] = base; base += hdr[r].litSum + hdr[r].trailing; }
+        L.misc[2] = base;                                  // all literals of the block
+    }
+    L.count[tid] = 0;
     __syncthreads();
     const uint32_t lastLits = L.misc[1];
-    const uint32_t *rngN = L.rngN, *rngCarry = L.rngCarry;
+    const uint32_t nlit = L.misc[2];
 
-    // ---- literals: gather into lits[], histogram ----
-    for (uint32_t i = lane; i < 256; i += 64) L.count[i] = 0;
-    __syncthreads();
-    uint32_t nlit = 0;
-    {
-        #pragma unroll 1
-        for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) {
-            const uint32_t ns = rngN[r];
-            const ZsSeqRec *sq = seqBase + (size_t)r * ZS_SEQ_PER_RANGE;
-            for (uint32_t base = 0; base < ns; base += 64) {
-                const uint32_t k = base + lane;
-                uint32_t ll = 0, mpos = 0;
-                if (k < ns) { const ZsSeqRec rec = sq[k]; ll = rec.ll; if (k == 0) ll += rngCarry[r]; mpos = rec.flags; }
-                const uint32_t incl = wave_incl_scan(ll);
-                const uint32_t dstOff = nlit + incl - ll;
-                const uint32_t srcPos = mpos - ll;
-                // short runs by their own lane (one round of loads), long runs by the whole wavefront
-                if (ll && ll <= 16) {
-                    const uint32_t endPos = srcPos + ll;
-                    const uint32_t skip = 16 - ll;
-                    uint64_t w0 = 0, w1 = 0;
-                    if (endPos >= 16) { w0 = zs_load64(s + endPos - 16); w1 = zs_load64(s + endPos - 8); }
-                    else for (uint32_t j = 0; j < ll; j++) { const uint64_t c = s[srcPos + j]; const uint32_t bi = skip + j; if (bi < 8) w0 |= c << (8 * bi); else w1 |= c << (8 * (bi - 8)); }
-                    for (uint32_t j = 0; j < ll; j++) {
-                        const uint32_t bi = skip + j;
-                        const uint8_t c = (uint8_t)((bi < 8 ? w0 >> (8 * bi) : w1 >> (8 * (bi - 8))));
-                        lits[dstOff + j] = c; atomicAdd(&L.count[c], 1u);
-                    }
+    // ---- literals: gather into lits[], histogram.  Range r's own literals start at litBase[r]; the first sequence of a
+    //      range also takes the literals carried over from the ranges before it (they sit right in front). ----
+    for (uint32_t r = wave; r < ZS_MAX_RANGES; r += 4) {
+        const uint32_t ns = L.rngN[r];
+        const ZsSeqRec *sq = seqBase + (size_t)r * ZS_SEQ_PER_RANGE;
+        uint32_t done = L.litBase[r] - L.rngCarry[r];
+        for (uint32_t base = 0; base < ns; base += 64) {
+            const uint32_t k = base + lane;
+            uint32_t ll = 0, mpos = 0;
+            if (k < ns) { const ZsSeqRec rec = sq[k]; ll = rec.ll; if (k == 0) ll += L.rngCarry[r]; mpos = rec.flags; }
+            const uint32_t incl = wave_incl_scan(ll);
+            const uint32_t dstOff = done + incl - ll;
+            const uint32_t srcPos = mpos - ll;
+            // short runs by their own lane (one round of loads), long runs by the whole wavefront
+            if (ll && ll <= 16) {
+                const uint32_t endPos = srcPos + ll;
+                const uint32_t skip = 16 - ll;
+                uint64_t w0 = 0, w1 = 0;
+                if (endPos >= 16) { w0 = zs_load64(s + endPos - 16); w1 = zs_load64(s + endPos - 8); }
+                else for (uint32_t j = 0; j < ll; j++) { const uint64_t c = s[srcPos + j]; const uint32_t bi = skip + j; if (bi < 8) w0 |= c << (8 * bi); else w1 |= c << (8 * (bi - 8)); }
+                for (uint32_t j = 0; j < ll; j++) {
+                    const uint32_t bi = skip + j;
+                    const uint8_t c = (uint8_t)((bi < 8 ? w0 >> (8 * bi) : w1 >> (8 * (bi - 8))));
+                    lits[dstOff + j] = c; atomicAdd(&L.count[c], 1u);
                 }
-                uint64_t longm = __ballot(ll > 16);
-                while (longm) {
-                    const int t = __builtin_ctzll(longm); longm &= longm - 1;
-                    const uint32_t l2 = (uint32_t)__shfl((int)ll, t), d2 = (uint32_t)__shfl((int)dstOff, t), s2 = (uint32_t)__shfl((int)srcPos, t);
-                    for (uint32_t j = lane; j < l2; j += 64) { const uint8_t c = s[s2 + j]; lits[d2 + j] = c; atomicAdd(&L.count[c], 1u); }
-                }
-                nlit += (uint32_t)__shfl((int)incl, 63);
             }
+            uint64_t longm = __ballot(ll > 16);
+            while (longm) {
+                const int t = __builtin_ctzll(longm); longm &= longm - 1;
+                const uint32_t l2 = (uint32_t)__shfl((int)ll, t), d2 = (uint32_t)__shfl((int)dstOff, t), s2 = (uint32_t)__shfl((int)srcPos, t);
+                for (uint32_t j = lane; j < l2; j += 64) { const uint8_t c = s[s2 + j]; lits[d2 + j] = c; atomicAdd(&L.count[c], 1u); }
+            }
+            done += (uint32_t)__shfl((int)incl, 63);
         }
-        for (uint32_t j = lane; j < lastLits; j += 64) { const uint8_t c = s[n - lastLits + j]; lits[nlit + j] = c; atomicAdd(&L.count[c], 1u); }
-        nlit += lastLits;
     }
+    for (uint32_t j = tid; j < lastLits; j += 256) { const uint8_t c = s[n - lastLits + j]; lits[nlit - lastLits + j] = c; atomicAdd(&L.count[c], 1u); }
     __syncthreads();
+    if (stopAt == 1) FINISH(0, 0, 0);            // timing aid (ZSMI_STOP_LIT): stop after the literal gather
 
     // ---- literals section (inverse of DecodeLiteralsBlock, ZStdDecompress.cs:683-821) ----
-    uint32_t litSecSize = 0;
-    {
+    if (wave == 0) {
         uint32_t maxSym = 0, largest = 0;
         for (uint32_t b = 0; b < 256; b += 64) {
             const uint32_t c = L.count[b + lane];
@@ -556,71 +575,76 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
             if (present) maxSym = b + 63u - (uint32_t)__builtin_clzll(present);
             largest = max(largest, wave_max(c));
         }
-        bool done = false;
-        if (nlit > 0 && largest == nlit && nlit > 4) {
-            if (lane == 0) {
-                const uint8_t b0 = lits[0];
-                if (nlit < 32) { payload[0] = (uint8_t)(1 + (nlit << 3)); payload[1] = b0; }
-                else if (nlit < 4096) { const uint32_t h = 1 + (1 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = b0; }
-                else { const uint32_t h = 1 + (3 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); payload[3] = b0; }
-            }
-            litSecSize = (nlit < 32) ? 2 : (nlit < 4096 ? 3 : 4);
-            done = true;
-        }
-        if (!done && nlit >= 64) {
-            const uint32_t tableLog = huffLengths(L, maxSym, ZS_HUF_MAXBITS);
-            const uint32_t lhSize = 3 + (nlit >= 1024) + (nlit >= 16384);
-            const bool single = nlit < 256;
-            if (lane == 0) { huffCodes(L, maxSym, tableLog); L.misc[0] = writeHuffHeader(L, payload + lhSize, cap - lhSize, maxSym, tableLog); }
-            __syncthreads();
-            const uint32_t hsz = L.misc[0];
-            if (hsz) {
-                bool ok = true;
-                uint32_t ssz[4] = { 0, 0, 0, 0 };
-                if (single) { ssz[0] = huffEncodeStream(L, streams, lits, 0, nlit); }
-                else {
-                    const uint32_t seg = (nlit + 3) / 4;
-                    #pragma unroll 1
-                    for (uint32_t k = 0; k < 4; k++) {
-                        const uint32_t len = (k < 3) ? seg : nlit - 3 * seg;
-                        ssz[k] = huffEncodeStream(L, streams + k * ZS_STREAM_STRIDE, lits, k * seg, len);
-                        if (ssz[k] > 65535) ok = false;
-                    }
-                }
-                const uint32_t csz = hsz + (single ? ssz[0] : 6 + ssz[0] + ssz[1] + ssz[2] + ssz[3]);
-                if (ok && lhSize + csz <= cap && csz + lhSize < nlit + (3 - (nlit < 32) - (nlit < 4096)) && (single || csz >= 10)) {
-                    uint8_t *op = payload + lhSize + hsz;
-                    if (!single) {
-                        if (lane == 0) { op[0] = (uint8_t)ssz[0]; op[1] = (uint8_t)(ssz[0] >> 8); op[2] = (uint8_t)ssz[1]; op[3] = (uint8_t)(ssz[1] >> 8); op[4] = (uint8_t)ssz[2]; op[5] = (uint8_t)(ssz[2] >> 8); }
-                        op += 6;
-                    }
-                    for (uint32_t k = 0; k < (single ? 1u : 4u); k++) {
-                        const uint8_t *from = streams + k * ZS_STREAM_STRIDE;
-                        for (uint32_t j = lane; j < ssz[k]; j += 64) op[j] = from[j];
-                        op += ssz[k];
-                    }
-                    if (lane == 0) {
-                        if (lhSize == 3) { const uint32_t h = 2 + ((single ? 0u : 1u) << 2) + (nlit << 4) + (csz << 14); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); }
-                        else if (lhSize == 4) { const uint32_t h = 2 + (2 << 2) + (nlit << 4) + (csz << 18); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); payload[3] = (uint8_t)(h >> 24); }
-                        else { const uint32_t h = 2 + (3 << 2) + (nlit << 4) + (csz << 22); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); payload[3] = (uint8_t)(h >> 24); payload[4] = (uint8_t)(csz >> 10); }
-                    }
-                    litSecSize = lhSize + csz;
-                    done = true;
-                }
-            }
-        }
-        if (!done) {
-            const uint32_t lh = 1 + (nlit > 31) + (nlit > 4095);
-            if (lane == 0) {
-                if (lh == 1) payload[0] = (uint8_t)(nlit << 3);
-                else if (lh == 2) { const uint32_t h = (1 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); }
-                else { const uint32_t h = (3 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); }
-            }
-            for (uint32_t j = lane; j < nlit; j += 64) payload[lh + j] = lits[j];
-            litSecSize = lh + nlit;
-        }
+        if (lane == 0) { L.misc[3] = maxSym; L.misc[4] = largest; }
     }
     __syncthreads();
+    const uint32_t maxSym = L.misc[3], largest = L.misc[4];
+    uint32_t litSecSize = 0;
+    bool done = false;
+    if (nlit > 0 && largest == nlit && nlit > 4) {
+        if (tid == 0) {
+            const uint8_t b0 = lits[0];
+            if (nlit < 32) { payload[0] = (uint8_t)(1 + (nlit << 3)); payload[1] = b0; }
+            else if (nlit < 4096) { const uint32_t h = 1 + (1 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = b0; }
+            else { const uint32_t h = 1 + (3 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); payload[3] = b0; }
+        }
+        litSecSize = (nlit < 32) ? 2 : (nlit < 4096 ? 3 : 4);
+        done = true;
+    }
+    if (!done && nlit >= 64) {
+        const uint32_t tableLog = huffLengths(L, maxSym, ZS_HUF_MAXBITS);
+        if (stopAt == 2) FINISH(0, 0, 0);    // stop after the code lengths
+        const uint32_t lhSize = 3 + (nlit >= 1024) + (nlit >= 16384);
+        const bool single = nlit < 256;
+        huffCodesAndWeights(L, maxSym, tableLog);
+        if (tid == 0) L.misc[0] = writeHuffHeader(L, payload + lhSize, cap - lhSize, maxSym, tableLog);
+        __syncthreads();
+        const uint32_t hsz = L.misc[0];
+        if (stopAt == 3) FINISH(0, 0, 0);    // stop after codes + table description
+        if (hsz) {
+            const uint32_t seg = (nlit + 3) / 4;
+            if (single) { if (wave == 0) { const uint32_t z = huffEncodeStream(L, L.tile[0], streams, lits, 0, nlit); if (lane == 0) L.misc[8] = z; } }
+            else {
+                const uint32_t len = (wave < 3) ? seg : nlit - 3 * seg;
+                const uint32_t z = huffEncodeStream(L, L.tile[wave], streams + wave * ZS_STREAM_STRIDE, lits, wave * seg, len);
+                if (lane == 0) L.misc[8 + wave] = z;
+            }
+            __syncthreads();
+            const uint32_t ssz0 = L.misc[8], ssz1 = single ? 0 : L.misc[9], ssz2 = single ? 0 : L.misc[10], ssz3 = single ? 0 : L.misc[11];
+            const bool ok = single || (ssz0 <= 65535 && ssz1 <= 65535 && ssz2 <= 65535 && ssz3 <= 65535);
+            const uint32_t csz = hsz + (single ? ssz0 : 6 + ssz0 + ssz1 + ssz2 + ssz3);
+            if (ok && lhSize + csz <= cap && csz + lhSize < nlit + (3 - (nlit < 32) - (nlit < 4096)) && (single || csz >= 10)) {
+                uint8_t *op = payload + lhSize + hsz;
+                if (!single) {
+                    if (tid == 0) { op[0] = (uint8_t)ssz0; op[1] = (uint8_t)(ssz0 >> 8); op[2] = (uint8_t)ssz1; op[3] = (uint8_t)(ssz1 >> 8); op[4] = (uint8_t)ssz2; op[5] = (uint8_t)(ssz2 >> 8); }
+                    op += 6;
+                }
+                const uint32_t ssz[4] = { ssz0, ssz1, ssz2, ssz3 };
+                for (uint32_t k = 0; k < (single ? 1u : 4u); k++) {
+                    const uint8_t *from = streams + k * ZS_STREAM_STRIDE;
+                    for (uint32_t j = tid; j < ssz[k]; j += 256) op[j] = from[j];
+                    op += ssz[k];
+                }
+                if (tid == 0) {
+                    if (lhSize == 3) { const uint32_t h = 2 + ((single ? 0u : 1u) << 2) + (nlit << 4) + (csz << 14); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); }
+                    else if (lhSize == 4) { const uint32_t h = 2 + (2 << 2) + (nlit << 4) + (csz << 18); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); payload[3] = (uint8_t)(h >> 24); }
+                    else { const uint32_t h = 2 + (3 << 2) + (nlit << 4) + (csz << 22); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); payload[3] = (uint8_t)(h >> 24); payload[4] = (uint8_t)(csz >> 10); }
+                }
+                litSecSize = lhSize + csz;
+                done = true;
+            }
+        }
+    }
+    if (!done) {
+        const uint32_t lh = 1 + (nlit > 31) + (nlit > 4095);
+        if (tid == 0) {
+            if (lh == 1) payload[0] = (uint8_t)(nlit << 3);
+            else if (lh == 2) { const uint32_t h = (1 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); }
+            else { const uint32_t h = (3 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); }
+        }
+        for (uint32_t j = tid; j < nlit; j += 256) payload[lh + j] = lits[j];
+        litSecSize = lh + nlit;
+    }
     FINISH(2, litSecSize, 0);
     #undef FINISH
 }
@@ -718,7 +742,7 @@ __device__ static void buildCTableWave(SeqLds &L, FseCT &ct, const int16_t *norm
 
 extern "C" __global__ void __launch_bounds__(64)
 k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict__ seqAll, const ZsRangeHdr *__restrict__ hdrAll,
-                   uint8_t *__restrict__ seqSecAll, ZsBlockMeta *__restrict__ metas)
+                   uint8_t *__restrict__ seqSecAll, ZsBlockMeta *__restrict__ metas, int stopAt)
 {
     __shared__ SeqLds L;
     const uint32_t blk = blockIdx.x;
@@ -795,6 +819,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
         }
     }
     __syncthreads();
+    if (stopAt == 1) FINISH(0xFFFFFFFFu);        // timing aid (ZSMI_STOP_SEQ): stop after repcodes + histograms
 
     // ---- modes and tables ----
     uint32_t pos = hdrBytes + 1;                        // after nbSeq and the modes byte
@@ -844,6 +869,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
         __syncthreads();
     }
     if (fail) FINISH(0xFFFFFFFFu);
+    if (stopAt == 2) FINISH(0xFFFFFFFFu);        // stop after the tables
     if (lane == 0) out[hdrBytes] = (uint8_t)modeByte;
     const uint32_t bitstreamOff = pos;
 

@@ -168,7 +168,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ block
     const uint32_t hashable = (n >= 4) ? n - 3 : 0;
     const uint32_t scanEnd = alive ? min(end, hashable) : 0;
 
-    uint32_t ip = start, anchor = start, nseq = 0;
+    uint32_t ip = start, anchor = start, nseq = 0, litSum = 0;
     for (;;) {
         const bool run = ip < scanEnd;
         if (!__any(run)) break;
@@ -266,9 +266,9 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ block
                 r.ll = (uint16_t)(bq - bback - anchor); r.ml = (uint16_t)(bback + bfwd); r.off = (uint16_t)boff; r.flags = (uint16_t)(bq - bback);   // flags: position of the match start
                 seqs[nseq] = r;
             }
-            nseq++;
+            nseq++; litSum += bq - bback - anchor;
             ip = bq + bfwd; anchor = ip;
         } else if (run) ip = wend;
     }
-    if (sub == 0) { ZsRangeHdr h; h.nseq = nseq; h.trailing = alive ? end - anchor : ((start < n) ? end - start : 0u); hdrAll[(size_t)blk * ZS_MAX_RANGES + grp] = h; }
+    if (sub == 0) { ZsRangeHdr h; h.nseq = nseq; h.trailing = alive ? end - anchor : ((start < n) ? end - start : 0u); h.litSum = litSum; h.pad = 0; hdrAll[(size_t)blk * ZS_MAX_RANGES + grp] = h; }
 }

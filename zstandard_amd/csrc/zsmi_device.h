@@ -28,7 +28,7 @@ struct ZsBlockDesc {
 // one sequence as the walk kernel leaves it (per range) / as the encode kernel consumes it
 struct ZsSeqRec { uint16_t ll, ml, off, flags; };   // flags: block position of the match start; ml bits 14-15: repcode (encode kernel)
 
-struct ZsRangeHdr { uint32_t nseq, trailing; };
+struct ZsRangeHdr { uint32_t nseq, trailing, litSum, pad; };   // litSum: literal bytes in front of the range's matches
 
 // per-block result of the encode kernel
 struct ZsBlockResult { uint32_t payloadSize; uint32_t type; /* 0 raw, 1 rle, 2 compressed */ uint32_t rleByte; uint32_t pad; };
