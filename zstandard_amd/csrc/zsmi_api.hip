@@ -117,10 +117,11 @@ struct zsmi_ctx {
     uint32_t maxBlocksInFlight = 8192;
     // compress workspace: plan (shared) + one scratch set per internal stream ("lane")
     DevBuf dBlocks, dChunks;
-    struct Scratch { DevBuf dDist, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
+    struct Scratch { DevBuf dDist, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr, aux = nullptr; hipEvent_t done = nullptr, evWalk = nullptr, evSeq = nullptr; };
     static const int kMaxLanes = 8;
     Scratch lanes[kMaxLanes];
     int nLanes = 1;
+    bool overlapEntropy = true;
     int stopLit = 0, stopSeq = 0;          // timing aids (ZSMI_STOP_LIT / ZSMI_STOP_SEQ): end a kernel after a stage; output is then invalid
     hipEvent_t evStart = nullptr;
     PinBuf hBlocks, hChunks;
@@ -162,12 +163,15 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     // the candidate kernel uses up to 128 KiB of dynamic LDS
     (void)hipFuncSetAttribute((const void *)k_lz_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
+    if (const char *e = getenv("ZSMI_OVERLAP")) c->overlapEntropy = atoi(e) != 0;
     if (const char *e = getenv("ZSMI_STOP_LIT")) c->stopLit = atoi(e);
     if (const char *e = getenv("ZSMI_STOP_SEQ")) c->stopSeq = atoi(e);
     if (const char *e = getenv("ZSMI_LANES")) { long v = atol(e); if (v >= 1 && v <= zsmi_ctx::kMaxLanes) c->nLanes = (int)v; }
     // sub-batches of one call run on internal streams so that the latency-bound kernels of different sub-batches overlap
     for (int i = 0; i < c->nLanes; i++) {
-        if (hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->lanes[i].done, hipEventDisableTiming) != hipSuccess) { c->nLanes = i; break; }
+        if (hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->lanes[i].aux, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->lanes[i].done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->lanes[i].evWalk, hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&c->lanes[i].evSeq, hipEventDisableTiming) != hipSuccess) { c->nLanes = i; break; }
     }
     if (c->nLanes == 0 || hipEventCreateWithFlags(&c->evStart, hipEventDisableTiming) != hipSuccess) { zsmi_freeCtx(c); return nullptr; }
     return c;
@@ -182,6 +186,9 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         for (DevBuf *b : { &L.dDist, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dLitSec, &L.dSeqSec, &L.dMetas }) b->release();
         if (L.done) (void)hipEventDestroy(L.done);
+        if (L.evWalk) (void)hipEventDestroy(L.evWalk);
+        if (L.evSeq) (void)hipEventDestroy(L.evSeq);
+        if (L.aux) { (void)hipStreamSynchronize(L.aux); (void)hipStreamDestroy(L.aux); }
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     if (c->evStart) (void)hipEventDestroy(c->evStart);
@@ -289,10 +296,15 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         LAUNCH_ON(c, st, "k_lz_candidates", k_lz_candidates, dim3(nb), dim3(512), lds, (const uint8_t *)dSrc, dB, (uint16_t *)L.dDist.p, hashLog);
         LAUNCH_ON(c, st, "k_lz_walk", k_lz_walk, dim3((nb + ZS_WALK_WAVES - 1) / ZS_WALK_WAVES), dim3(64 * ZS_WALK_WAVES), 0, (const uint8_t *)dSrc, dB, (const uint16_t *)L.dDist.p,
                   (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look, nb);
+        // the two entropy kernels are independent of each other: the sequences kernel runs on a side stream beside the literals kernel
+        const bool overlap = c->overlapEntropy;
+        hipStream_t st2 = overlap ? L.aux : st;
+        if (overlap) { (void)hipEventRecord(L.evWalk, st); (void)hipStreamWaitEvent(st2, L.evWalk, 0); }
+        LAUNCH_ON(c, st2, "k_encode_sequences", k_encode_sequences, dim3(nb), dim3(64), 0, dB, (ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
+                  (uint8_t *)L.dSeqSec.p, (ZsBlockMeta *)L.dMetas.p, c->stopSeq);
         LAUNCH_ON(c, st, "k_encode_literals", k_encode_literals, dim3(nb), dim3(256), 0, (const uint8_t *)dSrc, dB, (const ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
                   (uint8_t *)L.dLits.p, (uint8_t *)L.dStreams.p, (uint8_t *)L.dLitSec.p, (ZsBlockMeta *)L.dMetas.p, c->stopLit);
-        LAUNCH_ON(c, st, "k_encode_sequences", k_encode_sequences, dim3(nb), dim3(64), 0, dB, (ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
-                  (uint8_t *)L.dSeqSec.p, (ZsBlockMeta *)L.dMetas.p, c->stopSeq);
+        if (overlap) { (void)hipEventRecord(L.evSeq, st2); (void)hipStreamWaitEvent(st, L.evSeq, 0); }
         LAUNCH_ON(c, st, "k_assemble_frames", k_assemble_frames, dim3(chunk1 - chunk0), dim3(256), 0, (const uint8_t *)dSrc, (const ZsChunkDesc *)c->dChunks.p,
                   (const ZsBlockDesc *)c->dBlocks.p, (const ZsBlockMeta *)L.dMetas.p, (const uint8_t *)L.dLitSec.p, (const uint8_t *)L.dSeqSec.p, block0, (uint8_t *)dDst, dDstSizes, chunk0);
         chunk0 = chunk1;
