@@ -21,7 +21,7 @@
  *     with the same hash in its own range (prev = T[h]; T[h] = p), else the last
  *     position with that hash in the nearest earlier range that has one.  A candidate
  *     is kept when its 4 bytes equal those at p.  -> dist[p]
- *  2. parse: each range is walked greedily and independently: next position with a
+ *  2. parse: the block is cut again, in walk ranges of 1 KiB; each is walked greedily and independently: next position with a
  *     candidate (or a 4-byte match at the previous offset), forward extension to the
  *     range end, one sequence per match.
  *  3. ranges are concatenated (a range's trailing literals go to the next range's first
@@ -53,6 +53,9 @@ typedef uint64_t U64;
 #define RANGE_LOG   13
 #define RANGE_SIZE  (1u << RANGE_LOG)
 #define MAX_RANGES  (BLOCK_MAX / RANGE_SIZE)
+#define WALK_LOG    10              /* the walk cuts the block in ranges of 1 KiB (the hash tables keep their 8 KiB ranges) */
+#define WALK_SIZE   (1u << WALK_LOG)
+#define WALK_RANGES (BLOCK_MAX / WALK_SIZE)
 #define MINMATCH    4
 #define MAX_HASH_LOG 13
 #define HUF_MAXBITS 11
@@ -601,7 +604,7 @@ static U32 walkRange(Work *w, const BYTE *src, U32 n, U32 start, U32 end, const 
 static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32 n, const EParams *prm, int firstBlock)
 {
     U32 nseq = 0, nlit = 0;
-    U32 const nRanges = (n + RANGE_SIZE - 1) >> RANGE_LOG;
+    U32 const nRanges = (n + WALK_SIZE - 1) >> WALK_LOG;
     U32 r;
     if (n < 16) return 0;
     findCandidates(w, src, n, prm);
@@ -610,8 +613,8 @@ static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32
         U32 carry = 0, pos = 0;
         static __thread Seq rangeSeq[RANGE_SIZE / 3 + 8];
         for (r = 0; r < nRanges; r++) {
-            U32 const start = r << RANGE_LOG;
-            U32 const end = (start + RANGE_SIZE < n) ? start + RANGE_SIZE : n;
+            U32 const start = r << WALK_LOG;
+            U32 const end = (start + WALK_SIZE < n) ? start + WALK_SIZE : n;
             U32 trailing, k;
             U32 const ns = walkRange(w, src, n, start, end, prm, rangeSeq, &trailing);
             for (k = 0; k < ns; k++) {
@@ -806,23 +809,23 @@ int zso_debugCandidates(uint16_t *distOut, const void *src, uint32_t n, int leve
     free(w);
     return 0;
 }
-/* seqOut: per range r, up to 2048 triples (litLength, matchLength, offset) at seqOut[(r*2048 + k)*3];
+/* seqOut: per walk range r (1 KiB), up to 256 triples (litLength, matchLength, offset) at seqOut[(r*256 + k)*3];
  * hdrOut[r*2] = number of sequences, hdrOut[r*2+1] = trailing literals of the range */
 int zso_debugWalk(uint32_t *seqOut, uint32_t *hdrOut, const void *src, uint32_t n, int level)
 {
     EParams const prm = paramsForLevel(level);
     Work *w = (Work *)malloc(sizeof(Work));
     Seq *tmp = (Seq *)malloc(sizeof(Seq) * (RANGE_SIZE / 3 + 8));
-    U32 r, nRanges = (n + RANGE_SIZE - 1) >> RANGE_LOG;
+    U32 r, nRanges = (n + WALK_SIZE - 1) >> WALK_LOG;
     if (!w || !tmp || n > BLOCK_MAX) { free(w); free(tmp); return -1; }
     findCandidates(w, (const BYTE *)src, n, &prm);
     for (r = 0; r < nRanges; r++) {
-        U32 const start = r << RANGE_LOG;
-        U32 const end = (start + RANGE_SIZE < n) ? start + RANGE_SIZE : n;
+        U32 const start = r << WALK_LOG;
+        U32 const end = (start + WALK_SIZE < n) ? start + WALK_SIZE : n;
         U32 trailing, k;
         U32 const ns = walkRange(w, (const BYTE *)src, n, start, end, &prm, tmp, &trailing);
         hdrOut[r * 2] = ns; hdrOut[r * 2 + 1] = trailing;
-        for (k = 0; k < ns; k++) { seqOut[(r * 2048 + k) * 3] = tmp[k].litLength; seqOut[(r * 2048 + k) * 3 + 1] = tmp[k].matchLength; seqOut[(r * 2048 + k) * 3 + 2] = tmp[k].offset; }
+        for (k = 0; k < ns; k++) { seqOut[(r * 256 + k) * 3] = tmp[k].litLength; seqOut[(r * 256 + k) * 3 + 1] = tmp[k].matchLength; seqOut[(r * 256 + k) * 3 + 2] = tmp[k].offset; }
     }
     free(w); free(tmp);
     return 0;

@@ -34,13 +34,13 @@ def main():
             dist_g = np.zeros(65536, dtype=np.uint16); Z.zsmi_dbg_copyScratch(bc.ctx, 0, dist_g.ctypes.data_as(ctypes.c_void_p), 65536 * 2)
             bad = np.nonzero(dist_e != dist_g[:n0])[0]
             print(f"   dist mismatches (block 0): {len(bad)}", bad[:8], dist_e[bad[:8]], dist_g[bad[:8]])
-            seq_e = np.zeros(8 * 2048 * 3, dtype=np.uint32); hdr_e = np.zeros(16, dtype=np.uint32)
+            seq_e = np.zeros(64 * 256 * 3, dtype=np.uint32); hdr_e = np.zeros(128, dtype=np.uint32)
             L.zso_debugWalk(seq_e.ctypes.data_as(ctypes.c_void_p), hdr_e.ctypes.data_as(ctypes.c_void_p), blk, n0, 3)
-            hdr_g = np.zeros(16, dtype=np.uint32); Z.zsmi_dbg_copyScratch(bc.ctx, 2, hdr_g.ctypes.data_as(ctypes.c_void_p), 64)
-            seq_g = np.zeros(8 * 2048 * 4, dtype=np.uint16); Z.zsmi_dbg_copyScratch(bc.ctx, 1, seq_g.ctypes.data_as(ctypes.c_void_p), 8 * 2048 * 8)
+            hdr_g4 = np.zeros(256, dtype=np.uint32); Z.zsmi_dbg_copyScratch(bc.ctx, 2, hdr_g4.ctypes.data_as(ctypes.c_void_p), 1024); hdr_g = hdr_g4.reshape(64, 4)[:, :2].reshape(-1).copy()
+            seq_g = np.zeros(64 * 256 * 4, dtype=np.uint16); Z.zsmi_dbg_copyScratch(bc.ctx, 1, seq_g.ctypes.data_as(ctypes.c_void_p), 64 * 256 * 8)
             print("   hdr E", hdr_e.tolist()); print("   hdr G", hdr_g.tolist())
-            se = seq_e.reshape(8, 2048, 3); sg = seq_g.reshape(8, 2048, 4)
-            for r in range(8):
+            se = seq_e.reshape(64, 256, 3); sg = seq_g.reshape(64, 256, 4)
+            for r in range(64):
                 ns = min(hdr_e[2 * r], hdr_g[2 * r])
                 g3 = np.stack([sg[r, :ns, 0], sg[r, :ns, 1] & 0x3FFF, sg[r, :ns, 2]], axis=1).astype(np.uint32)
                 d = np.nonzero((se[r, :ns] != g3).any(axis=1))[0]

@@ -56,25 +56,26 @@ struct K3Lds {                       // literals kernel
     union {
         struct { uint32_t pkg[10][256]; uint32_t S[512]; uint32_t npk[12]; } pm;      // package-merge (levels 2..11)
         struct { FseCT ct[1]; int16_t norm[64]; uint8_t tableSymbol[512]; uint32_t cumul[66]; } fse;   // weights table
+        uint32_t tile[4][208];       // bit-packing tiles, one per wavefront (streams are written after the tables are done)
     } u;
-    uint32_t tile[4][208];           // bit-packing tiles, one per wavefront
     uint32_t misc[16];
-    uint32_t rngN[8], rngCarry[8], rngStart[9], litBase[8];
+    uint32_t rngN[ZS_WALK_RANGES], rngCarry[ZS_WALK_RANGES], litBase[ZS_WALK_RANGES];
     uint32_t wcount[16]; int16_t wnorm[16]; uint32_t rankStart[16], rankCount[16];   // small tables kept out of scratch memory
 };
-struct SeqLds {                      // sequences kernel
+struct SeqLds {                      // sequences kernel.  Kept under 10 KiB: 16 workgroups per CU = one round for 4096 blocks
     uint32_t count[192];             // code counts: [0..63] LL, [64..127] OF, [128..191] ML
     FseCT ct[3];                     // LL, OF, ML
     int16_t norm[64];
-    uint8_t tableSymbol[512];
-    uint32_t cumul[66];
-    uint32_t symCount[64];           // per-symbol running cell counter (table build)
-    uint32_t opNb[3][64];            // per tile: deltaNbBits of each sequence's code
-    int32_t  opFind[3][64];          // per tile: deltaFindState
-    uint32_t tileState[3][64];       // per tile: state bits out (value | nbBits << 16)
+    union {
+        struct { uint8_t tableSymbol[512]; uint32_t cumul[66]; uint32_t symCount[64]; } build;      // while a table is built
+        struct { uint32_t opNb[3][64];       // per tile: deltaNbBits of each sequence's code
+                 int32_t  opFind[3][64];     // per tile: deltaFindState
+                 uint32_t tileState[3][64];  // per tile: state bits out (value | nbBits << 16)
+               } tile;                                                                                 // while the bitstream is written
+    } u;
     uint32_t tile[208];              // bit-packing tile
     uint32_t misc[16];
-    uint32_t rngN[8], rngCarry[8], rngStart[9];
+    uint32_t rngN[ZS_WALK_RANGES], rngCarry[ZS_WALK_RANGES], rngStart[ZS_WALK_RANGES + 1];
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -462,16 +463,35 @@ struct ZsBlockMeta { uint32_t type;       // 0 raw, 1 rle, 2 literal + sequence 
 #define ZS_SEQSEC_STRIDE  (ZS_BLOCK_MAX + 4096u)
 #define ZS_STREAM_STRIDE  (24u * 1024u)          // per Huffman stream scratch: 16384 symbols * 11 bits = 22528 B max
 
-__device__ __forceinline__ void loadRanges(const ZsRangeHdr *hdr, uint32_t *rngN, uint32_t *rngCarry, uint32_t *rngStart, uint32_t *lastLits)
+// exclusive "last lane below me with flag" : returns lane index or -1
+__device__ __forceinline__ int lastFlagBelow(bool flag)
 {
-    uint32_t carry = 0, tot = 0;
-    for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) {
-        const uint32_t ns = hdr[r].nseq, tr = hdr[r].trailing;
-        rngN[r] = ns; rngCarry[r] = carry; rngStart[r] = tot;
-        carry = ns ? tr : carry + tr;
-        tot += ns;
-    }
-    rngStart[8] = tot; *lastLits = carry;
+    const uint64_t m = __ballot(flag);
+    const uint32_t lane = (uint32_t)zs_lane();
+    const uint64_t below = lane ? (m & ((1ull << lane) - 1)) : 0ull;
+    return below ? 63 - __builtin_clzll(below) : -1;
+}
+
+// Range bookkeeping by one wavefront, lane r = walk range r (64 ranges):
+//   rngN[r] sequences, rngStart[r] index of its first sequence in block order, rngCarry[r] literals carried into its first
+//   sequence (trailing literals of the ranges since the last one that had a sequence), litBase[r] (optional) index of its
+//   first own literal; returns the literals left after the last sequence of the block and the total literal count.
+__device__ __forceinline__ void loadRangesWave(const ZsRangeHdr *hdr, uint32_t *rngN, uint32_t *rngCarry, uint32_t *rngStart, uint32_t *litBase,
+                                               uint32_t *lastLits, uint32_t *allLits)
+{
+    const uint32_t lane = (uint32_t)zs_lane();
+    const ZsRangeHdr h = hdr[lane];
+    const uint32_t ns = h.nseq, tr = h.trailing, lsum = h.litSum + h.trailing;
+    const uint32_t nsIncl = wave_incl_scan(ns), trIncl = wave_incl_scan(tr), lsIncl = wave_incl_scan(lsum);
+    const uint32_t P = trIncl - tr;                                     // trailing literals of the ranges before me
+    const int j = lastFlagBelow(ns != 0);
+    const uint32_t Pj = (uint32_t)__shfl((int)P, max(j, 0));
+    rngN[lane] = ns; if (rngStart) rngStart[lane] = nsIncl - ns; rngCarry[lane] = (j >= 0) ? P - Pj : P;
+    if (litBase) litBase[lane] = lsIncl - lsum;
+    const uint64_t has = __ballot(ns != 0);
+    const uint32_t total = (uint32_t)__shfl((int)trIncl, 63);
+    const uint32_t Plast = has ? (uint32_t)__shfl((int)P, 63 - __builtin_clzll(has)) : 0u;
+    if (lane == 63) { if (rngStart) rngStart[ZS_WALK_RANGES] = nsIncl; *lastLits = has ? total - Plast : total; *allLits = lsIncl; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -491,8 +511,8 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     const ZsBlockDesc bd = blocks[blk];
     const uint8_t *s = src + bd.srcOff;
     const uint32_t n = bd.size;
-    const ZsSeqRec *seqBase = seqAll + (size_t)blk * ZS_MAX_RANGES * ZS_SEQ_PER_RANGE;
-    const ZsRangeHdr *hdr = hdrAll + (size_t)blk * ZS_MAX_RANGES;
+    const ZsSeqRec *seqBase = seqAll + (size_t)blk * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE;
+    const ZsRangeHdr *hdr = hdrAll + (size_t)blk * ZS_WALK_RANGES;
     uint8_t *lits = litsAll + (size_t)blk * (ZS_BLOCK_MAX + 64);
     uint8_t *streams = streamAll + (size_t)blk * 4 * ZS_STREAM_STRIDE;
     uint8_t *payload = litSecAll + (size_t)blk * ZS_LITSEC_STRIDE;
@@ -516,12 +536,7 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     }
     if (n < 16) FINISH(0, 0, 0);
 
-    if (tid == 0) {
-        loadRanges(hdr, L.rngN, L.rngCarry, L.rngStart, &L.misc[1]);
-        uint32_t base = 0;
-        for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) { L.litBase[r] = base; base += hdr[r].litSum + hdr[r].trailing; }
-        L.misc[2] = base;                                  // all literals of the block
-    }
+    if (wave == 0) loadRangesWave(hdr, L.rngN, L.rngCarry, nullptr, L.litBase, &L.misc[1], &L.misc[2]);
     L.count[tid] = 0;
     __syncthreads();
     const uint32_t lastLits = L.misc[1];
@@ -529,7 +544,7 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
 
     // ---- literals: gather into lits[], histogram.  Range r's own literals start at litBase[r]; the first sequence of a
     //      range also takes the literals carried over from the ranges before it (they sit right in front). ----
-    for (uint32_t r = wave; r < ZS_MAX_RANGES; r += 4) {
+    for (uint32_t r = wave; r < ZS_WALK_RANGES; r += 4) {
         const uint32_t ns = L.rngN[r];
         const ZsSeqRec *sq = seqBase + (size_t)r * ZS_SEQ_PER_RANGE;
         uint32_t done = L.litBase[r] - L.rngCarry[r];
@@ -603,10 +618,10 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
         if (stopAt == 3) FINISH(0, 0, 0);    // stop after codes + table description
         if (hsz) {
             const uint32_t seg = (nlit + 3) / 4;
-            if (single) { if (wave == 0) { const uint32_t z = huffEncodeStream(L, L.tile[0], streams, lits, 0, nlit); if (lane == 0) L.misc[8] = z; } }
+            if (single) { if (wave == 0) { const uint32_t z = huffEncodeStream(L, L.u.tile[0], streams, lits, 0, nlit); if (lane == 0) L.misc[8] = z; } }
             else {
                 const uint32_t len = (wave < 3) ? seg : nlit - 3 * seg;
-                const uint32_t z = huffEncodeStream(L, L.tile[wave], streams + wave * ZS_STREAM_STRIDE, lits, wave * seg, len);
+                const uint32_t z = huffEncodeStream(L, L.u.tile[wave], streams + wave * ZS_STREAM_STRIDE, lits, wave * seg, len);
                 if (lane == 0) L.misc[8 + wave] = z;
             }
             __syncthreads();
@@ -654,15 +669,6 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
 // histograms, tables (normalisation and encoding tables built by all lanes), bitstream
 // -> seqSec[], meta.seqSecSize
 // ---------------------------------------------------------------------------------------------
-// exclusive "last lane below me with flag" : returns lane index or -1
-__device__ __forceinline__ int lastFlagBelow(bool flag)
-{
-    const uint64_t m = __ballot(flag);
-    const uint32_t lane = (uint32_t)zs_lane();
-    const uint64_t below = lane ? (m & ((1ull << lane) - 1)) : 0ull;
-    return below ? 63 - __builtin_clzll(below) : -1;
-}
-
 // normalise counts to 2^tableLog, all lanes (lane s owns symbol s); scalar statement: normalizeCounts in the oracle
 __device__ static void normalizeCountsWave(int16_t *norm, uint32_t tableLog, const uint32_t *count, uint32_t total, uint32_t maxSym)
 {
@@ -701,8 +707,8 @@ __device__ static void buildCTableWave(SeqLds &L, FseCT &ct, const int16_t *norm
     const uint32_t nv = (lane <= maxSym) ? (uint32_t)norm[lane] : 0u;
     const uint32_t incl = wave_incl_scan(nv);
     const uint32_t excl = incl - nv;
-    L.cumul[lane] = excl; if (lane == 63) L.cumul[64] = incl;
-    L.symCount[lane] = excl;
+    L.u.build.cumul[lane] = excl; if (lane == 63) L.u.build.cumul[64] = incl;
+    L.u.build.symCount[lane] = excl;
     if (lane <= maxSym) {
         if (nv == 0) { ct.deltaNbBits[lane] = ((tableLog + 1) << 16) - (1u << tableLog); ct.deltaFindState[lane] = 0; }
         else if (nv == 1) { ct.deltaNbBits[lane] = (tableLog << 16) - (1u << tableLog); ct.deltaFindState[lane] = (int)excl - 1; }
@@ -713,15 +719,15 @@ __device__ static void buildCTableWave(SeqLds &L, FseCT &ct, const int16_t *norm
     for (uint32_t j = lane; j < tableSize; j += 64) {
         // symbol owning slot j : last s with cumul[s] <= j
         uint32_t lo = 0, hi = maxSym + 1;
-        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.cumul[mid] <= j) lo = mid; else hi = mid; }
-        L.tableSymbol[(j * step) & tableMask] = (uint8_t)lo;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.u.build.cumul[mid] <= j) lo = mid; else hi = mid; }
+        L.u.build.tableSymbol[(j * step) & tableMask] = (uint8_t)lo;
     }
     __syncthreads();
     // stateTable[cumul[sym] + (rank of cell u among the cells of sym)] = tableSize + u, cells taken in ascending u
     for (uint32_t base = 0; base < tableSize; base += 64) {
         const uint32_t u = base + lane;
         const bool in = u < tableSize;
-        const uint32_t sym = in ? L.tableSymbol[u] : 0xFFFFu;
+        const uint32_t sym = in ? L.u.build.tableSymbol[u] : 0xFFFFu;
         uint64_t todo = __ballot(in);
         while (todo) {
             const int leader = __builtin_ctzll(todo);
@@ -729,10 +735,10 @@ __device__ static void buildCTableWave(SeqLds &L, FseCT &ct, const int16_t *norm
             const uint64_t same = __ballot(in && sym == ls);
             if (in && sym == ls) {
                 const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1));
-                ct.stateTable[L.symCount[ls] + rank] = (uint16_t)(tableSize + u);
+                ct.stateTable[L.u.build.symCount[ls] + rank] = (uint16_t)(tableSize + u);
             }
             __syncthreads();
-            if (lane == (uint32_t)leader) L.symCount[ls] += (uint32_t)__popcll(same);
+            if (lane == (uint32_t)leader) L.u.build.symCount[ls] += (uint32_t)__popcll(same);
             __syncthreads();
             todo &= ~same;
         }
@@ -749,18 +755,18 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
     const uint32_t lane = (uint32_t)zs_lane();
     const ZsBlockDesc bd = blocks[blk];
     const uint32_t n = bd.size;
-    ZsSeqRec *seqBase = seqAll + (size_t)blk * ZS_MAX_RANGES * ZS_SEQ_PER_RANGE;
-    const ZsRangeHdr *hdr = hdrAll + (size_t)blk * ZS_MAX_RANGES;
+    ZsSeqRec *seqBase = seqAll + (size_t)blk * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE;
+    const ZsRangeHdr *hdr = hdrAll + (size_t)blk * ZS_WALK_RANGES;
     uint8_t *out = seqSecAll + (size_t)blk * ZS_SEQSEC_STRIDE;         // 4-byte aligned
     const uint32_t cap = n + 512;
 
     #define FINISH(sz) do { if (lane == 0) metas[blk].seqSecSize = (sz); return; } while (0)
     if (n < 16) FINISH(0xFFFFFFFFu);
 
-    if (lane == 0) loadRanges(hdr, L.rngN, L.rngCarry, L.rngStart, &L.misc[1]);
+    loadRangesWave(hdr, L.rngN, L.rngCarry, L.rngStart, nullptr, &L.misc[1], &L.misc[2]);
     for (uint32_t i = lane; i < 192; i += 64) L.count[i] = 0;
     __syncthreads();
-    const uint32_t nseq = L.rngStart[8];
+    const uint32_t nseq = L.rngStart[ZS_WALK_RANGES];
     const uint32_t *rngN = L.rngN, *rngCarry = L.rngCarry;
 
     // ---- sequences section header (inverse of DecodeSeqHeaders, ZStdDecompress.cs:1110-1180) ----
@@ -780,42 +786,46 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
     {
         uint32_t cPrev, cA, cB;                       // carried: previous offset (= rep0), rep1, rep2
         if (bd.firstInChunk) { cPrev = 1; cA = 4; cB = 8; } else { cPrev = 0xFFFFFFF1u; cA = 0xFFFFFFF2u; cB = 0xFFFFFFF3u; }
-        #pragma unroll 1
-        for (uint32_t r = 0; r < ZS_MAX_RANGES; r++) {
-            const uint32_t ns = rngN[r];
-            ZsSeqRec *sq = seqBase + (size_t)r * ZS_SEQ_PER_RANGE;
-            for (uint32_t base = 0; base < ns; base += 64) {
-                const uint32_t k = base + lane;
-                const bool in = k < ns;
-                uint32_t off = 0, ll = 0, ml = 0;
-                if (in) { const ZsSeqRec rec = sq[k]; off = rec.off; ll = rec.ll; ml = rec.ml & 0x3FFFu; if (k == 0) ll += rngCarry[r]; }
-                uint32_t prev = (uint32_t)__shfl_up((int)off, 1); if (lane == 0) prev = cPrev;        // rep0 before me
-                const bool change = in && !(ll > 0 && off == prev);
-                const int j = lastFlagBelow(change);                                                  // last changing sequence before me
-                const uint32_t aSh = (uint32_t)__shfl((int)prev, max(j, 0));                          // every lane takes part: a source lane must be active
-                const uint32_t a = (j >= 0) ? aSh : cA;                                               // rep1 before me
-                const bool reset = change && (off != a);                                              // sequences after which rep2 = their rep1
-                const int kk = lastFlagBelow(reset);
-                const uint32_t bSh = (uint32_t)__shfl((int)a, max(kk, 0));
-                const uint32_t b = (kk >= 0) ? bSh : cB;                                              // rep2 before me
-                uint32_t val = 0;
-                if (in) {
-                    if (ll) { val = (off == prev) ? 1u : (off == a) ? 2u : (off == b) ? 3u : 0u; }
-                    else    { val = (off == a) ? 1u : (off == b) ? 2u : 0u; }
-                    sq[k].ml = (uint16_t)(ml | (val << 14));
-                    const uint32_t v = val ? val : off + 3;
-                    atomicAdd(&L.count[llCodeOf(ll)], 1u);
-                    atomicAdd(&L.count[64 + zs_highbit(v)], 1u);
-                    atomicAdd(&L.count[128 + mlCodeOf(ml - 3)], 1u);
-                }
-                // carries for the next 64: state after the last sequence of this batch
-                const uint32_t cnt = min(64u, ns - base);
-                const uint64_t chm = __ballot(change), rsm = __ballot(reset);
-                const uint32_t lastOff = (uint32_t)__shfl((int)off, (int)(cnt - 1));
-                if (chm) { const int jl = 63 - __builtin_clzll(chm); cA = (uint32_t)__shfl((int)prev, jl); }
-                if (rsm) { const int kl = 63 - __builtin_clzll(rsm); cB = (uint32_t)__shfl((int)a, kl); }
-                cPrev = lastOff;
+        // sequences are taken 64 at a time in block order, whatever walk range they belong to
+        for (uint32_t base = 0; base < nseq; base += 64) {
+            const uint32_t g = base + lane;
+            const bool in = g < nseq;
+            uint32_t off = 0, ll = 0, ml = 0;
+            ZsSeqRec *rp = seqBase;
+            if (in) {
+                uint32_t rr = 0;
+                #pragma unroll
+                for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
+                const uint32_t k = g - L.rngStart[rr];
+                rp = seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + k;
+                const ZsSeqRec rec = *rp; off = rec.off; ll = rec.ll; ml = rec.ml & 0x3FFFu; if (k == 0) ll += rngCarry[rr];
             }
+            uint32_t prev = (uint32_t)__shfl_up((int)off, 1); if (lane == 0) prev = cPrev;        // rep0 before me
+            const bool change = in && !(ll > 0 && off == prev);
+            const int j = lastFlagBelow(change);                                                  // last changing sequence before me
+            const uint32_t aSh = (uint32_t)__shfl((int)prev, max(j, 0));                          // every lane takes part: a source lane must be active
+            const uint32_t a = (j >= 0) ? aSh : cA;                                               // rep1 before me
+            const bool reset = change && (off != a);                                              // sequences after which rep2 = their rep1
+            const int kk = lastFlagBelow(reset);
+            const uint32_t bSh = (uint32_t)__shfl((int)a, max(kk, 0));
+            const uint32_t b = (kk >= 0) ? bSh : cB;                                              // rep2 before me
+            if (in) {
+                uint32_t val;
+                if (ll) { val = (off == prev) ? 1u : (off == a) ? 2u : (off == b) ? 3u : 0u; }
+                else    { val = (off == a) ? 1u : (off == b) ? 2u : 0u; }
+                rp->ml = (uint16_t)(ml | (val << 14));
+                const uint32_t v = val ? val : off + 3;
+                atomicAdd(&L.count[llCodeOf(ll)], 1u);
+                atomicAdd(&L.count[64 + zs_highbit(v)], 1u);
+                atomicAdd(&L.count[128 + mlCodeOf(ml - 3)], 1u);
+            }
+            // carries for the next 64: state after the last sequence of this batch
+            const uint32_t cnt = min(64u, nseq - base);
+            const uint64_t chm = __ballot(change), rsm = __ballot(reset);
+            const uint32_t lastOff = (uint32_t)__shfl((int)off, (int)(cnt - 1));
+            if (chm) { const int jl = 63 - __builtin_clzll(chm); cA = (uint32_t)__shfl((int)prev, jl); }
+            if (rsm) { const int kl = 63 - __builtin_clzll(rsm); cB = (uint32_t)__shfl((int)a, kl); }
+            cPrev = lastOff;
         }
     }
     __syncthreads();
@@ -847,7 +857,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
             if (lane == 0) {
                 const int16_t *defNorm = t == 0 ? c_LL_defaultNorm : (t == 1 ? c_OF_defaultNorm : c_ML_defaultNorm);
                 for (uint32_t i = 0; i <= defMax; i++) L.norm[i] = defNorm[i];
-                buildCTable(ct, L.tableSymbol, L.cumul, L.norm, defMax, defLog);
+                buildCTable(ct, L.u.build.tableSymbol, L.u.build.cumul, L.norm, defMax, defLog);
             }
         } else {
             uint32_t tableLog = maxLog;
@@ -889,18 +899,18 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
             uint32_t ll = 0, ml = 0, val = 0, llc = 0, mlc = 0, ofc = 0;
             if (lane < T) {
                 const uint32_t g = remaining - 1 - lane;
-                uint32_t rr = 0;
+                uint32_t rr = 0;                                                  // last walk range whose first sequence index is <= g
                 #pragma unroll
-                for (uint32_t i = 1; i < ZS_MAX_RANGES; i++) if (g >= L.rngStart[i]) rr = i;
+                for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
                 const uint32_t k = g - L.rngStart[rr];
                 const ZsSeqRec rec = seqBase[(size_t)rr * ZS_SEQ_PER_RANGE + k];
                 ll = rec.ll; if (k == 0) ll += L.rngCarry[rr];
                 ml = rec.ml & 0x3FFFu; const uint32_t rep = rec.ml >> 14;
                 val = rep ? rep : (uint32_t)rec.off + 3;
                 llc = llCodeOf(ll); mlc = mlCodeOf(ml - 3); ofc = zs_highbit(val);
-                L.opNb[0][lane] = L.ct[0].deltaNbBits[llc]; L.opFind[0][lane] = L.ct[0].deltaFindState[llc];
-                L.opNb[1][lane] = L.ct[1].deltaNbBits[ofc]; L.opFind[1][lane] = L.ct[1].deltaFindState[ofc];
-                L.opNb[2][lane] = L.ct[2].deltaNbBits[mlc]; L.opFind[2][lane] = L.ct[2].deltaFindState[mlc];
+                L.u.tile.opNb[0][lane] = L.ct[0].deltaNbBits[llc]; L.u.tile.opFind[0][lane] = L.ct[0].deltaFindState[llc];
+                L.u.tile.opNb[1][lane] = L.ct[1].deltaNbBits[ofc]; L.u.tile.opFind[1][lane] = L.ct[1].deltaFindState[ofc];
+                L.u.tile.opNb[2][lane] = L.ct[2].deltaNbBits[mlc]; L.u.tile.opFind[2][lane] = L.ct[2].deltaFindState[mlc];
             }
             __syncthreads();
             if (lane < 3) {
@@ -908,30 +918,30 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
                 if (!ct.rle) {
                     uint32_t t = 0;
                     if (first) {
-                        const uint32_t dnb = L.opNb[lane][0];
+                        const uint32_t dnb = L.u.tile.opNb[lane][0];
                         const uint32_t nbo = (dnb + (1u << 15)) >> 16;
                         const uint32_t v = (nbo << 16) - dnb;
-                        chainState = ct.stateTable[(v >> nbo) + L.opFind[lane][0]];
-                        L.tileState[lane][0] = 0;
+                        chainState = ct.stateTable[(v >> nbo) + L.u.tile.opFind[lane][0]];
+                        L.u.tile.tileState[lane][0] = 0;
                         t = 1;
                     }
-                    uint32_t dnb = (t < T) ? L.opNb[lane][t] : 0; int dfs = (t < T) ? L.opFind[lane][t] : 0;
+                    uint32_t dnb = (t < T) ? L.u.tile.opNb[lane][t] : 0; int dfs = (t < T) ? L.u.tile.opFind[lane][t] : 0;
                     for (; t < T; t++) {
-                        const uint32_t dnbN = (t + 1 < T) ? L.opNb[lane][t + 1] : 0; const int dfsN = (t + 1 < T) ? L.opFind[lane][t + 1] : 0;   // operands of the next step, ahead of the dependent lookup
+                        const uint32_t dnbN = (t + 1 < T) ? L.u.tile.opNb[lane][t + 1] : 0; const int dfsN = (t + 1 < T) ? L.u.tile.opFind[lane][t + 1] : 0;   // operands of the next step, ahead of the dependent lookup
                         const uint32_t nbo = (chainState + dnb) >> 16;
-                        L.tileState[lane][t] = (chainState & ((1u << nbo) - 1)) | (nbo << 16);
+                        L.u.tile.tileState[lane][t] = (chainState & ((1u << nbo) - 1)) | (nbo << 16);
                         chainState = ct.stateTable[(chainState >> nbo) + dfs];
                         dnb = dnbN; dfs = dfsN;
                     }
                 } else {
-                    for (uint32_t t = 0; t < T; t++) L.tileState[lane][t] = 0;
+                    for (uint32_t t = 0; t < T; t++) L.u.tile.tileState[lane][t] = 0;
                 }
             }
             __syncthreads();
             uint64_t lo = 0; uint32_t hi = 0, nb = 0;
             if (lane < T) {
                 #define PUTB(v, b) { const uint32_t b_ = (b); if (b_) { const uint64_t v_ = (uint64_t)(v); if (nb < 64) { lo |= v_ << nb; if (nb + b_ > 64) hi |= (uint32_t)(v_ >> (64 - nb)); } else hi |= (uint32_t)(v_ << (nb - 64)); nb += b_; } }
-                const uint32_t sOF = L.tileState[1][lane], sML = L.tileState[2][lane], sLL = L.tileState[0][lane];
+                const uint32_t sOF = L.u.tile.tileState[1][lane], sML = L.u.tile.tileState[2][lane], sLL = L.u.tile.tileState[0][lane];
                 PUTB(sOF & 0xFFFFu, sOF >> 16);
                 PUTB(sML & 0xFFFFu, sML >> 16);
                 PUTB(sLL & 0xFFFFu, sLL >> 16);

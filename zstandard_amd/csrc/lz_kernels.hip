@@ -120,51 +120,57 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_lz_walk : one wavefront per block; the 64 lanes are 8 independent walkers of 8 lanes, walker g
-// walks range g.  A walker step: its 8 lanes read dist[ip .. ip+64) (8 positions each), the first
-// LOOK positions holding a candidate go one per lane; a lane compares 64 bytes forward and 32 bytes
-// backward (into the pending literals) for its candidate with one round of loads (ZS_FCAP / ZS_BCAP bytes), scores it, the
-// best one of the walker becomes a sequence (extended by the walker's 8 lanes if it hit the 64-byte
-// cap).  Eight dependent chains per wavefront hide each other's memory latency.
+// k_lz_walk : one workgroup of 8 wavefronts per block.  The block's source bytes are staged in LDS once
+// (64 KiB + pads), so every compare of the walk is an LDS read and the block is fetched from HBM once.
+// The 512 lanes are 64 independent walkers of 8 lanes; walker g walks the walk range g (1 KiB).
+// A walker step: its 8 lanes read dist[ip .. ip+64) (8 positions each, global, coalesced); the first LOOK
+// positions holding a candidate go one per lane; a lane compares 16 bytes forward (the score counts
+// ZS_FCAP of them) and 8 bytes backward (into the pending literals) for its candidate, scores it; the
+// best one of the walker becomes a sequence (extended by the walker's 8 lanes if it hit the 16-byte cap).
 // Scalar statement: walkRange in oracle/zso_encoder.c.
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint64_t load64_fwd(const uint8_t *s, uint32_t pos, uint32_t n)
-{
-    // bytes s[pos .. pos+8), positions >= n read as 0   (n >= 8)
-    const uint32_t a = min(pos, n - 8u);
-    const uint32_t sh = pos - a;
-    const uint64_t w = zs_load64(s + a);
-    return sh >= 8u ? 0ull : (w >> (8u * sh));
-}
-__device__ __forceinline__ uint64_t load64_bwd(const uint8_t *s, int32_t pos)
-{
-    // bytes s[pos .. pos+8), positions < 0 read as 0   (pos + 8 > 0 not required)
-    const int32_t a = max(pos, 0);
-    const uint32_t sh = (uint32_t)(a - pos);
-    const uint64_t w = zs_load64(s + a);
-    return sh >= 8u ? 0ull : (w << (8u * sh));
-}
+#define ZS_WALK_FRONT 16u          // LDS bytes in front of the block (backward reads near position 0)
+#define ZS_WALK_TAIL  144u         // zero bytes behind the block (forward reads near the end)
+#define ZS_WALK_LDS   (ZS_WALK_FRONT + ZS_BLOCK_MAX + ZS_WALK_TAIL + 8u * 8u * 64u * 2u)
 
-#define ZS_WALK_WAVES 4
-extern "C" __global__ void __launch_bounds__(64 * ZS_WALK_WAVES)
+__device__ __forceinline__ uint64_t lds64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+
+extern "C" __global__ void __launch_bounds__(512)
 k_lz_walk(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ blocks,
           const uint16_t *__restrict__ distAll, ZsSeqRec *__restrict__ seqAll, ZsRangeHdr *__restrict__ hdrAll,
-          int look, uint32_t nBlocks)
+          int look)
 {
-    __shared__ __attribute__((aligned(16))) uint16_t winDist[ZS_WALK_WAVES][8][64];
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t blk = blockIdx.x * ZS_WALK_WAVES + wave;
-    if (blk >= nBlocks) return;                                   // no workgroup barrier is used below
+    extern __shared__ __attribute__((aligned(16))) uint8_t walkLds[];
+    uint8_t *ls = walkLds + ZS_WALK_FRONT;                                       // ls[p] = source byte p
+    uint16_t *winAll = reinterpret_cast<uint16_t *>(walkLds + ZS_WALK_FRONT + ZS_BLOCK_MAX + ZS_WALK_TAIL);
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    const uint32_t blk = blockIdx.x;
     const ZsBlockDesc bd = blocks[blk];
     const uint8_t *s = src + bd.srcOff;
     const uint32_t n = bd.size;
     const uint16_t *dist = distAll + (size_t)blk * ZS_BLOCK_MAX;
     const uint32_t grp = lane >> 3, sub = lane & 7u;
-    ZsSeqRec *seqs = seqAll + ((size_t)blk * ZS_MAX_RANGES + grp) * ZS_SEQ_PER_RANGE;
-    uint16_t *win = winDist[wave][grp];
-    const uint32_t start = grp << ZS_RANGE_LOG;
+    const uint32_t walker = wave * 8 + grp;
+    ZsSeqRec *seqs = seqAll + ((size_t)blk * ZS_WALK_RANGES + walker) * ZS_SEQ_PER_RANGE;
+    uint16_t *win = winAll + (wave * 8 + grp) * 64;
+
+    // ---- stage the block ----
+    if (tid < ZS_WALK_FRONT / 4) reinterpret_cast<uint32_t *>(walkLds)[tid] = 0;
+    for (uint32_t i = tid * 16; i < n + ZS_WALK_TAIL; i += 512 * 16) {
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (i + 16 <= n) __builtin_memcpy(&v, s + i, 16);
+        else if (i < n) {
+            uint64_t lo = 0, hi = 0;
+            for (uint32_t k = 0; k < 16 && i + k < n; k++) { const uint64_t c = s[i + k]; if (k < 8) lo |= c << (8 * k); else hi |= c << (8 * (k - 8)); }
+            v = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+        }
+        if (i + 16 <= ZS_BLOCK_MAX + ZS_WALK_TAIL) *reinterpret_cast<uint4 *>(ls + i) = v;
+    }
+    __syncthreads();
+
+    const uint32_t start = walker << ZS_WALK_LOG;
     const bool alive = (start < n) && (n >= 16);
-    const uint32_t end = min(start + ZS_RANGE_SIZE, n);
+    const uint32_t end = min(start + ZS_WALK_SIZE, n);
     const uint32_t hashable = (n >= 4) ? n - 3 : 0;
     const uint32_t scanEnd = alive ? min(end, hashable) : 0;
 
@@ -194,27 +200,19 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ block
         { uint64_t mm = m64; for (uint32_t t = 0; t < sub; t++) mm &= mm - 1; idx = mm ? (uint32_t)__builtin_ctzll(mm) : 0u; }
         const uint32_t off = active ? (uint32_t)win[idx] : 0u;
         const uint32_t q = ip + idx;
-        // ---- one round of loads: 64 bytes forward, 32 bytes backward, both sides ----
+        // ---- compare from LDS: 16 bytes forward, 8 bytes backward, both sides ----
         uint32_t fwd = 0, back = 0;
         int key = 0;
         if (active) {
-            // 16 bytes forward (the score only counts ZS_FCAP of them; the rest saves most extension rounds),
-            // 8 bytes backward, both sides: 6 loads
-            const uint64_t fa0 = load64_fwd(s, q, n), fa1 = load64_fwd(s, q + 8, n);
-            const uint64_t fb0 = load64_fwd(s, q - off, n), fb1 = load64_fwd(s, q - off + 8, n);
-            const uint64_t ba = load64_bwd(s, (int32_t)q - 8), bb = load64_bwd(s, (int32_t)(q - off) - 8);
+            const uint8_t *pa = ls + q, *pb = ls + q - off;
+            const uint64_t x0 = lds64(pa) ^ lds64(pb), x1 = lds64(pa + 8) ^ lds64(pb + 8);
+            const uint64_t xb = lds64(pa - 8) ^ lds64(pb - 8);
             const uint32_t cap = min(end - q, ZS_LCAP);
-            {
-                const uint64_t x0 = fa0 ^ fb0, x1 = fa1 ^ fb1;
-                const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
-                const uint32_t n1 = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u;
-                fwd = min((n0 < 8u) ? n0 : 8u + n1, cap);
-            }
-            {
-                const uint32_t maxBack = min(min(q - anchor, q - off), ZS_BCAP);
-                const uint64_t x = ba ^ bb;
-                back = min(x ? ((uint32_t)__builtin_clzll(x) >> 3) : 8u, maxBack);
-            }
+            const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
+            const uint32_t n1 = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u;
+            fwd = min((n0 < 8u) ? n0 : 8u + n1, cap);
+            const uint32_t maxBack = min(min(q - anchor, q - off), ZS_BCAP);
+            back = min(xb ? ((uint32_t)__builtin_clzll(xb) >> 3) : 8u, maxBack);
             if (fwd >= ZS_MINMATCH) {
                 const int gain = (int)(min(fwd, ZS_FCAP) + back) * 4 - (int)zs_highbit(off + 1) - 4 * ((int)(q - back) - (int)ip) - (int)(q - ip);
                 key = ((gain + 2048) << 3) | (int)(7u - sub);
@@ -230,7 +228,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ block
         uint32_t bfwd = (uint32_t)__shfl((int)fwd, (int)bl);
         const uint32_t bback = (uint32_t)__shfl((int)back, (int)bl);
         const bool took = run && best != 0;
-        // ---- long match: the walker's 8 lanes extend it, 128 bytes per round ----
+        // ---- long match: the walker's 8 lanes extend it, 128 bytes per round (LDS) ----
         bool need = took && bfwd == ZS_LCAP && (end - bq) > ZS_LCAP;
         const bool extended = need;
         uint32_t pos = bq + ZS_LCAP;
@@ -238,16 +236,13 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ block
             uint32_t nb = 0;
             if (need) {
                 const uint32_t cap = end - pos;            // pos < end while need
-                #pragma unroll
-                for (uint32_t h = 0; h < 2; h++) {
-                    const uint32_t fo = 16 * sub + 8 * h;
-                    uint32_t m = 0;
-                    if (fo < cap) {
-                        const uint64_t x = load64_fwd(s, pos + fo, n) ^ load64_fwd(s, pos - boff + fo, n);
-                        m = x ? ((uint32_t)__builtin_ctzll(x) >> 3) : 8u;
-                        m = min(m, cap - fo);
-                    }
-                    if (h == 0) nb = m; else if (nb == 8u) nb += m;
+                const uint32_t fo = 16 * sub;
+                if (fo < cap) {
+                    const uint8_t *pa = ls + pos + fo, *pb = ls + pos - boff + fo;
+                    const uint64_t x0 = lds64(pa) ^ lds64(pb), x1 = lds64(pa + 8) ^ lds64(pb + 8);
+                    const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
+                    const uint32_t n1 = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u;
+                    nb = min((n0 < 8u) ? n0 : 8u + n1, cap - fo);
                 }
             }
             const uint64_t stopm = __ballot(nb < 16u);
@@ -270,5 +265,5 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ block
             ip = bq + bfwd; anchor = ip;
         } else if (run) ip = wend;
     }
-    if (sub == 0) { ZsRangeHdr h; h.nseq = nseq; h.trailing = alive ? end - anchor : ((start < n) ? end - start : 0u); h.litSum = litSum; h.pad = 0; hdrAll[(size_t)blk * ZS_MAX_RANGES + grp] = h; }
+    if (sub == 0) { ZsRangeHdr h; h.nseq = nseq; h.trailing = alive ? end - anchor : ((start < n) ? end - start : 0u); h.litSum = litSum; h.pad = 0; hdrAll[(size_t)blk * ZS_WALK_RANGES + walker] = h; }
 }

@@ -162,6 +162,7 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; } c->ownStream = true; }
     // the candidate kernel uses up to 128 KiB of dynamic LDS
     (void)hipFuncSetAttribute((const void *)k_lz_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    (void)hipFuncSetAttribute((const void *)k_lz_walk, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS);
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_OVERLAP")) c->overlapEntropy = atoi(e) != 0;
     if (const char *e = getenv("ZSMI_STOP_LIT")) c->stopLit = atoi(e);
@@ -277,8 +278,8 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
     if (cap < maxChunkBlocks) cap = maxChunkBlocks;
     for (int i = 0; i < nLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
-        if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2) || !L.dSeqs.reserve((size_t)cap * ZS_MAX_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
-            !L.dHdrs.reserve((size_t)cap * ZS_MAX_RANGES * sizeof(ZsRangeHdr)) || !L.dLits.reserve((size_t)cap * (ZS_BLOCK_MAX + 64)) ||
+        if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2 + 256) || !L.dSeqs.reserve((size_t)cap * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
+            !L.dHdrs.reserve((size_t)cap * ZS_WALK_RANGES * sizeof(ZsRangeHdr)) || !L.dLits.reserve((size_t)cap * (ZS_BLOCK_MAX + 64)) ||
             !L.dStreams.reserve((size_t)cap * 4 * ZS_STREAM_STRIDE) || !L.dLitSec.reserve((size_t)cap * ZS_LITSEC_STRIDE) ||
             !L.dSeqSec.reserve((size_t)cap * ZS_SEQSEC_STRIDE) || !L.dMetas.reserve((size_t)cap * sizeof(ZsBlockMeta))) return ZSMI_error_memory_allocation;
     }
@@ -294,8 +295,8 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         zsmi_ctx::Scratch &L = c->lanes[turn % nLanes]; turn++;
         hipStream_t st = L.stream;
         LAUNCH_ON(c, st, "k_lz_candidates", k_lz_candidates, dim3(nb), dim3(512), lds, (const uint8_t *)dSrc, dB, (uint16_t *)L.dDist.p, hashLog);
-        LAUNCH_ON(c, st, "k_lz_walk", k_lz_walk, dim3((nb + ZS_WALK_WAVES - 1) / ZS_WALK_WAVES), dim3(64 * ZS_WALK_WAVES), 0, (const uint8_t *)dSrc, dB, (const uint16_t *)L.dDist.p,
-                  (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look, nb);
+        LAUNCH_ON(c, st, "k_lz_walk", k_lz_walk, dim3(nb), dim3(512), ZS_WALK_LDS, (const uint8_t *)dSrc, dB, (const uint16_t *)L.dDist.p,
+                  (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
         // the two entropy kernels are independent of each other: the sequences kernel runs on a side stream beside the literals kernel
         const bool overlap = c->overlapEntropy;
         hipStream_t st2 = overlap ? L.aux : st;
