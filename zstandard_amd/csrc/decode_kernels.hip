@@ -67,30 +67,39 @@ __device__ __forceinline__ uint32_t rd32(const uint8_t *p) { return zs_load32(p)
 
 // ---- backward bit reader (BitStream.cs:322-494).  64-bit container here; the reference's 32-bit reload
 //      points only decide where a damaged stream is rejected, the bits read are the same. ----
-struct BitR { const uint8_t *start; uint32_t size; int64_t bitPos; /* number of unread bits below the cursor */ uint32_t err; };
+struct BitR { const uint8_t *start; uint32_t size; int64_t bitPos; /* number of unread bits below the cursor */ uint32_t err;
+              uint64_t cont; int64_t contLo; /* cont = stream bits [contLo, contLo + 64) */ };
+__device__ __forceinline__ void br_fill(BitR &b)
+{
+    // 8 bytes whose top byte holds the bit just below the cursor (or the first 8 bytes of the stream)
+    int64_t b0 = 0;
+    if (b.size >= 8) {
+        b0 = ((b.bitPos - 1) >> 3) - 7; if (b0 < 0) b0 = 0;
+        if (b0 > (int64_t)b.size - 8) b0 = (int64_t)b.size - 8;
+        b.cont = zs_load64(b.start + b0);
+    } else {
+        uint64_t w = 0;
+        for (uint32_t k = 0; k < b.size; k++) w |= (uint64_t)b.start[k] << (8 * k);
+        b.cont = w;
+    }
+    b.contLo = 8 * b0;
+}
 __device__ __forceinline__ void br_init(BitR &b, const uint8_t *src, uint32_t size)
 {
-    b.start = src; b.size = size; b.err = 0; b.bitPos = 0;
+    b.start = src; b.size = size; b.err = 0; b.bitPos = 0; b.cont = 0; b.contLo = 0;
     if (size == 0) { b.err = 1; return; }
     const uint32_t last = src[size - 1];
     if (last == 0) { b.err = 1; return; }
     b.bitPos = (int64_t)size * 8 - (int64_t)(8 - zs_highbit(last));      // bits below the end mark
+    br_fill(b);
 }
 // next n bits (n <= 32) below the cursor, most significant first; bits below the stream start read as 0
-__device__ __forceinline__ uint32_t br_look(const BitR &b, uint32_t n)
+__device__ __forceinline__ uint32_t br_look(BitR &b, uint32_t n)
 {
     if (n == 0 || b.bitPos <= 0) return 0;
-    const int64_t lo = b.bitPos - (int64_t)n;           // lowest stream bit wanted (may be negative)
-    uint64_t w; int64_t b0;
-    if (b.size >= 8) {
-        b0 = ((b.bitPos - 1) >> 3) - 7; if (b0 < 0) b0 = 0;
-        w = zs_load64(b.start + b0);
-    } else {
-        b0 = 0; w = 0;
-        for (uint32_t k = 0; k < b.size; k++) w |= (uint64_t)b.start[k] << (8 * k);
-    }
-    const int64_t rel = lo - 8 * b0;
-    const uint64_t v = (rel >= 0) ? (w >> (uint32_t)rel) : ((rel <= -64) ? 0ull : (w << (uint32_t)(-rel)));
+    int64_t rel = b.bitPos - (int64_t)n - b.contLo;       // position of the lowest wanted bit inside cont
+    if (rel < 0 && b.contLo > 0) { br_fill(b); rel = b.bitPos - (int64_t)n - b.contLo; }
+    const uint64_t v = (rel >= 0) ? (b.cont >> (uint32_t)rel) : ((rel <= -64) ? 0ull : (b.cont << (uint32_t)(-rel)));
     return (uint32_t)(v & ((n >= 32) ? 0xFFFFFFFFull : ((1ull << n) - 1)));
 }
 __device__ __forceinline__ uint32_t br_read(BitR &b, uint32_t n) { const uint32_t v = br_look(b, n); b.bitPos -= n; return v; }
