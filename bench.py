@@ -116,8 +116,17 @@ def main():
             per_launch_bytes = (nbytes + comp_bytes) * args.steps / launches
             avg = secs / launches
             achieved = per_launch_bytes / avg / 1e9
+            # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE), scaled to this launch size
+            traffic = None
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))["kernels"].get(name)
+                if tj:
+                    traffic = int(tj["hbm_bytes"] * (n * args.steps / launches) / tj["blocks_per_launch"])
+            except Exception:
+                traffic = None
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None, "avg_launch_ms": round(avg * 1e3, 4),
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch_bytes),
+                        "avg_launch_ms": round(avg * 1e3, 4),
                         "kernels_ms_per_step": {k: round(v[0] / args.steps * 1e3, 4) for k, v in ktimes.items()}}
         # exactness spot check of the timed output + ratio yardstick
         import _oracle as O
