@@ -68,8 +68,7 @@ struct SeqLds {                      // sequences kernel.  Kept under 10 KiB: 16
     int16_t norm[64];
     union {
         struct { uint8_t tableSymbol[512]; uint32_t cumul[66]; uint32_t symCount[64]; } build;      // while a table is built
-        struct { uint32_t opNb[3][64];       // per tile: deltaNbBits of each sequence's code
-                 int32_t  opFind[3][64];     // per tile: deltaFindState
+        struct { uint2    op[3][66];         // per tile and table: {deltaNbBits, deltaFindState} of each sequence's code (+ padding)
                  uint32_t tileState[3][64];  // per tile: state bits out (value | nbBits << 16)
                } tile;                                                                                 // while the bitstream is written
     } u;
@@ -894,47 +893,67 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
     {
         uint32_t remaining = nseq;
         bool first = true;
-        while (remaining) {
-            const uint32_t T = min(64u, remaining);
-            uint32_t ll = 0, ml = 0, val = 0, llc = 0, mlc = 0, ofc = 0;
-            if (lane < T) {
-                const uint32_t g = remaining - 1 - lane;
+        // sequence records are fetched one tile ahead: the loads of tile i+1 fly while the state chains of tile i run
+        ZsSeqRec recN; uint32_t carryN = 0; bool validN = false;
+        auto fetch = [&](uint32_t rem) {
+            validN = false; carryN = 0; recN.ll = recN.ml = recN.off = recN.flags = 0;
+            const uint32_t T2 = min(64u, rem);
+            if (lane < T2) {
+                const uint32_t g = rem - 1 - lane;
                 uint32_t rr = 0;                                                  // last walk range whose first sequence index is <= g
                 #pragma unroll
                 for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
                 const uint32_t k = g - L.rngStart[rr];
-                const ZsSeqRec rec = seqBase[(size_t)rr * ZS_SEQ_PER_RANGE + k];
-                ll = rec.ll; if (k == 0) ll += L.rngCarry[rr];
+                recN = seqBase[(size_t)rr * ZS_SEQ_PER_RANGE + k];
+                carryN = (k == 0) ? L.rngCarry[rr] : 0u;
+                validN = true;
+            }
+        };
+        fetch(remaining);
+        while (remaining) {
+            const uint32_t T = min(64u, remaining);
+            const ZsSeqRec rec = recN; const uint32_t carry = carryN; const bool valid = validN;
+            if (remaining > T) fetch(remaining - T);
+            uint32_t ll = 0, ml = 0, val = 0, llc = 0, mlc = 0, ofc = 0;
+            uint2 o0 = make_uint2(0, 0), o1 = o0, o2 = o0;
+            if (valid) {
+                ll = (uint32_t)rec.ll + carry;
                 ml = rec.ml & 0x3FFFu; const uint32_t rep = rec.ml >> 14;
                 val = rep ? rep : (uint32_t)rec.off + 3;
                 llc = llCodeOf(ll); mlc = mlCodeOf(ml - 3); ofc = zs_highbit(val);
-                L.u.tile.opNb[0][lane] = L.ct[0].deltaNbBits[llc]; L.u.tile.opFind[0][lane] = L.ct[0].deltaFindState[llc];
-                L.u.tile.opNb[1][lane] = L.ct[1].deltaNbBits[ofc]; L.u.tile.opFind[1][lane] = L.ct[1].deltaFindState[ofc];
-                L.u.tile.opNb[2][lane] = L.ct[2].deltaNbBits[mlc]; L.u.tile.opFind[2][lane] = L.ct[2].deltaFindState[mlc];
+                o0 = make_uint2(L.ct[0].deltaNbBits[llc], (uint32_t)L.ct[0].deltaFindState[llc]);
+                o1 = make_uint2(L.ct[1].deltaNbBits[ofc], (uint32_t)L.ct[1].deltaFindState[ofc]);
+                o2 = make_uint2(L.ct[2].deltaNbBits[mlc], (uint32_t)L.ct[2].deltaFindState[mlc]);
             }
+            L.u.tile.op[0][lane] = o0; L.u.tile.op[1][lane] = o1; L.u.tile.op[2][lane] = o2;
+            if (lane < 2) { L.u.tile.op[0][64 + lane] = make_uint2(0, 0); L.u.tile.op[1][64 + lane] = make_uint2(0, 0); L.u.tile.op[2][64 + lane] = make_uint2(0, 0); }
             __syncthreads();
             if (lane < 3) {
                 const FseCT &ct = L.ct[lane];
+                const uint2 *op = L.u.tile.op[lane];
+                uint32_t *outp = L.u.tile.tileState[lane];
                 if (!ct.rle) {
                     uint32_t t = 0;
                     if (first) {
-                        const uint32_t dnb = L.u.tile.opNb[lane][0];
+                        const uint32_t dnb = op[0].x;
                         const uint32_t nbo = (dnb + (1u << 15)) >> 16;
                         const uint32_t v = (nbo << 16) - dnb;
-                        chainState = ct.stateTable[(v >> nbo) + L.u.tile.opFind[lane][0]];
-                        L.u.tile.tileState[lane][0] = 0;
+                        chainState = ct.stateTable[(v >> nbo) + (int)op[0].y];
+                        outp[0] = 0;
                         t = 1;
                     }
-                    uint32_t dnb = (t < T) ? L.u.tile.opNb[lane][t] : 0; int dfs = (t < T) ? L.u.tile.opFind[lane][t] : 0;
-                    for (; t < T; t++) {
-                        const uint32_t dnbN = (t + 1 < T) ? L.u.tile.opNb[lane][t + 1] : 0; const int dfsN = (t + 1 < T) ? L.u.tile.opFind[lane][t + 1] : 0;   // operands of the next step, ahead of the dependent lookup
-                        const uint32_t nbo = (chainState + dnb) >> 16;
-                        L.u.tile.tileState[lane][t] = (chainState & ((1u << nbo) - 1)) | (nbo << 16);
-                        chainState = ct.stateTable[(chainState >> nbo) + dfs];
-                        dnb = dnbN; dfs = dfsN;
+                    // operands of step t+1 are read before the dependent table lookup of step t
+                    const uint32_t Tn = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
+                    uint2 cur = op[t];
+                    for (; t < Tn; t++) {
+                        const uint2 nxt = op[t + 1];
+                        const uint32_t nbo = (chainState + cur.x) >> 16;
+                        outp[t] = (chainState & ((1u << nbo) - 1)) | (nbo << 16);
+                        chainState = ct.stateTable[(chainState >> nbo) + (int)cur.y];
+                        cur = nxt;
                     }
                 } else {
-                    for (uint32_t t = 0; t < T; t++) L.u.tile.tileState[lane][t] = 0;
+                    for (uint32_t t = 0; t < T; t++) outp[t] = 0;
                 }
             }
             __syncthreads();
