@@ -175,3 +175,40 @@ def test_encode_128k_chunks_and_ragged(codec):
         c = data[int(offs[i]):int(offs[i]) + int(sizes[i])].tobytes()
         assert O.decompress(f, len(c)) == c
         assert f == O.compress(c, 3)
+
+
+def test_many_tiny_and_odd_chunks(codec):
+    """ragged batch: 3000 chunks of 0..3000 bytes, plus sizes around the block / frame-header boundaries"""
+    data = D.zipf_log(6 << 20, seed_lo=99)
+    rng = np.random.default_rng(11)
+    sizes = np.concatenate([rng.integers(0, 3000, 3000), [255, 256, 257, 65535, 65536, 65537, 65791, 65792, 131071, 131072, 131073, 262144, 0, 1, 15, 16, 17]]).astype(np.uint32)
+    offs = np.zeros(len(sizes), dtype=np.uint64); offs[1:] = np.cumsum(sizes.astype(np.uint64))[:-1]
+    assert int(offs[-1]) + int(sizes[-1]) <= len(data)
+    arena, do, dsz = codec.compress_host(data, offs, sizes, 3)
+    assert (dsz < ERR).all()
+    ea, eo, es = O.compress_batch(data, offs, sizes, 3, 8)
+    assert (dsz == es).all()
+    bad = [i for i in range(len(sizes)) if not (arena[int(do[i]):int(do[i]) + int(dsz[i])] == ea[int(eo[i]):int(eo[i]) + int(es[i])]).all()]
+    assert not bad, bad[:5]
+    frames = np.concatenate([arena[int(do[i]):int(do[i]) + int(dsz[i])] for i in range(len(sizes))])
+    fo = np.zeros(len(sizes), dtype=np.uint64); fo[1:] = np.cumsum(dsz.astype(np.uint64))[:-1]
+    out, oo, osz = codec.decompress_host(frames, fo, dsz, np.maximum(sizes, 1))
+    assert (osz == sizes).all()
+    for i in range(len(sizes)):
+        assert (out[int(oo[i]):int(oo[i]) + int(sizes[i])] == data[int(offs[i]):int(offs[i]) + int(sizes[i])]).all(), i
+
+
+def test_one_shot_large_frame(codec):
+    """one frame of 5 MiB + 123 bytes (81 blocks) through the reference-shaped API; decodes under oracle D and this decoder"""
+    from zstandard_amd import ZstdCompressor, ZStdDecompress
+    data = D.zipf_log((5 << 20) + 123, seed_lo=5).tobytes()
+    f = ZstdCompressor(3).compress(data)
+    assert f == O.compress(data, 3)
+    assert O.decompress(f, len(data)) == data
+    dst = bytearray(len(data))
+    assert ZStdDecompress.Decompress(dst, f) == len(data) and bytes(dst) == data
+    # incompressible and constant inputs take the raw / RLE block paths
+    rnd = np.random.default_rng(2).integers(0, 256, 300000, dtype=np.uint8).tobytes()
+    for blob in (rnd, bytes(300000), b"\\xAB" * 70001):
+        f = ZstdCompressor(3).compress(blob)
+        assert f == O.compress(blob, 3) and O.decompress(f, len(blob)) == blob
