@@ -16,7 +16,7 @@
 // range that has the hash, checks the 4 bytes and writes the match distance.
 // HBM/L2 traffic per block: reads n (twice, second time from cache) + n gathers; writes 2n (dist twice).
 // ---------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(512)
+extern "C" __global__ void __launch_bounds__(1024)
 k_lz_candidates(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ blocks,
                 uint16_t *__restrict__ distAll, int hashLog)
 {
@@ -33,7 +33,10 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__
     }
     __syncthreads();
 
-    const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    // 16 wavefronts: phase A (table order matters) is run by wavefronts 0..7, one table range each; phase B (position
+    // parallel) by all 16, two per range (each takes every other trip of 8 steps).
+    const uint32_t wave16 = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+    const uint32_t wave = wave16 & 7u, half = wave16 >> 3;
     const uint32_t start = wave << ZS_RANGE_LOG;
     const uint32_t hashable = (n >= 4) ? n - 3 : 0;                   // positions [0, hashable) have 4 bytes
     const uint32_t end = min(start + ZS_RANGE_SIZE, hashable);
@@ -42,7 +45,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__
     // 8 steps per trip.  The loads of trip t+1 are issued before trip t is worked on (registers double-buffered),
     // so the table walk of a trip runs under the memory latency of the next one.
     constexpr uint32_t U = 8;
-    {
+    if (half == 0) {
         uint32_t v[U], vn[U];
         #pragma unroll
         for (uint32_t u = 0; u < U; u++) { const uint32_t p = start + u * 64 + lane; v[u] = (p < end) ? zs_load32(s + p) : 0u; }
@@ -71,10 +74,11 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__
         // gathers (issued one trip earlier) are compared and stored.
         uint32_t v[U], cand[U], vn[U], candn[U], pv[U], pcand[U], pcv[U];
         uint32_t pbase = 0; bool havePrev = false;
+        const uint32_t first = start + half * 64 * U;
         #pragma unroll
-        for (uint32_t u = 0; u < U; u++) { const uint32_t p = start + u * 64 + lane; const bool in = p < end; v[u] = in ? zs_load32(s + p) : 0u; cand[u] = in ? (uint32_t)dist[p] : 0u; }
-        for (uint32_t base = start; base < end; base += 64 * U) {
-            const uint32_t nbase = base + 64 * U;
+        for (uint32_t u = 0; u < U; u++) { const uint32_t p = first + u * 64 + lane; const bool in = p < end; v[u] = in ? zs_load32(s + p) : 0u; cand[u] = in ? (uint32_t)dist[p] : 0u; }
+        for (uint32_t base = first; base < end; base += 2 * 64 * U) {
+            const uint32_t nbase = base + 2 * 64 * U;
             #pragma unroll
             for (uint32_t u = 0; u < U; u++) { const uint32_t p = nbase + u * 64 + lane; const bool in = p < end; vn[u] = in ? zs_load32(s + p) : 0u; candn[u] = in ? (uint32_t)dist[p] : 0u; }
             #pragma unroll
@@ -115,7 +119,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__
     // positions without 4 bytes left: no candidate
     {
         const uint32_t rend = min(start + ZS_RANGE_SIZE, n);
-        for (uint32_t p = max(end, start) + lane; p < rend; p += 64) dist[p] = 0;
+        if (half == 0) for (uint32_t p = max(end, start) + lane; p < rend; p += 64) dist[p] = 0;
     }
 }
 

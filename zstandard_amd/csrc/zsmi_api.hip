@@ -294,7 +294,7 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         const ZsBlockDesc *dB = (const ZsBlockDesc *)c->dBlocks.p + block0;
         zsmi_ctx::Scratch &L = c->lanes[turn % nLanes]; turn++;
         hipStream_t st = L.stream;
-        LAUNCH_ON(c, st, "k_lz_candidates", k_lz_candidates, dim3(nb), dim3(512), lds, (const uint8_t *)dSrc, dB, (uint16_t *)L.dDist.p, hashLog);
+        LAUNCH_ON(c, st, "k_lz_candidates", k_lz_candidates, dim3(nb), dim3(1024), lds, (const uint8_t *)dSrc, dB, (uint16_t *)L.dDist.p, hashLog);
         LAUNCH_ON(c, st, "k_lz_walk", k_lz_walk, dim3(nb), dim3(512), ZS_WALK_LDS, (const uint8_t *)dSrc, dB, (const uint16_t *)L.dDist.p,
                   (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
         // the two entropy kernels are independent of each other: the sequences kernel runs on a side stream beside the literals kernel
