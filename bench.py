@@ -148,10 +148,13 @@ def main():
         cpu = None
         if not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
-            m = min(n, max(256, 8 * cores))                       # bounded sample of the same workload
-            t1 = time.perf_counter()
-            O.compress_batch(host, offs[:m], sizes[:m], args.level, cores)
-            dt = time.perf_counter() - t1
+            m = min(n, max(256, 32 * cores))                      # bounded sample of the same workload (whole default batch)
+            dt = None
+            for _ in range(2):                                    # best of two: the first run pays the threads' workspace page faults
+                t1 = time.perf_counter()
+                O.compress_batch(host, offs[:m], sizes[:m], args.level, cores)
+                d = time.perf_counter() - t1
+                dt = d if dt is None else min(dt, d)
             cpu = {"value": round(m * cs / dt / (1 << 30), 4), "unit": "GiB/s", "cores": cores, "kind": "port",
                    "sample": f"{m} x {cs} B chunks of the same batch, oracle E (scalar statement of the HIP encoder), one thread per core"}
         out = {"metric": "GiB/s compress @ level 3, 64 KiB chunks", "value": round(value, 3), "unit": "GiB/s", "n_gpus": world,
