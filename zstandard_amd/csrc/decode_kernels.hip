@@ -454,7 +454,6 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
         if (L.misc[0]) return ZE(E_corruption_detected);
         (void)longOff;
         uint32_t left = nbSeq;
-        uint64_t syncedTo = op;                // output below this position is visible to every lane
         while (left) {
             const uint32_t T = min(64u, left);
             if (lane == 0) {
@@ -484,20 +483,67 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
             }
             __syncthreads();
             if (L.misc[0]) return ZE(E_corruption_detected);
-            // execute the tile (ExecSequence :1265-1352): literals then match, all lanes copy
-            for (uint32_t t = 0; t < T; t++) {
-                const uint32_t ll = L.tileLL[t], ml = L.tileML[t], off = L.tileOff[t];
-                if ((uint64_t)ll + ml > oend - op) return ZE(E_dstSize_tooSmall);
-                if (ll > litSize - litPos) return ZE(E_corruption_detected);
-                for (uint32_t j = lane; j < ll; j += 64) dstBase[op + j] = litPtr[litPos + j];
-                op += ll; litPos += ll;
-                if (off > op - frameStart) return ZE(E_corruption_detected);
-                const uint64_t mstart = op - off;
-                const uint64_t srcEnd = (off >= ml) ? mstart + ml : op;      // highest byte read (exclusive)
-                if (srcEnd > syncedTo) { __syncthreads(); syncedTo = op; }
-                if (off >= ml) { for (uint32_t j = lane; j < ml; j += 64) dstBase[op + j] = dstBase[mstart + j]; }
-                else { for (uint32_t j = lane; j < ml; j += 64) dstBase[op + j] = dstBase[mstart + (j % off)]; }   // period = offset
-                op += ml;
+            // execute the tile (ExecSequence :1265-1352).  Lane t owns sequence t: output positions by prefix sums, the checks
+            // of the reference in its order (the first failing sequence decides), then all literal runs at once, then all
+            // matches whose source lies before this tile's output at once, then the matches that read this tile's own output
+            // one after the other.
+            {
+                const uint32_t ll = (lane < T) ? L.tileLL[lane] : 0u, ml = (lane < T) ? L.tileML[lane] : 0u, off = (lane < T) ? L.tileOff[lane] : 0u;
+                uint32_t incl = ll + ml, inclL = ll;
+                #pragma unroll
+                for (int d = 1; d < 64; d <<= 1) { const uint32_t a = (uint32_t)__shfl_up((int)incl, d), c = (uint32_t)__shfl_up((int)inclL, d); if ((int)lane >= d) { incl += a; inclL += c; } }
+                const uint64_t outStart = op + (incl - ll - ml);              // where my literals go
+                const uint32_t litStart = litPos + (inclL - ll);
+                const uint64_t mdst = outStart + ll;                          // where my match goes
+                uint32_t err = 0;
+                if (lane < T) {
+                    if ((uint64_t)ll + ml > oend - outStart || outStart > oend) err = E_dstSize_tooSmall;
+                    else if (ll > litSize - litStart || litStart > litSize) err = E_corruption_detected;
+                    else if (off > mdst - frameStart) err = E_corruption_detected;
+                }
+                const uint64_t em = __ballot(err != 0);
+                if (em) return ZE((uint32_t)__shfl((int)err, __builtin_ctzll(em)));
+                const uint64_t tileStart = op;
+                // literals
+                if (ll && ll <= 16) {
+                    if (litStart + 16 <= litSize) {
+                        const uint64_t a = zs_load64(litPtr + litStart), c = zs_load64(litPtr + litStart + 8);
+                        for (uint32_t j = 0; j < ll; j++) dstBase[outStart + j] = (uint8_t)(j < 8 ? a >> (8 * j) : c >> (8 * (j - 8)));
+                    } else for (uint32_t j = 0; j < ll; j++) dstBase[outStart + j] = litPtr[litStart + j];
+                }
+                for (uint64_t lm = __ballot(ll > 16); lm; lm &= lm - 1) {
+                    const int t = __builtin_ctzll(lm);
+                    const uint32_t l2 = (uint32_t)__shfl((int)ll, t), s2 = (uint32_t)__shfl((int)litStart, t);
+                    const uint64_t d2 = (uint64_t)__shfl((long long)outStart, t);
+                    for (uint32_t j = lane; j < l2; j += 64) dstBase[d2 + j] = litPtr[s2 + j];
+                }
+                __syncthreads();
+                // matches reading only output that existed before this tile
+                const uint64_t msrc = mdst - off;
+                const bool indep = ml && (msrc + ml <= tileStart);
+                if (indep && ml <= 32) {
+                    uint32_t j = 0;
+                    for (; j + 8 <= ml; j += 8) { const uint64_t v = zs_load64(dstBase + msrc + j); __builtin_memcpy(dstBase + mdst + j, &v, 8); }
+                    for (; j < ml; j++) dstBase[mdst + j] = dstBase[msrc + j];
+                }
+                for (uint64_t lm = __ballot(indep && ml > 32); lm; lm &= lm - 1) {
+                    const int t = __builtin_ctzll(lm);
+                    const uint32_t m2 = (uint32_t)__shfl((int)ml, t);
+                    const uint64_t s2 = (uint64_t)__shfl((long long)msrc, t), d2 = (uint64_t)__shfl((long long)mdst, t);
+                    for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j];
+                }
+                __syncthreads();
+                // matches reading this tile's own output (earlier sequences are complete by then), in order
+                for (uint64_t dm = __ballot(ml && !indep); dm; dm &= dm - 1) {
+                    const int t = __builtin_ctzll(dm);
+                    const uint32_t m2 = (uint32_t)__shfl((int)ml, t), o2 = (uint32_t)__shfl((int)off, t);
+                    const uint64_t s2 = (uint64_t)__shfl((long long)msrc, t), d2 = (uint64_t)__shfl((long long)mdst, t);
+                    if (o2 >= m2) { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j]; }
+                    else { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + (j % o2)]; }      // period = offset
+                    __syncthreads();
+                }
+                op += (uint32_t)__shfl((int)incl, 63);
+                litPos += (uint32_t)__shfl((int)inclL, 63);
             }
             left -= T;
         }
