@@ -21,6 +21,21 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0            # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def usable_cores():
+    """threads for the CPU baseline: the cgroup CPU quota if there is one, else the affinity mask (the GPU boxes expose all
+    host CPUs but give a job a share of about 16); ZSMI_CPU_THREADS overrides"""
+    if os.environ.get("ZSMI_CPU_THREADS"):
+        return max(1, int(os.environ["ZSMI_CPU_THREADS"]))
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return min(n, 64)
+
+
 def load_corpus(path, nbytes, rank):
     data = np.fromfile(path, dtype=np.uint8)
     if len(data) == 0:
@@ -147,7 +162,7 @@ def main():
             ratio_vs_zstd = round(z / e, 4)          # > 1: smaller than libzstd ; 0.99 = 1 % larger
         cpu = None
         if not args.no_cpu_baseline:
-            cores = os.cpu_count() or 1
+            cores = usable_cores()
             m = min(n, max(256, 32 * cores))                      # bounded sample of the same workload (whole default batch)
             dt = None
             for _ in range(2):                                    # best of two: the first run pays the threads' workspace page faults
