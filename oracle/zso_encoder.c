@@ -15,15 +15,17 @@
  * upstream libzstd 1.4.8 in tests.  Ratio parity "vs the reference" is unpinned by the
  * reference (no encoder exists); the stated yardstick is libzstd level 3.
  *
- * Algorithm (one frame per chunk, blocks of <= 64 KiB, each block independent):
- *  1. candidates: the block is cut in RANGES of 8 KiB; each range owns a hash table
- *     (2^HASH_LOG entries).  Position p hashes its 4 bytes, gets the previous position
- *     with the same hash in its own range (prev = T[h]; T[h] = p), else the last
- *     position with that hash in the nearest earlier range that has one.  A candidate
- *     is kept when its 4 bytes equal those at p.  -> dist[p]
- *  2. parse: the block is cut again, in walk ranges of 1 KiB; each is walked greedily and independently: next position with a
- *     candidate (or a 4-byte match at the previous offset), forward extension to the
- *     range end, one sequence per match.
+ * Algorithm (one frame per chunk, blocks of <= 64 KiB; match search works on LZ UNITS of <= 128 KiB =
+ * two consecutive blocks of a chunk, so the second block of a unit may copy from the first):
+ *  1. candidates: the unit is cut in RANGES of 8 KiB; each range owns a hash table of 2^HASH_LOG
+ *     16-bit slots.  A slot holds the position within the range (13 bits) and a 3-bit TAG (the
+ *     hash bits below the slot index).  Position p hashes its 4 bytes and takes the slot's
+ *     previous owner in its own range if the tag agrees, else the entry of the nearest earlier
+ *     range whose slot is filled with the same tag.  A candidate is kept when its 4 bytes equal
+ *     those at p.  -> dist[p]
+ *  2. parse: the unit is cut again, in walk ranges of 1 KiB; each is walked greedily and
+ *     independently: the first LOOK candidates of a 64-position window are scored, the best one
+ *     becomes a sequence, extended forward to the range end at most.
  *  3. ranges are concatenated (a range's trailing literals go to the next range's first
  *     sequence), offsets become repcodes through the decoder's 3-entry recent-offset list
  *     (inverse of ZStdDecompress.cs:1509-1530).
@@ -49,15 +51,18 @@ typedef uint64_t U64;
 #define ERR(code) ((size_t)0 - (size_t)(code))
 
 /* ---- tunables (the HIP kernels are built with the same values) ---- */
-#define BLOCK_MAX   65536u          /* bytes per block: positions fit 16 bits */
+#define BLOCK_MAX   65536u          /* bytes per block */
+#define UNIT_MAX    131072u         /* bytes per LZ unit (match window): two blocks */
 #define RANGE_LOG   13
 #define RANGE_SIZE  (1u << RANGE_LOG)
-#define MAX_RANGES  (BLOCK_MAX / RANGE_SIZE)
-#define WALK_LOG    10              /* the walk cuts the block in ranges of 1 KiB (the hash tables keep their 8 KiB ranges) */
+#define MAX_RANGES  (UNIT_MAX / RANGE_SIZE)
+#define WALK_LOG    10              /* the walk cuts the unit in ranges of 1 KiB (the hash tables keep their 8 KiB ranges) */
 #define WALK_SIZE   (1u << WALK_LOG)
-#define WALK_RANGES (BLOCK_MAX / WALK_SIZE)
+#define WALK_RANGES (UNIT_MAX / WALK_SIZE)
 #define MINMATCH    4
 #define MAX_HASH_LOG 13
+#define TAG_BITS    3               /* RANGE_LOG + TAG_BITS = 16: one slot is a uint16 */
+#define SLOT_EMPTY  0xFFFFu
 #define HUF_MAXBITS 11
 #define MaxLL 35
 #define MaxML 52
@@ -66,7 +71,7 @@ typedef uint64_t U64;
 #define MLFSELog 9
 #define OffFSELog 8
 
-/* level <= 2 : hashLog 12, LOOK 4 ("fast") ; level >= 3 : hashLog 13, LOOK 8 */
+/* level <= 2 : LOOK 4 ("fast") ; level >= 3 : LOOK 8.  Both: 2^12 slots per 8 KiB range. */
 typedef struct { int hashLog; int look; } EParams;
 static EParams g_override = { 0, 0 };
 /* test hook: lets the ratio-tuning script try parameters without recompiling (0 = keep level default) */
@@ -76,7 +81,7 @@ void zso_encoderOverride(int hashLog, int look)
 static EParams paramsForLevel(int level)
 {
     EParams p;
-    if (level <= 2) { p.hashLog = 12; p.look = 4; } else { p.hashLog = 13; p.look = 8; }
+    p.hashLog = 12; p.look = (level <= 2) ? 4 : 8;
     if (g_override.hashLog) p.hashLog = g_override.hashLog;
     if (g_override.look) p.look = g_override.look;
     return p;
@@ -509,11 +514,9 @@ static size_t writeLiterals(BYTE *dst, size_t cap, const BYTE *lit, U32 nlit)
  * ======================================================================= */
 typedef struct { U32 litLength, matchLength, offset; } Seq;
 
-static U32 hash4(U32 v, int hashLog) { return (v * 2654435761u) >> (32 - hashLog); }
-
 typedef struct {
-    U16 dist[BLOCK_MAX];                      /* verified candidate distance per position, 0 = none */
-    U16 tables[MAX_RANGES][1 << MAX_HASH_LOG];          /* per-range hash tables (value = position + 1) */
+    U32 dist[UNIT_MAX];                       /* verified candidate distance per unit position, 0 = none */
+    U16 tables[MAX_RANGES][1 << MAX_HASH_LOG];          /* per-range hash tables (slot = tag << 13 | position in range) */
     Seq seqs[BLOCK_MAX / 3 + 8];
     BYTE lits[BLOCK_MAX + 8];
     BYTE llCode[BLOCK_MAX / 3 + 8], mlCode[BLOCK_MAX / 3 + 8], ofCode[BLOCK_MAX / 3 + 8];
@@ -521,18 +524,21 @@ typedef struct {
     BYTE tmp[BLOCK_MAX + 1024];
 } Work;
 
-/* stage 1.  Positions are taken in STEPS of 64 (one wavefront): all 64 read the table first, then all
- * 64 write it, the highest position winning a shared bucket; so a position never sees a candidate from
- * its own step.  Table values are position + 1 (16 bit), 0 = empty. */
+/* stage 1, once per unit.  Positions are taken in STEPS of 64 (one wavefront): all 64 read the tables
+ * first, then all 64 write their own range's table, the highest position winning a shared slot; so a
+ * position never sees a candidate from its own step.  A distance of exactly 65536 is not kept (the GPU
+ * keeps the low 16 bits of the distance in one array and bit 16 in another; low bits 0 = no candidate). */
 #define STEP 64u
+static U32 slotOf(U32 v, int hashLog) { return (v * 2654435761u) >> (32 - hashLog); }
+static U32 tagOf(U32 v, int hashLog) { return ((v * 2654435761u) >> (32 - hashLog - TAG_BITS)) & ((1u << TAG_BITS) - 1); }
 static void findCandidates(Work *w, const BYTE *src, U32 n, const EParams *prm)
 {
     U32 const nRanges = (n + RANGE_SIZE - 1) >> RANGE_LOG;
     U32 const last = (n >= 4) ? n - 4 : 0;          /* last position whose 4 bytes exist */
     U32 r, p, base;
-    memset(w->dist, 0, n * sizeof(U16));
+    memset(w->dist, 0, n * sizeof(U32));
     if (n < 4) return;
-    for (r = 0; r < nRanges; r++) memset(w->tables[r], 0, sizeof(U16) << prm->hashLog);
+    for (r = 0; r < nRanges; r++) memset(w->tables[r], 0xFF, sizeof(U16) << prm->hashLog);
     for (r = 0; r < nRanges; r++) {
         U32 const start = r << RANGE_LOG;
         U32 end = start + RANGE_SIZE; if (end > last + 1) end = last + 1;
@@ -540,12 +546,21 @@ static void findCandidates(Work *w, const BYTE *src, U32 n, const EParams *prm)
             U32 const stop = base + STEP < end ? base + STEP : end;
             for (p = base; p < stop; p++) {
                 U32 const v = rd32(src + p);
-                U32 const h = hash4(v, prm->hashLog);
-                U32 cand = w->tables[r][h];
-                if (!cand) { int q; for (q = (int)r - 1; q >= 0 && !cand; q--) cand = w->tables[q][h]; }
-                if (cand && rd32(src + cand - 1) == v) w->dist[p] = (U16)(p - (cand - 1));
+                U32 const h = slotOf(v, prm->hashLog), tag = tagOf(v, prm->hashLog);
+                int q;
+                for (q = (int)r; q >= 0; q--) {
+                    U32 const e = w->tables[q][h];
+                    if (e != SLOT_EMPTY && (e >> RANGE_LOG) == tag) {
+                        U32 const cand = ((U32)q << RANGE_LOG) + (e & (RANGE_SIZE - 1));
+                        if (rd32(src + cand) == v && p - cand != 65536u) w->dist[p] = p - cand;
+                        break;
+                    }
+                }
             }
-            for (p = base; p < stop; p++) w->tables[r][hash4(rd32(src + p), prm->hashLog)] = (U16)(p + 1);
+            for (p = base; p < stop; p++) {
+                U32 const v = rd32(src + p);
+                w->tables[r][slotOf(v, prm->hashLog)] = (U16)((tagOf(v, prm->hashLog) << RANGE_LOG) | (p & (RANGE_SIZE - 1)));
+            }
         }
     }
 }
@@ -601,22 +616,23 @@ static U32 walkRange(Work *w, const BYTE *src, U32 n, U32 start, U32 end, const 
  *  one block -> compressed block payload (without the 3-byte block header)
  *  returns payload size, or 0 if the block should be stored raw
  * ======================================================================= */
-static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32 n, const EParams *prm, int firstBlock)
+/* src / unitN: the LZ unit (findCandidates has run on it); the block is src[blockOff .. blockOff + n) */
+static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32 unitN, U32 blockOff, U32 n, const EParams *prm, int firstBlock)
 {
     U32 nseq = 0, nlit = 0;
     U32 const nRanges = (n + WALK_SIZE - 1) >> WALK_LOG;
+    U32 const blockEnd = blockOff + n;
     U32 r;
     if (n < 16) return 0;
-    findCandidates(w, src, n, prm);
     {
         /* stage 2 + 3a: walk ranges, concatenate */
-        U32 carry = 0, pos = 0;
-        static __thread Seq rangeSeq[RANGE_SIZE / 3 + 8];
+        U32 carry = 0, pos = blockOff;
+        static __thread Seq rangeSeq[WALK_SIZE / 3 + 8];
         for (r = 0; r < nRanges; r++) {
-            U32 const start = r << WALK_LOG;
-            U32 const end = (start + WALK_SIZE < n) ? start + WALK_SIZE : n;
+            U32 const start = blockOff + (r << WALK_LOG);
+            U32 const end = (start + WALK_SIZE < blockEnd) ? start + WALK_SIZE : blockEnd;
             U32 trailing, k;
-            U32 const ns = walkRange(w, src, n, start, end, prm, rangeSeq, &trailing);
+            U32 const ns = walkRange(w, src, unitN, start, end, prm, rangeSeq, &trailing);
             for (k = 0; k < ns; k++) {
                 Seq s = rangeSeq[k];
                 if (k == 0) s.litLength += carry;
@@ -625,7 +641,7 @@ static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32
             }
             carry = ns ? trailing : carry + trailing;
         }
-        memcpy(w->lits + nlit, src + pos, n - pos); nlit += n - pos;    /* last literals */
+        memcpy(w->lits + nlit, src + pos, blockEnd - pos); nlit += blockEnd - pos;    /* last literals */
     }
     if (nseq == 0 && nlit == n) {
         /* no match at all: only worth a compressed block if Huffman alone wins; handled below with nbSeq = 0 */
@@ -633,7 +649,7 @@ static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32
     {
         /* stage 3b: offsets -> offset field values through the 3-entry recent-offset list
          * (inverse of ZStdDecompress.cs:1509-1530).  Blocks after the first start from an unknown
-         * history: sentinels that never equal a real offset (<= 65535). */
+         * history: sentinels that never equal a real offset (< 131072). */
         U32 rep[3];
         U32 i;
         if (firstBlock) { rep[0] = 1; rep[1] = 4; rep[2] = 8; } else { rep[0] = 0xFFFFFFF1u; rep[1] = 0xFFFFFFF2u; rep[2] = 0xFFFFFFF3u; }
@@ -776,6 +792,9 @@ size_t zso_compress(void *dstv, size_t dstCapacity, const void *srcv, size_t src
     do {
         U32 const n = (U32)((srcSize - pos < BLOCK_MAX) ? srcSize - pos : BLOCK_MAX);
         int const last = (pos + n == srcSize);
+        size_t const unitPos = pos & ~(size_t)(UNIT_MAX - 1);             /* units are cut every 128 KiB of the chunk */
+        U32 const unitN = (U32)((srcSize - unitPos < UNIT_MAX) ? srcSize - unitPos : UNIT_MAX);
+        if (pos == unitPos && n) findCandidates(w, src + unitPos, unitN, &prm);
         size_t csize = 0;
         U32 i, same = n > 0;
         if ((size_t)(oend - op) < 3 + 1) return ERR(ZSO_dstSize_tooSmall);
@@ -785,7 +804,7 @@ size_t zso_compress(void *dstv, size_t dstCapacity, const void *srcv, size_t src
         } else {
             /* the payload is built in scratch of n + 512 bytes; it is used iff it is smaller than n
              * (anything that would not fit the scratch is larger than n anyway) */
-            if (n) csize = compressBlock(w, w->tmp, n + 512, src + pos, n, &prm, pos == 0);
+            if (n) csize = compressBlock(w, w->tmp, n + 512, src + unitPos, unitN, (U32)(pos - unitPos), n, &prm, pos == 0);
             if (csize && csize < n && (size_t)(oend - op) >= 3 + csize) { wr24(op, (U32)last + (2u << 1) + ((U32)csize << 3)); memcpy(op + 3, w->tmp, csize); op += 3 + csize; }
             else {                                                   /* raw block (ZStdDecompress.cs:662-667) */
                 if ((size_t)(oend - op) < 3 + (size_t)n) return ERR(ZSO_dstSize_tooSmall);
@@ -797,15 +816,15 @@ size_t zso_compress(void *dstv, size_t dstCapacity, const void *srcv, size_t src
     return (size_t)(op - dst);
 }
 
-/* ---- test hooks: intermediate results of stages 1 and 2 for one block (n <= 65536), so the HIP
+/* ---- test hooks: intermediate results of stages 1 and 2 for one LZ unit (n <= 131072), so the HIP
  *      kernels can be checked stage by stage ---- */
-int zso_debugCandidates(uint16_t *distOut, const void *src, uint32_t n, int level)
+int zso_debugCandidates(uint32_t *distOut, const void *src, uint32_t n, int level)
 {
     EParams const prm = paramsForLevel(level);
     Work *w = (Work *)malloc(sizeof(Work));
-    if (!w || n > BLOCK_MAX) { free(w); return -1; }
+    if (!w || n > UNIT_MAX) { free(w); return -1; }
     findCandidates(w, (const BYTE *)src, n, &prm);
-    memcpy(distOut, w->dist, n * sizeof(U16));
+    memcpy(distOut, w->dist, n * sizeof(U32));
     free(w);
     return 0;
 }
@@ -815,9 +834,9 @@ int zso_debugWalk(uint32_t *seqOut, uint32_t *hdrOut, const void *src, uint32_t 
 {
     EParams const prm = paramsForLevel(level);
     Work *w = (Work *)malloc(sizeof(Work));
-    Seq *tmp = (Seq *)malloc(sizeof(Seq) * (RANGE_SIZE / 3 + 8));
+    Seq *tmp = (Seq *)malloc(sizeof(Seq) * (WALK_SIZE / 3 + 8));
     U32 r, nRanges = (n + WALK_SIZE - 1) >> WALK_LOG;
-    if (!w || !tmp || n > BLOCK_MAX) { free(w); free(tmp); return -1; }
+    if (!w || !tmp || n > UNIT_MAX) { free(w); free(tmp); return -1; }
     findCandidates(w, (const BYTE *)src, n, &prm);
     for (r = 0; r < nRanges; r++) {
         U32 const start = r << WALK_LOG;

@@ -57,6 +57,10 @@ def mixed_inputs(seed=7):
         "highbytes": (rng.integers(0, 40, 40000, dtype=np.uint8) + 200).astype(np.uint8).tobytes(),
         "run_mix": b"".join(bytes([int(rng.integers(0, 256))]) * int(rng.integers(1, 400)) for _ in range(600)),
         "longmatch": (lambda b: b + b + b)(rng.integers(0, 256, 20000, dtype=np.uint8).tobytes()),
+        # matches farther back than 64 KiB (second block of an LZ unit copying from the first), incl. distance exactly 65536
+        "far_70000x2": (lambda b: b + b)(rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()),
+        "far_65536x2": (lambda b: b + b)(rng.integers(0, 256, 65536, dtype=np.uint8).tobytes()),
+        "far_text": z[:60000] + rng.integers(0, 256, 30000, dtype=np.uint8).tobytes() + z[:41000],
     }
     rec = bytearray()
     for i in range(3000):

@@ -163,6 +163,35 @@ def test_encode_batch_64k_chunks_log(codec):
         assert e <= z * 1.01, (e, z)
 
 
+@pytest.mark.parametrize("level", [1, 3])
+def test_encode_batch_128k_chunks_log(codec, level):
+    """BASELINE configs 3 and 5 shape: 128 KiB chunks (one LZ unit of two blocks, the second copying from the first);
+    bit-exact vs oracle E; ratio within 1 % of libzstd at the same level and chunk size"""
+    data = D.zipf_log(8 << 20, seed_lo=21)
+    cs = 131072
+    n = len(data) // cs
+    offs = np.arange(n, dtype=np.uint64) * cs
+    sizes = np.full(n, cs, dtype=np.uint32)
+    arena, do, dsz = codec.compress_host(data, offs, sizes, level)
+    assert (dsz < ERR).all()
+    ea, eo, es = O.compress_batch(data, offs, sizes, level, 8)
+    assert (dsz == es).all()
+    for i in range(n):
+        assert (arena[int(do[i]):int(do[i]) + int(dsz[i])] == ea[int(eo[i]):int(eo[i]) + int(es[i])]).all(), i
+    for i in range(0, n, 8):
+        f = arena[int(do[i]):int(do[i]) + int(dsz[i])].tobytes()
+        out, st = O.decode_stats(f, cs)
+        assert out == data[i * cs:(i + 1) * cs].tobytes()
+    frames = np.concatenate([arena[int(do[i]):int(do[i]) + int(dsz[i])] for i in range(n)])
+    fo = np.zeros(n, dtype=np.uint64); fo[1:] = np.cumsum(dsz.astype(np.uint64))[:-1]
+    out, oo, osz = codec.decompress_host(frames, fo, dsz, sizes)
+    assert (osz == cs).all() and (out[:n * cs] == data[:n * cs]).all()
+    if O.libzstd():
+        z = sum(len(O.zstd_compress(data[i * cs:(i + 1) * cs].tobytes(), level)) for i in range(0, n, 4))
+        e = int(dsz[::4].sum())
+        assert e <= z * 1.01, (e, z)
+
+
 def test_encode_128k_chunks_and_ragged(codec):
     data = D.zipf_log(3 << 20, seed_lo=77)
     rng = np.random.default_rng(5)

@@ -42,16 +42,29 @@ def test_constructs_emitted():
 
 
 @pytest.mark.skipif(not O.libzstd(), reason="libzstd not present")
-def test_ratio_vs_libzstd_level3():
-    """north_star tolerance: within 1 % of libzstd level 3 on 64 KiB chunks of the Zipf log stream"""
+@pytest.mark.parametrize("cs,level", [(65536, 3), (131072, 3), (131072, 1), (65536, 1)])
+def test_ratio_vs_libzstd(cs, level):
+    """north_star tolerance: within 1 % of libzstd at the same level and chunk size on the Zipf log stream
+    (BASELINE configs: 64 KiB level 3 is the headline; 128 KiB level 1 and level 3 are configs 3 and 5)"""
     data = D.zipf_log(2 << 20)
-    cs = 65536
     e = z = 0
     for i in range(0, len(data), cs):
         c = data[i:i + cs].tobytes()
-        e += len(O.compress(c, 3))
-        z += len(O.zstd_compress(c, 3))
+        e += len(O.compress(c, level))
+        z += len(O.zstd_compress(c, level))
     assert e <= z * 1.01, (e, z)
+
+
+def test_far_offsets_reach_the_first_block():
+    """second block of an LZ unit copies from the first: offsets beyond 65535 appear, except the unsupported distance 65536"""
+    rng = np.random.default_rng(3)
+    b = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    f = O.compress(b + b, 3)
+    # raw first block (65536) + 4464 new literals + matches into the first block + 8928 bytes of a second unit without history
+    assert len(f) < 80000 and O.decompress(f, 140000) == b + b
+    b = rng.integers(0, 256, 65536, dtype=np.uint8).tobytes()
+    f = O.compress(b + b, 3)                     # distance exactly 65536 is dropped by design: both blocks stay raw
+    assert len(f) > 131072 and O.decompress(f, 131072) == b + b
 
 
 def test_batch_threads_agree():

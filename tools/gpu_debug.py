@@ -8,7 +8,7 @@ import _oracle as O, _data as D
 from zstandard_amd import BatchCodec, _lib
 
 def main():
-    names = sys.argv[1:] or ["log_65536", "log_1000", "zeros_65536", "rand_70000", "alphabet", "log_200001", "records", "sixbit_2000", "empty", "one", "skewed"]
+    names = sys.argv[1:] or ["log_131072", "log_65536", "log_1000", "zeros_65536", "rand_70000", "alphabet", "log_200001", "records", "sixbit_2000", "empty", "one", "skewed"]
     inputs = D.mixed_inputs()
     bc = BatchCodec()
     L = O.lib(); Z = _lib.lib()
@@ -28,21 +28,27 @@ def main():
                 ok_rt = f"oracle error {e.code}"
         print(f"{name:14s} n={len(data):7d} gpu={dsz[0]:10d} E={len(ref):7d} same={frame == ref} roundtrip={ok_rt}")
         if frame != ref and len(data) >= 16:
-            n0 = min(len(data), 65536)
+            n0 = min(len(data), 131072)          # first LZ unit
             blk = data[:n0]
-            dist_e = np.zeros(n0, dtype=np.uint16); L.zso_debugCandidates(dist_e.ctypes.data_as(ctypes.c_void_p), blk, n0, 3)
-            dist_g = np.zeros(65536, dtype=np.uint16); Z.zsmi_dbg_copyScratch(bc.ctx, 0, dist_g.ctypes.data_as(ctypes.c_void_p), 65536 * 2)
-            bad = np.nonzero(dist_e != dist_g[:n0])[0]
-            print(f"   dist mismatches (block 0): {len(bad)}", bad[:8], dist_e[bad[:8]], dist_g[bad[:8]])
-            seq_e = np.zeros(64 * 256 * 3, dtype=np.uint32); hdr_e = np.zeros(128, dtype=np.uint32)
+            nr = (n0 + 1023) // 1024               # walk ranges
+            dist_e = np.zeros(n0, dtype=np.uint32); L.zso_debugCandidates(dist_e.ctypes.data_as(ctypes.c_void_p), blk, n0, 3)
+            dist_lo = np.zeros(131072, dtype=np.uint16); Z.zsmi_dbg_copyScratch(bc.ctx, 0, dist_lo.ctypes.data_as(ctypes.c_void_p), 131072 * 2)
+            dist_g = dist_lo[:n0].astype(np.uint32)
+            if n0 > 65536:
+                hi = np.zeros(16384, dtype=np.uint8); Z.zsmi_dbg_copyScratch(bc.ctx, 4, hi.ctypes.data_as(ctypes.c_void_p), 16384)
+                dist_g |= np.unpackbits(hi, bitorder="little")[:n0].astype(np.uint32) << 16
+                dist_g[dist_lo[:n0] == 0] = 0
+            bad = np.nonzero(dist_e != dist_g)[0]
+            print(f"   dist mismatches (unit 0): {len(bad)}", bad[:8], dist_e[bad[:8]], dist_g[bad[:8]])
+            seq_e = np.zeros(128 * 256 * 3, dtype=np.uint32); hdr_e = np.zeros(256, dtype=np.uint32)
             L.zso_debugWalk(seq_e.ctypes.data_as(ctypes.c_void_p), hdr_e.ctypes.data_as(ctypes.c_void_p), blk, n0, 3)
-            hdr_g4 = np.zeros(256, dtype=np.uint32); Z.zsmi_dbg_copyScratch(bc.ctx, 2, hdr_g4.ctypes.data_as(ctypes.c_void_p), 1024); hdr_g = hdr_g4.reshape(64, 4)[:, :2].reshape(-1).copy()
-            seq_g = np.zeros(64 * 256 * 4, dtype=np.uint16); Z.zsmi_dbg_copyScratch(bc.ctx, 1, seq_g.ctypes.data_as(ctypes.c_void_p), 64 * 256 * 8)
-            print("   hdr E", hdr_e.tolist()); print("   hdr G", hdr_g.tolist())
-            se = seq_e.reshape(64, 256, 3); sg = seq_g.reshape(64, 256, 4)
-            for r in range(64):
+            hdr_g4 = np.zeros(512, dtype=np.uint32); Z.zsmi_dbg_copyScratch(bc.ctx, 2, hdr_g4.ctypes.data_as(ctypes.c_void_p), 2048); hdr_g = hdr_g4.reshape(128, 4)[:, :2].reshape(-1).copy()
+            seq_g = np.zeros(128 * 256 * 4, dtype=np.uint16); Z.zsmi_dbg_copyScratch(bc.ctx, 1, seq_g.ctypes.data_as(ctypes.c_void_p), 128 * 256 * 8)
+            print("   hdr E", hdr_e[:2 * nr].tolist()); print("   hdr G", hdr_g[:2 * nr].tolist())
+            se = seq_e.reshape(128, 256, 3); sg = seq_g.reshape(128, 256, 4)
+            for r in range(nr):
                 ns = min(hdr_e[2 * r], hdr_g[2 * r])
-                g3 = np.stack([sg[r, :ns, 0], sg[r, :ns, 1] & 0x3FFF, sg[r, :ns, 2]], axis=1).astype(np.uint32)
+                g3 = np.stack([sg[r, :ns, 0], sg[r, :ns, 1] & 0x1FFF, sg[r, :ns, 2].astype(np.uint32) | ((sg[r, :ns, 1].astype(np.uint32) >> 13) & 1) << 16], axis=1).astype(np.uint32)
                 d = np.nonzero((se[r, :ns] != g3).any(axis=1))[0]
                 if len(d):
                     k = d[0]; print(f"   range {r}: first seq mismatch at {k}: E={se[r, k].tolist()} G={sg[r, k].tolist()}"); break

@@ -14,6 +14,7 @@ def build(force=False):
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH, os.path.join(CSRC, "zsmi_api.hip")]
+    cmd += os.environ.get("ZSMI_HIPCC_FLAGS", "").split()          # kernel-shape experiments (-DZS_CAND_WPR=2 ...)
     subprocess.check_call(cmd)
     return LIB_PATH
 

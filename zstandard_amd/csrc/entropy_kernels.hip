@@ -797,7 +797,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
                 for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
                 const uint32_t k = g - L.rngStart[rr];
                 rp = seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + k;
-                const ZsSeqRec rec = *rp; off = rec.off; ll = rec.ll; ml = rec.ml & 0x3FFFu; if (k == 0) ll += rngCarry[rr];
+                const ZsSeqRec rec = *rp; off = (uint32_t)rec.off | (((uint32_t)rec.ml >> 13) & 1u) << 16; ll = rec.ll; ml = rec.ml & 0x1FFFu; if (k == 0) ll += rngCarry[rr];
             }
             uint32_t prev = (uint32_t)__shfl_up((int)off, 1); if (lane == 0) prev = cPrev;        // rep0 before me
             const bool change = in && !(ll > 0 && off == prev);
@@ -812,7 +812,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
                 uint32_t val;
                 if (ll) { val = (off == prev) ? 1u : (off == a) ? 2u : (off == b) ? 3u : 0u; }
                 else    { val = (off == a) ? 1u : (off == b) ? 2u : 0u; }
-                rp->ml = (uint16_t)(ml | (val << 14));
+                rp->ml = (uint16_t)(ml | ((off >> 16) << 13) | (val << 14));
                 const uint32_t v = val ? val : off + 3;
                 atomicAdd(&L.count[llCodeOf(ll)], 1u);
                 atomicAdd(&L.count[64 + zs_highbit(v)], 1u);
@@ -918,8 +918,8 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
             uint2 o0 = make_uint2(0, 0), o1 = o0, o2 = o0;
             if (valid) {
                 ll = (uint32_t)rec.ll + carry;
-                ml = rec.ml & 0x3FFFu; const uint32_t rep = rec.ml >> 14;
-                val = rep ? rep : (uint32_t)rec.off + 3;
+                ml = rec.ml & 0x1FFFu; const uint32_t rep = rec.ml >> 14;
+                val = rep ? rep : ((uint32_t)rec.off | (((uint32_t)rec.ml >> 13) & 1u) << 16) + 3;
                 llc = llCodeOf(ll); mlc = mlCodeOf(ml - 3); ofc = zs_highbit(val);
                 o0 = make_uint2(L.ct[0].deltaNbBits[llc], (uint32_t)L.ct[0].deltaFindState[llc]);
                 o1 = make_uint2(L.ct[1].deltaNbBits[ofc], (uint32_t)L.ct[1].deltaFindState[ofc]);

@@ -116,15 +116,17 @@ struct zsmi_ctx {
     bool ownStream = false;
     uint32_t maxBlocksInFlight = 8192;
     // compress workspace: plan (shared) + one scratch set per internal stream ("lane")
-    DevBuf dBlocks, dChunks;
-    struct Scratch { DevBuf dDist, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr, aux = nullptr; hipEvent_t done = nullptr, evWalk = nullptr, evSeq = nullptr; };
+    DevBuf dBlocks, dChunks, dUnits;     // dUnits: small units (<= 64 KiB) first, then big ones, each in chunk order
+    struct Scratch { DevBuf dDist, dDistHi, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr, aux = nullptr; hipEvent_t done = nullptr, evWalk = nullptr, evSeq = nullptr; };
     static const int kMaxLanes = 8;
     Scratch lanes[kMaxLanes];
     int nLanes = 1;
     bool overlapEntropy = true;
     int stopLit = 0, stopSeq = 0;          // timing aids (ZSMI_STOP_LIT / ZSMI_STOP_SEQ): end a kernel after a stage; output is then invalid
     hipEvent_t evStart = nullptr;
-    PinBuf hBlocks, hChunks;
+    PinBuf hBlocks, hChunks, hUnits;
+    std::vector<uint32_t> smallBefore, bigBefore;   // per chunk (n + 1 entries): small / big units in front of it
+    uint32_t planSmall = 0, planBig = 0;
     std::vector<uint64_t> planKey;       // copy of (srcOffsets, srcSizes, dstOffsets) the device-side plan was built from
     uint64_t planBlocks = 0; uint32_t planMaxChunkBlocks = 1;
     // decompress workspace
@@ -160,9 +162,11 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     else { c->device = device; if (hipSetDevice(device) != hipSuccess) { delete c; return nullptr; } }
     if (hipStream) { c->stream = (hipStream_t)hipStream; c->ownStream = false; }
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; } c->ownStream = true; }
-    // the candidate kernel uses up to 128 KiB of dynamic LDS
-    (void)hipFuncSetAttribute((const void *)k_lz_candidates, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
-    (void)hipFuncSetAttribute((const void *)k_lz_walk, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS);
+    // dynamic LDS beyond the 64 KiB default
+    (void)hipFuncSetAttribute((const void *)k_lz_candidates<8, ZS_CAND_WPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (8 << ZS_HASH_LOG) * 2);
+    (void)hipFuncSetAttribute((const void *)k_lz_candidates<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (16 << ZS_HASH_LOG) * 2);
+    (void)hipFuncSetAttribute((const void *)k_lz_walk<64>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(64));
+    (void)hipFuncSetAttribute((const void *)k_lz_walk<128>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(128));
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_OVERLAP")) c->overlapEntropy = atoi(e) != 0;
     if (const char *e = getenv("ZSMI_STOP_LIT")) c->stopLit = atoi(e);
@@ -181,11 +185,11 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
 {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dItems, &c->dLitScratch, &c->sSrc, &c->sDst, &c->sSizes }) b->release();
+    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dUnits, &c->dItems, &c->dLitScratch, &c->sSrc, &c->sDst, &c->sSizes }) b->release();
     for (int i = 0; i < zsmi_ctx::kMaxLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
         if (L.stream) (void)hipStreamSynchronize(L.stream);
-        for (DevBuf *b : { &L.dDist, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dLitSec, &L.dSeqSec, &L.dMetas }) b->release();
+        for (DevBuf *b : { &L.dDist, &L.dDistHi, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dLitSec, &L.dSeqSec, &L.dMetas }) b->release();
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.evWalk) (void)hipEventDestroy(L.evWalk);
         if (L.evSeq) (void)hipEventDestroy(L.evSeq);
@@ -193,7 +197,7 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     if (c->evStart) (void)hipEventDestroy(c->evStart);
-    for (PinBuf *b : { &c->hBlocks, &c->hChunks, &c->hItems }) b->release();
+    for (PinBuf *b : { &c->hBlocks, &c->hChunks, &c->hUnits, &c->hItems }) b->release();
     for (auto &tl : c->launches) { (void)hipEventDestroy(tl.a); (void)hipEventDestroy(tl.b); }
     for (auto e : c->eventPool) (void)hipEventDestroy(e);
     if (c->ownStream) (void)hipStreamDestroy(c->stream);
@@ -239,7 +243,7 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
     if (!c) return ZSMI_error_init_missing;
     if (n == 0) return 0;
     if (hipSetDevice(c->device) != hipSuccess) return ZSMI_error_GENERIC;
-    const int hashLog = level <= 2 ? 12 : 13, look = level <= 2 ? 4 : 8;
+    const int hashLog = ZS_HASH_LOG, look = level <= 2 ? 4 : 8;
     // plan: chunks -> blocks.  The device-side plan is reused when the chunk layout repeats (steady-state batches).
     std::vector<uint64_t> key((size_t)n * 3 + 1);
     key[0] = n;
@@ -252,6 +256,7 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         if (nBlocks > 0x7FFFFFFFull) return ZSMI_error_srcSize_wrong;
         if (!c->hChunks.reserve(sizeof(ZsChunkDesc) * n) || !c->hBlocks.reserve(sizeof(ZsBlockDesc) * nBlocks)) return ZSMI_error_memory_allocation;
         if (!c->dChunks.reserve(sizeof(ZsChunkDesc) * n) || !c->dBlocks.reserve(sizeof(ZsBlockDesc) * nBlocks)) return ZSMI_error_memory_allocation;
+        if (!c->hUnits.reserve(sizeof(ZsUnitDesc) * nBlocks) || !c->dUnits.reserve(sizeof(ZsUnitDesc) * nBlocks)) return ZSMI_error_memory_allocation;
         // the pinned plan buffers may still feed a previous asynchronous copy
         if (hipStreamSynchronize(c->stream) != hipSuccess) return ZSMI_error_GENERIC;
         ZsChunkDesc *hc0 = (ZsChunkDesc *)c->hChunks.p; ZsBlockDesc *hb = (ZsBlockDesc *)c->hBlocks.p;
@@ -267,6 +272,26 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
             }
             if (nb > maxChunkBlocks) maxChunkBlocks = nb;
         }
+        // LZ units: every 128 KiB of a chunk (two blocks); a unit of <= 64 KiB goes to the small-unit kernels
+        c->smallBefore.assign((size_t)n + 1, 0); c->bigBefore.assign((size_t)n + 1, 0);
+        uint32_t nSmall = 0, nBig = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            c->smallBefore[i] = nSmall; c->bigBefore[i] = nBig;
+            for (uint64_t o = 0; o < srcSizes[i]; o += ZS_UNIT_MAX) { if ((uint64_t)srcSizes[i] - o > ZS_BLOCK_MAX) nBig++; else nSmall++; }
+        }
+        c->smallBefore[n] = nSmall; c->bigBefore[n] = nBig;
+        {
+            ZsUnitDesc *hu = (ZsUnitDesc *)c->hUnits.p;
+            uint32_t is = 0, ib = nSmall;
+            for (uint32_t i = 0; i < n; i++)
+                for (uint64_t o = 0; o < srcSizes[i]; o += ZS_UNIT_MAX) {
+                    const uint64_t left = (uint64_t)srcSizes[i] - o;
+                    ZsUnitDesc &u = hu[left > ZS_BLOCK_MAX ? ib++ : is++];
+                    u.srcOff = srcOffsets[i] + o; u.size = (uint32_t)(left < ZS_UNIT_MAX ? left : ZS_UNIT_MAX); u.firstBlock = hc0[i].firstBlock + (uint32_t)(o / ZS_BLOCK_MAX);
+                }
+            if (nSmall + nBig && hipMemcpyAsync(c->dUnits.p, hu, sizeof(ZsUnitDesc) * (nSmall + nBig), hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+        }
+        c->planSmall = nSmall; c->planBig = nBig;
         if (hipMemcpyAsync(c->dChunks.p, hc0, sizeof(ZsChunkDesc) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
         if (hipMemcpyAsync(c->dBlocks.p, hb, sizeof(ZsBlockDesc) * nBlocks, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
         c->planKey.swap(key); c->planBlocks = nBlocks; c->planMaxChunkBlocks = maxChunkBlocks;
@@ -278,14 +303,13 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
     if (cap < maxChunkBlocks) cap = maxChunkBlocks;
     for (int i = 0; i < nLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
-        if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2 + 256) || !L.dSeqs.reserve((size_t)cap * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
+        if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2 + 256) || !L.dDistHi.reserve((size_t)cap * (ZS_BLOCK_MAX / 8) + 256) || !L.dSeqs.reserve((size_t)cap * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
             !L.dHdrs.reserve((size_t)cap * ZS_WALK_RANGES * sizeof(ZsRangeHdr)) || !L.dLits.reserve((size_t)cap * (ZS_BLOCK_MAX + 64)) ||
             !L.dStreams.reserve((size_t)cap * 4 * ZS_STREAM_STRIDE) || !L.dLitSec.reserve((size_t)cap * ZS_LITSEC_STRIDE) ||
             !L.dSeqSec.reserve((size_t)cap * ZS_SEQSEC_STRIDE) || !L.dMetas.reserve((size_t)cap * sizeof(ZsBlockMeta))) return ZSMI_error_memory_allocation;
     }
     if (hipEventRecord(c->evStart, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
     for (int i = 0; i < nLanes; i++) if (hipStreamWaitEvent(c->lanes[i].stream, c->evStart, 0) != hipSuccess) return ZSMI_error_GENERIC;
-    const size_t lds = (size_t)(ZS_MAX_RANGES << hashLog) * sizeof(uint16_t);
     uint32_t chunk0 = 0; int turn = 0;
     while (chunk0 < n) {
         uint32_t chunk1 = chunk0, nb = 0;
@@ -294,9 +318,17 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         const ZsBlockDesc *dB = (const ZsBlockDesc *)c->dBlocks.p + block0;
         zsmi_ctx::Scratch &L = c->lanes[turn % nLanes]; turn++;
         hipStream_t st = L.stream;
-        LAUNCH_ON(c, st, "k_lz_candidates", k_lz_candidates, dim3(nb), dim3(1024), lds, (const uint8_t *)dSrc, dB, (uint16_t *)L.dDist.p, hashLog);
-        LAUNCH_ON(c, st, "k_lz_walk", k_lz_walk, dim3(nb), dim3(512), ZS_WALK_LDS, (const uint8_t *)dSrc, dB, (const uint16_t *)L.dDist.p,
-                  (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
+        // match search per LZ unit: small units (one block) and big units (two blocks) have their own kernel shapes
+        const uint32_t s0 = c->smallBefore[chunk0], ns = c->smallBefore[chunk1] - s0, b0 = c->bigBefore[chunk0], nbig = c->bigBefore[chunk1] - b0;
+        const ZsUnitDesc *dUS = (const ZsUnitDesc *)c->dUnits.p + s0, *dUB = (const ZsUnitDesc *)c->dUnits.p + c->planSmall + b0;
+        if (ns) LAUNCH_ON(c, st, "k_lz_candidates", (k_lz_candidates<8, ZS_CAND_WPR>), dim3(ns), dim3(8 * ZS_CAND_WPR * 64), (size_t)(8 << hashLog) * 2, (const uint8_t *)dSrc, dUS, block0,
+                          (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, hashLog);
+        if (nbig) LAUNCH_ON(c, st, "k_lz_candidates_big", (k_lz_candidates<16, 1>), dim3(nbig), dim3(1024), (size_t)(16 << hashLog) * 2, (const uint8_t *)dSrc, dUB, block0,
+                            (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, hashLog);
+        if (ns) LAUNCH_ON(c, st, "k_lz_walk", (k_lz_walk<64>), dim3(ns), dim3(512), ZS_WALK_LDS(64), (const uint8_t *)dSrc, dUS, block0, (const uint16_t *)L.dDist.p,
+                          (const uint8_t *)L.dDistHi.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
+        if (nbig) LAUNCH_ON(c, st, "k_lz_walk_big", (k_lz_walk<128>), dim3(nbig), dim3(1024), ZS_WALK_LDS(128), (const uint8_t *)dSrc, dUB, block0, (const uint16_t *)L.dDist.p,
+                            (const uint8_t *)L.dDistHi.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
         // the two entropy kernels are independent of each other: the sequences kernel runs on a side stream beside the literals kernel
         const bool overlap = c->overlapEntropy;
         hipStream_t st2 = overlap ? L.aux : st;
@@ -486,7 +518,7 @@ extern "C" int zsmi_dbg_copyScratch(zsmi_ctx *c, int which, void *hostDst, size_
     if (!c) return -1;
     (void)hipStreamSynchronize(c->stream);
     zsmi_ctx::Scratch &L0 = c->lanes[0];
-    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : &L0.dMetas;
+    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : which == 4 ? &L0.dDistHi : &L0.dMetas;
     if (bytes > b->cap) return -2;
     return hipMemcpy(hostDst, b->p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }

@@ -5,12 +5,13 @@
 #include <stdint.h>
 
 #define ZS_BLOCK_MAX   65536u     // bytes per block; block positions fit 16 bits
+#define ZS_UNIT_MAX    131072u    // bytes per LZ unit (match window): two consecutive blocks of a chunk
 #define ZS_RANGE_LOG   13
-#define ZS_RANGE_SIZE  (1u << ZS_RANGE_LOG)
-#define ZS_MAX_RANGES  8u         // hash-table ranges (8 KiB)
+#define ZS_RANGE_SIZE  (1u << ZS_RANGE_LOG)   // hash-table ranges (8 KiB): 8 per block, 16 per full unit
+#define ZS_HASH_LOG    12         // slots per range table
 #define ZS_WALK_LOG    10
 #define ZS_WALK_SIZE   (1u << ZS_WALK_LOG)   // the walk cuts the block in ranges of 1 KiB
-#define ZS_WALK_RANGES 64u
+#define ZS_WALK_RANGES 64u        // per block
 #define ZS_MINMATCH    4u
 #define ZS_WINDOW      64u        // positions looked at per walk step (one wavefront)
 #define ZS_FCAP        8u         // forward bytes compared when scoring a candidate
@@ -28,8 +29,15 @@ struct ZsBlockDesc {
     uint32_t lastInChunk;
 };
 
+// one LZ unit: blocks firstBlock, firstBlock + 1 (if size > 64 KiB) of one chunk
+struct ZsUnitDesc {
+    uint64_t srcOff;      // byte offset of the unit in the source arena
+    uint32_t size;        // 1..131072
+    uint32_t firstBlock;  // index of its first block in the call's block list
+};
+
 // one sequence as the walk kernel leaves it (per range) / as the encode kernel consumes it
-struct ZsSeqRec { uint16_t ll, ml, off, flags; };   // flags: block position of the match start; ml bits 14-15: repcode (encode kernel)
+struct ZsSeqRec { uint16_t ll, ml, off, flags; };   // off: low 16 bits of the offset, ml bit 13: its bit 16; flags: block position of the match start; ml bits 14-15: repcode (encode kernel)
 
 struct ZsRangeHdr { uint32_t nseq, trailing, litSum, pad; };   // litSum: literal bytes in front of the range's matches
 
