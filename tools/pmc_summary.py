@@ -1,4 +1,4 @@
-import csv, glob, collections, sys, os
+import re, csv, glob, collections, sys, os
 tag = sys.argv[1]
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 res = collections.defaultdict(dict)
@@ -8,8 +8,9 @@ for d in "abcd":
     rows = list(csv.DictReader(open(fs[0])))
     agg = collections.defaultdict(float); disp = collections.Counter()
     for r in rows:
-        k = r["Kernel_Name"]
-        if not k.startswith("k_"): continue
+        m = re.search(r"k_[a-z_]+(<[^>]*>)?", r["Kernel_Name"])
+        if not m: continue
+        k = m.group(0).replace(", ", "_").replace("<", "_").replace(">", "")
         agg[(k, r["Counter_Name"])] += float(r["Counter_Value"]); disp[(k, r["Counter_Name"])] += 1
     for (k, c), v in agg.items():
         res[k][c] = v / disp[(k, c)]

@@ -39,7 +39,7 @@ __device__ __forceinline__ uint32_t zs_slot_entry(uint32_t hh, int hashLog, uint
 template <int NR, int WPR>
 __global__ void __launch_bounds__(NR * WPR * 64, (NR == 8 ? ZS_CAND_MINWG : 1))
 k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units, uint32_t block0,
-                uint16_t *__restrict__ distAll, uint8_t *__restrict__ distHiAll, int hashLog)
+                uint16_t *__restrict__ distAll, uint8_t *__restrict__ distHiAll, uint8_t *__restrict__ distMaskAll, int hashLog)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t tables[];
     const ZsUnitDesc ud = units[blockIdx.x];
@@ -47,6 +47,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     const uint32_t n = ud.size;
     uint16_t *dist = distAll + (size_t)(ud.firstBlock - block0) * ZS_BLOCK_MAX;
     uint8_t *distHi = distHiAll + (size_t)(ud.firstBlock - block0) * (ZS_BLOCK_MAX / 8);
+    uint8_t *distMask = distMaskAll + (size_t)(ud.firstBlock - block0) * (ZS_BLOCK_MAX / 8);     // bit p: position p has a candidate
 
     {   // clear the tables
         const uint32_t words = ((uint32_t)NR << hashLog) >> 1;      // 32-bit words
@@ -99,6 +100,9 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
         uint32_t pbase = 0; bool havePrev = false;
         const uint32_t first = start + half * 64 * U;
         auto finish = [&](uint32_t fbase) {
+            // candidate bits (and bit 16 of the distances) of the trip's U groups of 64 positions: lane u keeps group u's word,
+            // so each plane takes one store of U * 8 contiguous bytes
+            uint64_t pmMine = 0, hiMine = 0;
             #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
                 const uint32_t p = fbase + u * 64 + lane;
@@ -106,9 +110,15 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
                 if (NR > 8) {
                     if (d == 65536u) d = 0;
                     const uint64_t hi = __ballot((d >> 16) != 0);
-                    if (lane == 0 && fbase + u * 64 < end) *reinterpret_cast<uint64_t *>(distHi + ((fbase + u * 64) >> 3)) = hi;
+                    if (lane == u) hiMine = hi;
                 }
+                const uint64_t pm = __ballot(d != 0);
+                if (lane == u) pmMine = pm;
                 if (p < end) dist[p] = (uint16_t)d;
+            }
+            if (lane < U && fbase + lane * 64 < end) {
+                *reinterpret_cast<uint64_t *>(distMask + ((fbase + lane * 64) >> 3)) = pmMine;
+                if (NR > 8) *reinterpret_cast<uint64_t *>(distHi + ((fbase + lane * 64) >> 3)) = hiMine;
             }
         };
         #pragma unroll
@@ -168,21 +178,34 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
 // ---------------------------------------------------------------------------------------------
 #define ZS_WALK_FRONT 16u          // LDS bytes in front of the unit (backward reads near position 0)
 #define ZS_WALK_TAIL  144u         // zero bytes behind the unit (forward reads near the end)
-#define ZS_WALK_LDS(NW) (ZS_WALK_FRONT + (NW) * ZS_WALK_SIZE + ZS_WALK_TAIL + (NW) * 64u * 2u)
+#define ZS_WALK_LDS(CAPB) (ZS_WALK_FRONT + (CAPB) + ZS_WALK_TAIL + (CAPB) / 8 + 16)   // source + candidate bit plane
 
-__device__ __forceinline__ uint64_t lds64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+// K dwords of the LDS copy starting at any byte offset, fetched as K + 1 aligned dwords and shifted into place
+// (an unaligned ds_read_b64 / b128 costs the LDS several passes: SQ_LDS_UNALIGNED_STALL was 80 % of its busy time)
+template <int K>
+__device__ __forceinline__ void lds_span(const uint8_t *ldsBase, uint32_t byteOff, uint32_t (&out)[K])
+{
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(ldsBase + (byteOff & ~3u));
+    uint32_t w[K + 1];
+    #pragma unroll
+    for (int k = 0; k <= K; k++) w[k] = d[k];
+    const uint32_t sh = byteOff & 3u;
+    #pragma unroll
+    for (int k = 0; k < K; k++) out[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
+}
+__device__ __forceinline__ uint64_t zs_u64(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
 
-template <int NW>
+template <int NW, int WLOG>
 __global__ void __launch_bounds__(NW * 8)
 k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units, uint32_t block0,
-          const uint16_t *__restrict__ distAll, const uint8_t *__restrict__ distHiAll,
+          const uint16_t *__restrict__ distAll, const uint8_t *__restrict__ distHiAll, const uint8_t *__restrict__ distMaskAll,
           ZsSeqRec *__restrict__ seqAll, ZsRangeHdr *__restrict__ hdrAll, int look)
 {
-    constexpr uint32_t CAP = NW * ZS_WALK_SIZE;                                   // unit capacity in bytes
-    constexpr bool BIG = NW > 64;
+    constexpr uint32_t WSIZE = 1u << WLOG;                                        // bytes per walk range
+    constexpr uint32_t CAP = NW * WSIZE;                                          // unit capacity in bytes
+    constexpr bool BIG = CAP > ZS_BLOCK_MAX;
     extern __shared__ __attribute__((aligned(16))) uint8_t walkLds[];
     uint8_t *ls = walkLds + ZS_WALK_FRONT;                                       // ls[p] = source byte p
-    uint16_t *winAll = reinterpret_cast<uint16_t *>(walkLds + ZS_WALK_FRONT + CAP + ZS_WALK_TAIL);
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const ZsUnitDesc ud = units[blockIdx.x];
     const uint32_t slot = ud.firstBlock - block0;                                // scratch slot of the unit's first block
@@ -190,10 +213,11 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
     const uint32_t n = ud.size;
     const uint16_t *dist = distAll + (size_t)slot * ZS_BLOCK_MAX;
     const uint8_t *distHi = distHiAll + (size_t)slot * (ZS_BLOCK_MAX / 8);
+    const uint64_t *distMask = reinterpret_cast<const uint64_t *>(distMaskAll + (size_t)slot * (ZS_BLOCK_MAX / 8));
+    uint64_t *lm = reinterpret_cast<uint64_t *>(walkLds + ZS_WALK_FRONT + CAP + ZS_WALK_TAIL);     // lm: bit p set = position p has a candidate
     const uint32_t grp = lane >> 3, sub = lane & 7u;
     const uint32_t walker = wave * 8 + grp;
-    ZsSeqRec *seqs = seqAll + ((size_t)slot * ZS_WALK_RANGES + walker) * ZS_SEQ_PER_RANGE;
-    uint16_t *win = winAll + walker * 64;
+    ZsSeqRec *seqs = seqAll + (size_t)slot * (ZS_BLOCK_MAX / 4) + (size_t)walker * (WSIZE / 4);
 
     // ---- stage the unit ----
     if (tid < ZS_WALK_FRONT / 4) reinterpret_cast<uint32_t *>(walkLds)[tid] = 0;
@@ -207,13 +231,18 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
         }
         if (i + 16 <= CAP + ZS_WALK_TAIL) *reinterpret_cast<uint4 *>(ls + i) = v;
     }
+    // candidate bits of the positions that can start a match; the word behind them reads as zero
+    {
+        const uint32_t hashableAll = (n >= 4) ? n - 3 : 0, words = (hashableAll + 63) >> 6;
+        for (uint32_t i = tid; i <= words; i += NW * 8) lm[i] = (i < words) ? distMask[i] : 0ull;
+    }
     __syncthreads();
 
-    const uint32_t start = walker << ZS_WALK_LOG;
+    const uint32_t start = walker << WLOG;
     const uint32_t blockStart = start & ~(ZS_BLOCK_MAX - 1);                     // the walker's block inside the unit
     const uint32_t blockN = (blockStart < n) ? min(n - blockStart, ZS_BLOCK_MAX) : 0u;
     const bool alive = (start < n) && (blockN >= 16);
-    const uint32_t end = min(start + ZS_WALK_SIZE, n);
+    const uint32_t end = min(start + WSIZE, n);
     const uint32_t hashable = (n >= 4) ? n - 3 : 0;
     const uint32_t scanEnd = alive ? min(end, hashable) : 0;
 
@@ -222,38 +251,37 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
         const bool run = ip < scanEnd;
         if (!__any(run)) break;
         const uint32_t wend = min(ip + ZS_WINDOW, scanEnd);
-        // ---- window: 8 positions per lane ----
-        uint64_t w0 = 0, w1 = 0; uint32_t hi8 = 0;
+        // ---- window: candidate bits of [ip, ip + 64) from LDS (the same for the walker's 8 lanes); lane sub takes the
+        //      sub-th candidate and fetches its distance ----
+        uint64_t m64 = 0;
         if (run) {
-            const uint8_t *dp = reinterpret_cast<const uint8_t *>(dist + ip + 8 * sub); w0 = zs_load64(dp); w1 = zs_load64(dp + 8);
-            if (BIG) { const uint8_t *hp = distHi + ((ip + 8 * sub) >> 3); hi8 = (((uint32_t)hp[0] | ((uint32_t)hp[1] << 8)) >> (ip & 7u)) & 0xFFu; }
+            const uint32_t wi = ip >> 6, sh = ip & 63u, wlen = wend - ip;
+            const uint64_t lo = lm[wi], hi = lm[wi + 1];
+            m64 = (lo >> sh) | ((hi << 1) << (63u - sh));
+            if (wlen < 64u) m64 &= (1ull << wlen) - 1ull;
         }
-        uint32_t mask8 = 0;
-        #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
-            const uint32_t dk = (uint32_t)((k < 4 ? (w0 >> (16 * k)) : (w1 >> (16 * (k - 4)))) & 0xFFFFu);
-            if (dk && (ip + 8 * sub + k) < wend) mask8 |= 1u << k;
-        }
-        *reinterpret_cast<uint64_t *>(win + 8 * sub) = w0;
-        *reinterpret_cast<uint64_t *>(win + 8 * sub + 4) = w1;
-        uint64_t m64 = run ? ((uint64_t)mask8 << (8 * sub)) : 0ull;
-        m64 |= (uint64_t)__shfl_xor((long long)m64, 1);
-        m64 |= (uint64_t)__shfl_xor((long long)m64, 2);
-        m64 |= (uint64_t)__shfl_xor((long long)m64, 4);
-        const uint32_t ncand = min((uint32_t)__popcll(m64), (uint32_t)look);
+        const uint32_t mlo = (uint32_t)m64, mhi = (uint32_t)(m64 >> 32);
+        const uint32_t clo = (uint32_t)__popc(mlo);
+        const uint32_t ncand = min(clo + (uint32_t)__popc(mhi), (uint32_t)look);
         const bool active = run && sub < ncand;
         uint32_t idx = 0;
-        { uint64_t mm = m64; for (uint32_t t = 0; t < sub; t++) mm &= mm - 1; idx = mm ? (uint32_t)__builtin_ctzll(mm) : 0u; }
-        uint32_t off = active ? (uint32_t)win[idx] : 0u;
-        if (BIG) { const uint32_t hsrc = (uint32_t)__shfl((int)hi8, (int)((lane & ~7u) + (idx >> 3))); if (active) off |= ((hsrc >> (idx & 7u)) & 1u) << 16; }
+        {   // position of the sub-th set bit
+            const bool upper = sub >= clo;
+            uint32_t mm = upper ? mhi : mlo; const uint32_t skip = upper ? sub - clo : sub;
+            for (uint32_t t = 0; t < skip; t++) mm &= mm - 1;
+            idx = mm ? (uint32_t)__builtin_ctz(mm) + (upper ? 32u : 0u) : 0u;
+        }
+        uint32_t off = active ? (uint32_t)dist[ip + idx] : 0u;
+        if (BIG) { if (active) off |= (((uint32_t)distHi[(ip + idx) >> 3] >> ((ip + idx) & 7u)) & 1u) << 16; }
         const uint32_t q = ip + idx;
         // ---- compare from LDS: 16 bytes forward, 8 bytes backward, both sides ----
         uint32_t fwd = 0, back = 0;
         int key = 0;
         if (active) {
-            const uint8_t *pa = ls + q, *pb = ls + q - off;
-            const uint64_t x0 = lds64(pa) ^ lds64(pb), x1 = lds64(pa + 8) ^ lds64(pb + 8);
-            const uint64_t xb = lds64(pa - 8) ^ lds64(pb - 8);
+            uint32_t a[6], b[6];                                                 // bytes [q - 8, q + 16) of both sides
+            lds_span<6>(walkLds, ZS_WALK_FRONT + q - 8, a);
+            lds_span<6>(walkLds, ZS_WALK_FRONT + q - off - 8, b);
+            const uint64_t xb = zs_u64(a[0] ^ b[0], a[1] ^ b[1]), x0 = zs_u64(a[2] ^ b[2], a[3] ^ b[3]), x1 = zs_u64(a[4] ^ b[4], a[5] ^ b[5]);
             const uint32_t cap = min(end - q, ZS_LCAP);
             const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
             const uint32_t n1 = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u;
@@ -285,8 +313,10 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
                 const uint32_t cap = end - pos;            // pos < end while need
                 const uint32_t fo = 16 * sub;
                 if (fo < cap) {
-                    const uint8_t *pa = ls + pos + fo, *pb = ls + pos - boff + fo;
-                    const uint64_t x0 = lds64(pa) ^ lds64(pb), x1 = lds64(pa + 8) ^ lds64(pb + 8);
+                    uint32_t a[4], b[4];
+                    lds_span<4>(walkLds, ZS_WALK_FRONT + pos + fo, a);
+                    lds_span<4>(walkLds, ZS_WALK_FRONT + pos - boff + fo, b);
+                    const uint64_t x0 = zs_u64(a[0] ^ b[0], a[1] ^ b[1]), x1 = zs_u64(a[2] ^ b[2], a[3] ^ b[3]);
                     const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
                     const uint32_t n1 = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u;
                     nb = min((n0 < 8u) ? n0 : 8u + n1, cap - fo);
@@ -313,5 +343,5 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
             ip = bq + bfwd; anchor = ip;
         } else if (run) ip = wend;
     }
-    if (sub == 0) { ZsRangeHdr h; h.nseq = nseq; h.trailing = alive ? end - anchor : ((start < n) ? end - start : 0u); h.litSum = litSum; h.pad = 0; hdrAll[(size_t)slot * ZS_WALK_RANGES + walker] = h; }
+    if (sub == 0) { ZsRangeHdr h; h.nseq = nseq; h.trailing = alive ? end - anchor : ((start < n) ? end - start : 0u); h.litSum = litSum; h.pad = 0; hdrAll[(size_t)slot * (ZS_BLOCK_MAX >> WLOG) + walker] = h; }
 }

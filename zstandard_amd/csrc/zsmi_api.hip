@@ -117,7 +117,7 @@ struct zsmi_ctx {
     uint32_t maxBlocksInFlight = 8192;
     // compress workspace: plan (shared) + one scratch set per internal stream ("lane")
     DevBuf dBlocks, dChunks, dUnits;     // dUnits: small units (<= 64 KiB) first, then big ones, each in chunk order
-    struct Scratch { DevBuf dDist, dDistHi, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr, aux = nullptr; hipEvent_t done = nullptr, evWalk = nullptr, evSeq = nullptr; };
+    struct Scratch { DevBuf dDist, dDistHi, dDistMask, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr, aux = nullptr; hipEvent_t done = nullptr, evWalk = nullptr, evSeq = nullptr; };
     static const int kMaxLanes = 8;
     Scratch lanes[kMaxLanes];
     int nLanes = 1;
@@ -165,8 +165,9 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     // dynamic LDS beyond the 64 KiB default
     (void)hipFuncSetAttribute((const void *)k_lz_candidates<8, ZS_CAND_WPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (8 << ZS_HASH_LOG) * 2);
     (void)hipFuncSetAttribute((const void *)k_lz_candidates<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (16 << ZS_HASH_LOG) * 2);
-    (void)hipFuncSetAttribute((const void *)k_lz_walk<64>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(64));
-    (void)hipFuncSetAttribute((const void *)k_lz_walk<128>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(128));
+    (void)hipFuncSetAttribute((const void *)k_lz_walk<64, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_BLOCK_MAX));
+    (void)hipFuncSetAttribute((const void *)k_lz_walk<128, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_BLOCK_MAX));
+    (void)hipFuncSetAttribute((const void *)k_lz_walk<128, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_UNIT_MAX));
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_OVERLAP")) c->overlapEntropy = atoi(e) != 0;
     if (const char *e = getenv("ZSMI_STOP_LIT")) c->stopLit = atoi(e);
@@ -189,7 +190,7 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
     for (int i = 0; i < zsmi_ctx::kMaxLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
         if (L.stream) (void)hipStreamSynchronize(L.stream);
-        for (DevBuf *b : { &L.dDist, &L.dDistHi, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dLitSec, &L.dSeqSec, &L.dMetas }) b->release();
+        for (DevBuf *b : { &L.dDist, &L.dDistHi, &L.dDistMask, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dLitSec, &L.dSeqSec, &L.dMetas }) b->release();
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.evWalk) (void)hipEventDestroy(L.evWalk);
         if (L.evSeq) (void)hipEventDestroy(L.evSeq);
@@ -303,7 +304,7 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
     if (cap < maxChunkBlocks) cap = maxChunkBlocks;
     for (int i = 0; i < nLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
-        if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2 + 256) || !L.dDistHi.reserve((size_t)cap * (ZS_BLOCK_MAX / 8) + 256) || !L.dSeqs.reserve((size_t)cap * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
+        if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2 + 256) || !L.dDistHi.reserve((size_t)cap * (ZS_BLOCK_MAX / 8) + 256) || !L.dDistMask.reserve((size_t)cap * (ZS_BLOCK_MAX / 8) + 256) || !L.dSeqs.reserve((size_t)cap * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
             !L.dHdrs.reserve((size_t)cap * ZS_WALK_RANGES * sizeof(ZsRangeHdr)) || !L.dLits.reserve((size_t)cap * (ZS_BLOCK_MAX + 64)) ||
             !L.dStreams.reserve((size_t)cap * 4 * ZS_STREAM_STRIDE) || !L.dLitSec.reserve((size_t)cap * ZS_LITSEC_STRIDE) ||
             !L.dSeqSec.reserve((size_t)cap * ZS_SEQSEC_STRIDE) || !L.dMetas.reserve((size_t)cap * sizeof(ZsBlockMeta))) return ZSMI_error_memory_allocation;
@@ -322,13 +323,15 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         const uint32_t s0 = c->smallBefore[chunk0], ns = c->smallBefore[chunk1] - s0, b0 = c->bigBefore[chunk0], nbig = c->bigBefore[chunk1] - b0;
         const ZsUnitDesc *dUS = (const ZsUnitDesc *)c->dUnits.p + s0, *dUB = (const ZsUnitDesc *)c->dUnits.p + c->planSmall + b0;
         if (ns) LAUNCH_ON(c, st, "k_lz_candidates", (k_lz_candidates<8, ZS_CAND_WPR>), dim3(ns), dim3(8 * ZS_CAND_WPR * 64), (size_t)(8 << hashLog) * 2, (const uint8_t *)dSrc, dUS, block0,
-                          (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, hashLog);
+                          (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, (uint8_t *)L.dDistMask.p, hashLog);
         if (nbig) LAUNCH_ON(c, st, "k_lz_candidates_big", (k_lz_candidates<16, 1>), dim3(nbig), dim3(1024), (size_t)(16 << hashLog) * 2, (const uint8_t *)dSrc, dUB, block0,
-                            (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, hashLog);
-        if (ns) LAUNCH_ON(c, st, "k_lz_walk", (k_lz_walk<64>), dim3(ns), dim3(512), ZS_WALK_LDS(64), (const uint8_t *)dSrc, dUS, block0, (const uint16_t *)L.dDist.p,
-                          (const uint8_t *)L.dDistHi.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
-        if (nbig) LAUNCH_ON(c, st, "k_lz_walk_big", (k_lz_walk<128>), dim3(nbig), dim3(1024), ZS_WALK_LDS(128), (const uint8_t *)dSrc, dUB, block0, (const uint16_t *)L.dDist.p,
-                            (const uint8_t *)L.dDistHi.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
+                            (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, (uint8_t *)L.dDistMask.p, hashLog);
+        if (ns && getenv("ZSMI_EXP_WALK")) LAUNCH_ON(c, st, "k_lz_walk_exp", (k_lz_walk<128, 9>), dim3(ns), dim3(1024), ZS_WALK_LDS(ZS_BLOCK_MAX), (const uint8_t *)dSrc, dUS, block0, (const uint16_t *)L.dDist.p,
+                          (const uint8_t *)L.dDistHi.p, (const uint8_t *)L.dDistMask.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dLits.p, look);
+        if (ns) LAUNCH_ON(c, st, "k_lz_walk", (k_lz_walk<64, 10>), dim3(ns), dim3(512), ZS_WALK_LDS(ZS_BLOCK_MAX), (const uint8_t *)dSrc, dUS, block0, (const uint16_t *)L.dDist.p,
+                          (const uint8_t *)L.dDistHi.p, (const uint8_t *)L.dDistMask.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
+        if (nbig) LAUNCH_ON(c, st, "k_lz_walk_big", (k_lz_walk<128, 10>), dim3(nbig), dim3(1024), ZS_WALK_LDS(ZS_UNIT_MAX), (const uint8_t *)dSrc, dUB, block0, (const uint16_t *)L.dDist.p,
+                            (const uint8_t *)L.dDistHi.p, (const uint8_t *)L.dDistMask.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
         // the two entropy kernels are independent of each other: the sequences kernel runs on a side stream beside the literals kernel
         const bool overlap = c->overlapEntropy;
         hipStream_t st2 = overlap ? L.aux : st;
