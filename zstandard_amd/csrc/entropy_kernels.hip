@@ -45,6 +45,11 @@ struct FseCT {                       // encoding table of one symbol type
     uint32_t tableLog;
     uint32_t rle;
 };
+// workgroups per CU the literals kernel is compiled for: 8 caps it at 64 VGPRs, so the 16 blocks a CU gets per 4096-block
+// batch run in two full rounds (measured alone: 0.89 ms uncapped (88 VGPRs, 5 per CU), 0.74 at 6, 0.57 at 8 despite spills)
+#ifndef ZS_LIT_MINWG
+#define ZS_LIT_MINWG 8
+#endif
 struct K3Lds {                       // literals kernel
     uint32_t count[256];             // literal histogram
     uint8_t  nbBits[256];
@@ -498,7 +503,7 @@ __device__ __forceinline__ void loadRangesWave(const ZsRangeHdr *hdr, uint32_t *
 // literal gather + histogram (wavefront w takes ranges w and w+4), Huffman lengths by package-merge (256 threads),
 // table description (one lane), the 4 Huffman streams (one wavefront each)  -> litSec[], meta.{type, rleByte, litSecSize}
 // ---------------------------------------------------------------------------------------------
-extern "C" __global__ void __launch_bounds__(256)
+extern "C" __global__ void __launch_bounds__(256, ZS_LIT_MINWG)
 k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ blocks,
                   const ZsSeqRec *__restrict__ seqAll, const ZsRangeHdr *__restrict__ hdrAll,
                   uint8_t *__restrict__ litsAll, uint8_t *__restrict__ streamAll, uint8_t *__restrict__ litSecAll,
@@ -694,7 +699,7 @@ __device__ static void normalizeCountsWave(int16_t *norm, uint32_t tableLog, con
         still++;
     }
     if (lane <= maxSym) norm[lane] = (int16_t)p;
-    __syncthreads();
+    wave_sync();
 }
 
 // encoding table from a distribution without -1 entries, all lanes.  Cell order is the decoder's
@@ -714,14 +719,14 @@ __device__ static void buildCTableWave(SeqLds &L, FseCT &ct, const int16_t *norm
         else { const uint32_t maxBitsOut = tableLog - zs_highbit(nv - 1); ct.deltaNbBits[lane] = (maxBitsOut << 16) - (nv << maxBitsOut); ct.deltaFindState[lane] = (int)excl - (int)nv; }
     }
     if (lane == 0) { ct.tableLog = tableLog; ct.rle = 0; }
-    __syncthreads();
+    wave_sync();
     for (uint32_t j = lane; j < tableSize; j += 64) {
         // symbol owning slot j : last s with cumul[s] <= j
         uint32_t lo = 0, hi = maxSym + 1;
         while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (L.u.build.cumul[mid] <= j) lo = mid; else hi = mid; }
         L.u.build.tableSymbol[(j * step) & tableMask] = (uint8_t)lo;
     }
-    __syncthreads();
+    wave_sync();
     // stateTable[cumul[sym] + (rank of cell u among the cells of sym)] = tableSize + u, cells taken in ascending u
     for (uint32_t base = 0; base < tableSize; base += 64) {
         const uint32_t u = base + lane;
@@ -736,185 +741,208 @@ __device__ static void buildCTableWave(SeqLds &L, FseCT &ct, const int16_t *norm
                 const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1));
                 ct.stateTable[L.u.build.symCount[ls] + rank] = (uint16_t)(tableSize + u);
             }
-            __syncthreads();
+            wave_sync();
             if (lane == (uint32_t)leader) L.u.build.symCount[ls] += (uint32_t)__popcll(same);
-            __syncthreads();
+            wave_sync();
             todo &= ~same;
         }
     }
-    __syncthreads();
+    wave_sync();
 }
 
-extern "C" __global__ void __launch_bounds__(64)
-k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict__ seqAll, const ZsRangeHdr *__restrict__ hdrAll,
+#ifndef ZS_SEQ_GROUP
+#define ZS_SEQ_GROUP 4             // blocks (= wavefronts) per workgroup of the sequences kernel
+#endif
+template <int G>
+__global__ void __launch_bounds__(64 * G)
+k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsSeqRec *__restrict__ seqAll, const ZsRangeHdr *__restrict__ hdrAll,
                    uint8_t *__restrict__ seqSecAll, ZsBlockMeta *__restrict__ metas, int stopAt)
 {
-    __shared__ SeqLds L;
-    const uint32_t blk = blockIdx.x;
+    __shared__ SeqLds LS[G];
+    __shared__ uint32_t tilesOf[G];                    // bitstream tiles (64 sequences each) of the workgroup's blocks
+    const uint32_t wave = threadIdx.x >> 6;
+    SeqLds &L = LS[wave];
+    const uint32_t blk = blockIdx.x * G + wave;
     const uint32_t lane = (uint32_t)zs_lane();
-    const ZsBlockDesc bd = blocks[blk];
+    const bool exists = blk < nBlocks;
+    const ZsBlockDesc bd = blocks[exists ? blk : 0];
     const uint32_t n = bd.size;
     ZsSeqRec *seqBase = seqAll + (size_t)blk * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE;
     const ZsRangeHdr *hdr = hdrAll + (size_t)blk * ZS_WALK_RANGES;
     uint8_t *out = seqSecAll + (size_t)blk * ZS_SEQSEC_STRIDE;         // 4-byte aligned
     const uint32_t cap = n + 512;
 
-    #define FINISH(sz) do { if (lane == 0) metas[blk].seqSecSize = (sz); return; } while (0)
-    if (n < 16) FINISH(0xFFFFFFFFu);
+    // ======== part 1, each wavefront on its own block (no workgroup barrier inside): header, recent-offset codes,
+    //          histograms, tables.  result: section size so far / 0xFFFFFFFF = no compressed sequences section ========
+    uint32_t result = 0xFFFFFFFFu, nseq = 0, bitstreamOff = 0;
+    bool live = false;                                  // this wavefront has a bitstream to write in part 2
+    do {
+        if (!exists || n < 16) break;
+        loadRangesWave(hdr, L.rngN, L.rngCarry, L.rngStart, nullptr, &L.misc[1], &L.misc[2]);
+        for (uint32_t i = lane; i < 192; i += 64) L.count[i] = 0;
+        wave_sync();
+        nseq = L.rngStart[ZS_WALK_RANGES];
+        const uint32_t *rngN = L.rngN, *rngCarry = L.rngCarry;
 
-    loadRangesWave(hdr, L.rngN, L.rngCarry, L.rngStart, nullptr, &L.misc[1], &L.misc[2]);
-    for (uint32_t i = lane; i < 192; i += 64) L.count[i] = 0;
-    __syncthreads();
-    const uint32_t nseq = L.rngStart[ZS_WALK_RANGES];
-    const uint32_t *rngN = L.rngN, *rngCarry = L.rngCarry;
-
-    // ---- sequences section header (inverse of DecodeSeqHeaders, ZStdDecompress.cs:1110-1180) ----
-    uint32_t hdrBytes = (nseq < 128) ? 1 : (nseq < 0x7F00 ? 2 : 3);
-    if (lane == 0) {
-        if (nseq < 128) out[0] = (uint8_t)nseq;
-        else if (nseq < 0x7F00) { out[0] = (uint8_t)((nseq >> 8) + 0x80); out[1] = (uint8_t)nseq; }
-        else { out[0] = 0xFF; out[1] = (uint8_t)(nseq - 0x7F00); out[2] = (uint8_t)((nseq - 0x7F00) >> 8); }
-    }
-    if (nseq == 0) FINISH(hdrBytes);
-
-    // ---- pass 1: recent-offset codes + code histograms.  Rules (inverse of ZStdDecompress.cs:1509-1530):
-    //   the state changes unless (ll > 0 and off == rep0); a change gives [off, rep0, off == rep1 ? rep2 : rep1].
-    //   rep0 before a sequence is always the previous sequence's offset, so
-    //   rep1 = previous offset of the last changing sequence, rep2 = rep1 as seen by the last changing sequence
-    //   whose offset differed from its rep1: two "last index below me" scans per 64 sequences. ----
-    {
-        uint32_t cPrev, cA, cB;                       // carried: previous offset (= rep0), rep1, rep2
-        if (bd.firstInChunk) { cPrev = 1; cA = 4; cB = 8; } else { cPrev = 0xFFFFFFF1u; cA = 0xFFFFFFF2u; cB = 0xFFFFFFF3u; }
-        // sequences are taken 64 at a time in block order, whatever walk range they belong to
-        for (uint32_t base = 0; base < nseq; base += 64) {
-            const uint32_t g = base + lane;
-            const bool in = g < nseq;
-            uint32_t off = 0, ll = 0, ml = 0;
-            ZsSeqRec *rp = seqBase;
-            if (in) {
-                uint32_t rr = 0;
-                #pragma unroll
-                for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
-                const uint32_t k = g - L.rngStart[rr];
-                rp = seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + k;
-                const ZsSeqRec rec = *rp; off = (uint32_t)rec.off | (((uint32_t)rec.ml >> 13) & 1u) << 16; ll = rec.ll; ml = rec.ml & 0x1FFFu; if (k == 0) ll += rngCarry[rr];
-            }
-            uint32_t prev = (uint32_t)__shfl_up((int)off, 1); if (lane == 0) prev = cPrev;        // rep0 before me
-            const bool change = in && !(ll > 0 && off == prev);
-            const int j = lastFlagBelow(change);                                                  // last changing sequence before me
-            const uint32_t aSh = (uint32_t)__shfl((int)prev, max(j, 0));                          // every lane takes part: a source lane must be active
-            const uint32_t a = (j >= 0) ? aSh : cA;                                               // rep1 before me
-            const bool reset = change && (off != a);                                              // sequences after which rep2 = their rep1
-            const int kk = lastFlagBelow(reset);
-            const uint32_t bSh = (uint32_t)__shfl((int)a, max(kk, 0));
-            const uint32_t b = (kk >= 0) ? bSh : cB;                                              // rep2 before me
-            if (in) {
-                uint32_t val;
-                if (ll) { val = (off == prev) ? 1u : (off == a) ? 2u : (off == b) ? 3u : 0u; }
-                else    { val = (off == a) ? 1u : (off == b) ? 2u : 0u; }
-                rp->ml = (uint16_t)(ml | ((off >> 16) << 13) | (val << 14));
-                const uint32_t v = val ? val : off + 3;
-                atomicAdd(&L.count[llCodeOf(ll)], 1u);
-                atomicAdd(&L.count[64 + zs_highbit(v)], 1u);
-                atomicAdd(&L.count[128 + mlCodeOf(ml - 3)], 1u);
-            }
-            // carries for the next 64: state after the last sequence of this batch
-            const uint32_t cnt = min(64u, nseq - base);
-            const uint64_t chm = __ballot(change), rsm = __ballot(reset);
-            const uint32_t lastOff = (uint32_t)__shfl((int)off, (int)(cnt - 1));
-            if (chm) { const int jl = 63 - __builtin_clzll(chm); cA = (uint32_t)__shfl((int)prev, jl); }
-            if (rsm) { const int kl = 63 - __builtin_clzll(rsm); cB = (uint32_t)__shfl((int)a, kl); }
-            cPrev = lastOff;
+        // ---- sequences section header (inverse of DecodeSeqHeaders, ZStdDecompress.cs:1110-1180) ----
+        uint32_t hdrBytes = (nseq < 128) ? 1 : (nseq < 0x7F00 ? 2 : 3);
+        if (lane == 0) {
+            if (nseq < 128) out[0] = (uint8_t)nseq;
+            else if (nseq < 0x7F00) { out[0] = (uint8_t)((nseq >> 8) + 0x80); out[1] = (uint8_t)nseq; }
+            else { out[0] = 0xFF; out[1] = (uint8_t)(nseq - 0x7F00); out[2] = (uint8_t)((nseq - 0x7F00) >> 8); }
         }
-    }
-    __syncthreads();
-    if (stopAt == 1) FINISH(0xFFFFFFFFu);        // timing aid (ZSMI_STOP_SEQ): stop after repcodes + histograms
+        if (nseq == 0) { result = hdrBytes; break; }
 
-    // ---- modes and tables ----
-    uint32_t pos = hdrBytes + 1;                        // after nbSeq and the modes byte
-    uint32_t modeByte = 0;
-    bool fail = false;
-    #pragma unroll 1
-    for (uint32_t t = 0; t < 3; t++) {
-        const uint32_t *count = L.count + 64 * t;
-        const uint32_t maxCode = t == 0 ? MaxLL : (t == 1 ? MaxOff : MaxML);
-        const uint32_t maxLog = t == 1 ? 8 : 9;
-        const uint32_t defLog = t == 1 ? 5 : 6, defMax = t == 0 ? MaxLL : (t == 1 ? 28 : MaxML);
-        FseCT &ct = L.ct[t];
-        const uint32_t c = (lane <= maxCode) ? count[lane] : 0u;
-        const uint64_t present = __ballot(c != 0);
-        const uint32_t maxSym = 63u - (uint32_t)__builtin_clzll(present);       // nseq > 0: at least one symbol
-        const uint32_t largest = wave_max(c);
-        uint32_t mode;
-        if (largest == nseq) {
-            mode = 1;
-            if (pos >= cap) { fail = true; break; }
-            if (lane == 0) { out[pos] = (uint8_t)maxSym; ct.rle = 1; ct.tableLog = 0; }
-            pos += 1;
-        } else if (nseq < 64 && maxSym <= defMax) {
-            mode = 0;
-            if (lane == 0) {
-                const int16_t *defNorm = t == 0 ? c_LL_defaultNorm : (t == 1 ? c_OF_defaultNorm : c_ML_defaultNorm);
-                for (uint32_t i = 0; i <= defMax; i++) L.norm[i] = defNorm[i];
-                buildCTable(ct, L.u.build.tableSymbol, L.u.build.cumul, L.norm, defMax, defLog);
+        // ---- pass 1: recent-offset codes + code histograms.  Rules (inverse of ZStdDecompress.cs:1509-1530):
+        //   the state changes unless (ll > 0 and off == rep0); a change gives [off, rep0, off == rep1 ? rep2 : rep1].
+        //   rep0 before a sequence is always the previous sequence's offset, so
+        //   rep1 = previous offset of the last changing sequence, rep2 = rep1 as seen by the last changing sequence
+        //   whose offset differed from its rep1: two "last index below me" scans per 64 sequences. ----
+        {
+            uint32_t cPrev, cA, cB;                       // carried: previous offset (= rep0), rep1, rep2
+            if (bd.firstInChunk) { cPrev = 1; cA = 4; cB = 8; } else { cPrev = 0xFFFFFFF1u; cA = 0xFFFFFFF2u; cB = 0xFFFFFFF3u; }
+            // sequences are taken 64 at a time in block order, whatever walk range they belong to
+            for (uint32_t base = 0; base < nseq; base += 64) {
+                const uint32_t g = base + lane;
+                const bool in = g < nseq;
+                uint32_t off = 0, ll = 0, ml = 0;
+                ZsSeqRec *rp = seqBase;
+                if (in) {
+                    uint32_t rr = 0;
+                    #pragma unroll
+                    for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
+                    const uint32_t k = g - L.rngStart[rr];
+                    rp = seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + k;
+                    const ZsSeqRec rec = *rp; off = (uint32_t)rec.off | (((uint32_t)rec.ml >> 13) & 1u) << 16; ll = rec.ll; ml = rec.ml & 0x1FFFu; if (k == 0) ll += rngCarry[rr];
+                }
+                uint32_t prev = (uint32_t)__shfl_up((int)off, 1); if (lane == 0) prev = cPrev;        // rep0 before me
+                const bool change = in && !(ll > 0 && off == prev);
+                const int j = lastFlagBelow(change);                                                  // last changing sequence before me
+                const uint32_t aSh = (uint32_t)__shfl((int)prev, max(j, 0));                          // every lane takes part: a source lane must be active
+                const uint32_t a = (j >= 0) ? aSh : cA;                                               // rep1 before me
+                const bool reset = change && (off != a);                                              // sequences after which rep2 = their rep1
+                const int kk = lastFlagBelow(reset);
+                const uint32_t bSh = (uint32_t)__shfl((int)a, max(kk, 0));
+                const uint32_t b = (kk >= 0) ? bSh : cB;                                              // rep2 before me
+                if (in) {
+                    uint32_t val;
+                    if (ll) { val = (off == prev) ? 1u : (off == a) ? 2u : (off == b) ? 3u : 0u; }
+                    else    { val = (off == a) ? 1u : (off == b) ? 2u : 0u; }
+                    rp->ml = (uint16_t)(ml | ((off >> 16) << 13) | (val << 14));
+                    const uint32_t v = val ? val : off + 3;
+                    atomicAdd(&L.count[llCodeOf(ll)], 1u);
+                    atomicAdd(&L.count[64 + zs_highbit(v)], 1u);
+                    atomicAdd(&L.count[128 + mlCodeOf(ml - 3)], 1u);
+                }
+                // carries for the next 64: state after the last sequence of this batch
+                const uint32_t cnt = min(64u, nseq - base);
+                const uint64_t chm = __ballot(change), rsm = __ballot(reset);
+                const uint32_t lastOff = (uint32_t)__shfl((int)off, (int)(cnt - 1));
+                if (chm) { const int jl = 63 - __builtin_clzll(chm); cA = (uint32_t)__shfl((int)prev, jl); }
+                if (rsm) { const int kl = 63 - __builtin_clzll(rsm); cB = (uint32_t)__shfl((int)a, kl); }
+                cPrev = lastOff;
             }
-        } else {
-            uint32_t tableLog = maxLog;
-            { const uint32_t hb = zs_highbit(nseq - 1); const uint32_t want = hb > 2 ? hb - 2 : 5; if (want < tableLog) tableLog = want; }
-            { const uint32_t minBits = zs_highbit(maxSym) + 2; const uint32_t npresent = (uint32_t)__popcll(present);
-              if (tableLog < minBits) tableLog = minBits; while ((1u << tableLog) < npresent) tableLog++; }
-            if (tableLog < 5) tableLog = 5;
-            if (tableLog > maxLog) tableLog = maxLog;
-            normalizeCountsWave(L.norm, tableLog, count, nseq, maxSym);
-            if (lane == 0) L.misc[0] = writeNCount(out + pos, cap - pos, L.norm, maxSym, tableLog);
-            __syncthreads();
-            const uint32_t h = L.misc[0];
-            if (!h) { fail = true; break; }
-            pos += h;
-            mode = 2;
-            buildCTableWave(L, ct, L.norm, maxSym, tableLog);
         }
-        modeByte |= mode << (6 - 2 * t);
-        __syncthreads();
-    }
-    if (fail) FINISH(0xFFFFFFFFu);
-    if (stopAt == 2) FINISH(0xFFFFFFFFu);        // stop after the tables
-    if (lane == 0) out[hdrBytes] = (uint8_t)modeByte;
-    const uint32_t bitstreamOff = pos;
+        wave_sync();
+        if (stopAt == 1) break;                         // timing aid (ZSMI_STOP_SEQ): stop after repcodes + histograms
 
-    // ---- sequences bitstream (inverse of ZStdDecompress.cs:1473-1608): last sequence first.  Per tile of 64:
-    //      codes + table operands (all lanes) -> FSE state chains (lanes 0..2 = LL, OF, ML) -> pack (all lanes).
-    //      The stream is built 4-byte aligned at out + 4096-slack... it is written in place after an aligned gap and moved. ----
+        // ---- modes and tables ----
+        uint32_t pos = hdrBytes + 1;                        // after nbSeq and the modes byte
+        uint32_t modeByte = 0;
+        bool fail = false;
+        #pragma unroll 1
+        for (uint32_t t = 0; t < 3; t++) {
+            const uint32_t *count = L.count + 64 * t;
+            const uint32_t maxCode = t == 0 ? MaxLL : (t == 1 ? MaxOff : MaxML);
+            const uint32_t maxLog = t == 1 ? 8 : 9;
+            const uint32_t defLog = t == 1 ? 5 : 6, defMax = t == 0 ? MaxLL : (t == 1 ? 28 : MaxML);
+            FseCT &ct = L.ct[t];
+            const uint32_t c = (lane <= maxCode) ? count[lane] : 0u;
+            const uint64_t present = __ballot(c != 0);
+            const uint32_t maxSym = 63u - (uint32_t)__builtin_clzll(present);       // nseq > 0: at least one symbol
+            const uint32_t largest = wave_max(c);
+            uint32_t mode;
+            if (largest == nseq) {
+                mode = 1;
+                if (pos >= cap) { fail = true; break; }
+                if (lane == 0) { out[pos] = (uint8_t)maxSym; ct.rle = 1; ct.tableLog = 0; }
+                pos += 1;
+            } else if (nseq < 64 && maxSym <= defMax) {
+                mode = 0;
+                if (lane == 0) {
+                    const int16_t *defNorm = t == 0 ? c_LL_defaultNorm : (t == 1 ? c_OF_defaultNorm : c_ML_defaultNorm);
+                    for (uint32_t i = 0; i <= defMax; i++) L.norm[i] = defNorm[i];
+                    buildCTable(ct, L.u.build.tableSymbol, L.u.build.cumul, L.norm, defMax, defLog);
+                }
+            } else {
+                uint32_t tableLog = maxLog;
+                { const uint32_t hb = zs_highbit(nseq - 1); const uint32_t want = hb > 2 ? hb - 2 : 5; if (want < tableLog) tableLog = want; }
+                { const uint32_t minBits = zs_highbit(maxSym) + 2; const uint32_t npresent = (uint32_t)__popcll(present);
+                  if (tableLog < minBits) tableLog = minBits; while ((1u << tableLog) < npresent) tableLog++; }
+                if (tableLog < 5) tableLog = 5;
+                if (tableLog > maxLog) tableLog = maxLog;
+                normalizeCountsWave(L.norm, tableLog, count, nseq, maxSym);
+                if (lane == 0) L.misc[0] = writeNCount(out + pos, cap - pos, L.norm, maxSym, tableLog);
+                wave_sync();
+                const uint32_t h = L.misc[0];
+                if (!h) { fail = true; break; }
+                pos += h;
+                mode = 2;
+                buildCTableWave(L, ct, L.norm, maxSym, tableLog);
+            }
+            modeByte |= mode << (6 - 2 * t);
+            wave_sync();
+        }
+        if (fail) break;
+        if (stopAt == 2) break;                         // stop after the tables
+        if (lane == 0) out[hdrBytes] = (uint8_t)modeByte;
+        bitstreamOff = pos;
+        live = true;
+    } while (0);
+
+    // ======== part 2: sequences bitstream (inverse of ZStdDecompress.cs:1473-1608), last sequence first.  Per tile of 64
+    //   sequences: every wavefront turns its block's sequences into codes + table operands (all lanes); then wavefront 0
+    //   runs the FSE state chains of ALL G blocks at once (lane 3g + c: table c = LL, OF, ML of block g) -- a chain step is a
+    //   dependent LDS lookup per sequence, so sharing its instructions between blocks is what keeps the vector ALU free --;
+    //   then every wavefront packs its block's bits (all lanes).  The stream is built 4-byte aligned and moved down. ========
+    const uint32_t nT = live ? (nseq + 63u) >> 6 : 0u;
+    if (lane == 0) tilesOf[wave] = nT;
+    __syncthreads();
+    uint32_t maxT = 0;
+    #pragma unroll
+    for (int g = 0; g < G; g++) maxT = max(maxT, tilesOf[g]);
+
     uint8_t *bsTmp = out + ((bitstreamOff + 3u) & ~3u);                // aligned start inside the section buffer
     BitSink sink; sink_init(sink, bsTmp, L.tile);
     const uint32_t bsCap = ZS_SEQSEC_STRIDE - ((bitstreamOff + 3u) & ~3u) - 1024u;
-    uint32_t chainState = 0;                          // lanes 0..2
+    uint32_t chainState = 0;                          // wavefront 0, lane 3g + c
     bool overflow = false;
-    {
-        uint32_t remaining = nseq;
-        bool first = true;
-        // sequence records are fetched one tile ahead: the loads of tile i+1 fly while the state chains of tile i run
-        ZsSeqRec recN; uint32_t carryN = 0; bool validN = false;
-        auto fetch = [&](uint32_t rem) {
-            validN = false; carryN = 0; recN.ll = recN.ml = recN.off = recN.flags = 0;
-            const uint32_t T2 = min(64u, rem);
-            if (lane < T2) {
-                const uint32_t g = rem - 1 - lane;
-                uint32_t rr = 0;                                                  // last walk range whose first sequence index is <= g
-                #pragma unroll
-                for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
-                const uint32_t k = g - L.rngStart[rr];
-                recN = seqBase[(size_t)rr * ZS_SEQ_PER_RANGE + k];
-                carryN = (k == 0) ? L.rngCarry[rr] : 0u;
-                validN = true;
-            }
-        };
-        fetch(remaining);
-        while (remaining) {
-            const uint32_t T = min(64u, remaining);
+    uint32_t remaining = live ? nseq : 0u;
+    // sequence records are fetched one tile ahead: the loads of tile i+1 fly while the state chains of tile i run
+    ZsSeqRec recN; uint32_t carryN = 0; bool validN = false;
+    recN.ll = recN.ml = recN.off = recN.flags = 0;
+    auto fetch = [&](uint32_t rem) {
+        validN = false; carryN = 0; recN.ll = recN.ml = recN.off = recN.flags = 0;
+        const uint32_t T2 = min(64u, rem);
+        if (lane < T2) {
+            const uint32_t g = rem - 1 - lane;
+            uint32_t rr = 0;                                                  // last walk range whose first sequence index is <= g
+            #pragma unroll
+            for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
+            const uint32_t k = g - L.rngStart[rr];
+            recN = seqBase[(size_t)rr * ZS_SEQ_PER_RANGE + k];
+            carryN = (k == 0) ? L.rngCarry[rr] : 0u;
+            validN = true;
+        }
+    };
+    if (remaining) fetch(remaining);
+    for (uint32_t i = 0; i < maxT; i++) {
+        const bool mine = (i < nT) && !overflow;
+        uint32_t T = 0, ll = 0, ml = 0, val = 0, llc = 0, mlc = 0, ofc = 0;
+        if (mine) {
+            T = min(64u, remaining);
             const ZsSeqRec rec = recN; const uint32_t carry = carryN; const bool valid = validN;
             if (remaining > T) fetch(remaining - T);
-            uint32_t ll = 0, ml = 0, val = 0, llc = 0, mlc = 0, ofc = 0;
             uint2 o0 = make_uint2(0, 0), o1 = o0, o2 = o0;
             if (valid) {
                 ll = (uint32_t)rec.ll + carry;
@@ -927,14 +955,22 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
             }
             L.u.tile.op[0][lane] = o0; L.u.tile.op[1][lane] = o1; L.u.tile.op[2][lane] = o2;
             if (lane < 2) { L.u.tile.op[0][64 + lane] = make_uint2(0, 0); L.u.tile.op[1][64 + lane] = make_uint2(0, 0); L.u.tile.op[2][64 + lane] = make_uint2(0, 0); }
-            __syncthreads();
-            if (lane < 3) {
-                const FseCT &ct = L.ct[lane];
-                const uint2 *op = L.u.tile.op[lane];
-                uint32_t *outp = L.u.tile.tileState[lane];
+        }
+        if (lane == 0) L.misc[3] = T;                  // 0: no tile of this block in this round
+        __syncthreads();
+        if (wave == 0) {
+            const uint32_t g = min(lane / 3u, (uint32_t)(G - 1)), c = lane - 3u * (lane / 3u);
+            const bool chainLane = lane < 3u * G;
+            SeqLds &B = LS[g];
+            const uint32_t Tg = chainLane ? B.misc[3] : 0u;
+            const uint32_t Tmax = wave_max(Tg);
+            if (chainLane && Tg && stopAt != 3) {              // stopAt 3: timing aid, no chains
+                const FseCT &ct = B.ct[c];
+                const uint2 *op = B.u.tile.op[c];
+                uint32_t *outp = B.u.tile.tileState[c];
                 if (!ct.rle) {
                     uint32_t t = 0;
-                    if (first) {
+                    if (i == 0) {                      // first step of the block: the state is chosen from the symbol alone
                         const uint32_t dnb = op[0].x;
                         const uint32_t nbo = (dnb + (1u << 15)) >> 16;
                         const uint32_t v = (nbo << 16) - dnb;
@@ -942,21 +978,24 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
                         outp[0] = 0;
                         t = 1;
                     }
-                    // operands of step t+1 are read before the dependent table lookup of step t
-                    const uint32_t Tn = (uint32_t)__builtin_amdgcn_readfirstlane((int)T);
+                    // operands of step t+1 are read before the dependent table lookup of step t; lanes whose tile is shorter idle
                     uint2 cur = op[t];
-                    for (; t < Tn; t++) {
+                    for (; t < Tmax; t++) {
                         const uint2 nxt = op[t + 1];
-                        const uint32_t nbo = (chainState + cur.x) >> 16;
-                        outp[t] = (chainState & ((1u << nbo) - 1)) | (nbo << 16);
-                        chainState = ct.stateTable[(chainState >> nbo) + (int)cur.y];
+                        if (t < Tg) {
+                            const uint32_t nbo = (chainState + cur.x) >> 16;
+                            outp[t] = (chainState & ((1u << nbo) - 1)) | (nbo << 16);
+                            chainState = ct.stateTable[(chainState >> nbo) + (int)cur.y];
+                        }
                         cur = nxt;
                     }
                 } else {
-                    for (uint32_t t = 0; t < T; t++) outp[t] = 0;
+                    for (uint32_t t = 0; t < Tg; t++) outp[t] = 0;
                 }
             }
-            __syncthreads();
+        }
+        __syncthreads();
+        if (mine && stopAt != 4) {                             // stopAt 4: timing aid, no packing
             uint64_t lo = 0; uint32_t hi = 0, nb = 0;
             if (lane < T) {
                 #define PUTB(v, b) { const uint32_t b_ = (b); if (b_) { const uint64_t v_ = (uint64_t)(v); if (nb < 64) { lo |= v_ << nb; if (nb + b_ > 64) hi |= (uint32_t)(v_ >> (64 - nb)); } else hi |= (uint32_t)(v_ << (nb - 64)); nb += b_; } }
@@ -969,42 +1008,45 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, ZsSeqRec *__restrict_
                 PUTB(val - (1u << ofc), ofc);
                 #undef PUTB
             }
-            if (sink.bitpos / 8 + 1024 > bsCap) { overflow = true; break; }
-            sink_put(sink, lo, hi, nb);
+            if (sink.bitpos / 8 + 1024 > bsCap) overflow = true;
+            else sink_put(sink, lo, hi, nb);
             remaining -= T;
-            first = false;
         }
     }
-    if (overflow) FINISH(0xFFFFFFFFu);
-    {
-        // final states: ML, OF, LL (ZStdDecompress.cs:1578-1580 reads LL, OF, ML)
-        const uint32_t tlLL = L.ct[0].rle ? 0 : L.ct[0].tableLog;
-        const uint32_t tlOF = L.ct[1].rle ? 0 : L.ct[1].tableLog;
-        const uint32_t tlML = L.ct[2].rle ? 0 : L.ct[2].tableLog;
-        const uint32_t stLL = (uint32_t)__shfl((int)chainState, 0), stOF = (uint32_t)__shfl((int)chainState, 1), stML = (uint32_t)__shfl((int)chainState, 2);
-        uint64_t lo = 0; uint32_t nb = 0;
-        if (lane == 0) {
-            if (tlML) { lo |= (uint64_t)(stML & ((1u << tlML) - 1)) << nb; nb += tlML; }
-            if (tlOF) { lo |= (uint64_t)(stOF & ((1u << tlOF) - 1)) << nb; nb += tlOF; }
-            if (tlLL) { lo |= (uint64_t)(stLL & ((1u << tlLL) - 1)) << nb; nb += tlLL; }
+    // final states back to their blocks
+    if (wave == 0 && lane < 3u * G) LS[lane / 3u].misc[4 + lane % 3u] = chainState;
+    __syncthreads();
+    if (live && !overflow) {
+        {
+            // final states: ML, OF, LL (ZStdDecompress.cs:1578-1580 reads LL, OF, ML)
+            const uint32_t tlLL = L.ct[0].rle ? 0 : L.ct[0].tableLog;
+            const uint32_t tlOF = L.ct[1].rle ? 0 : L.ct[1].tableLog;
+            const uint32_t tlML = L.ct[2].rle ? 0 : L.ct[2].tableLog;
+            const uint32_t stLL = L.misc[4], stOF = L.misc[5], stML = L.misc[6];
+            uint64_t lo = 0; uint32_t nb = 0;
+            if (lane == 0) {
+                if (tlML) { lo |= (uint64_t)(stML & ((1u << tlML) - 1)) << nb; nb += tlML; }
+                if (tlOF) { lo |= (uint64_t)(stOF & ((1u << tlOF) - 1)) << nb; nb += tlOF; }
+                if (tlLL) { lo |= (uint64_t)(stLL & ((1u << tlLL) - 1)) << nb; nb += tlLL; }
+            }
+            sink_put(sink, lo, 0u, nb);
         }
-        sink_put(sink, lo, 0u, nb);
-    }
-    const uint32_t bsSize = sink_close(sink);
-    // move the stream down to its unaligned place (gap <= 3 bytes; lanes move ascending chunks, reads of a round precede its writes)
-    const uint32_t gap = (uint32_t)(bsTmp - (out + bitstreamOff));
-    if (gap) {
-        for (uint32_t base = 0; base < bsSize; base += 64) {
-            const uint32_t j = base + lane;
-            const uint8_t v = (j < bsSize) ? bsTmp[j] : 0;
-            __syncthreads();
-            if (j < bsSize) out[bitstreamOff + j] = v;
-            __syncthreads();
+        const uint32_t bsSize = sink_close(sink);
+        // move the stream down to its unaligned place (gap <= 3 bytes; lanes move ascending chunks, reads of a round precede its writes)
+        const uint32_t gap = (uint32_t)(bsTmp - (out + bitstreamOff));
+        if (gap) {
+            for (uint32_t base = 0; base < bsSize; base += 64) {
+                const uint32_t j = base + lane;
+                const uint8_t v = (j < bsSize) ? bsTmp[j] : 0;
+                wave_sync();
+                if (j < bsSize) out[bitstreamOff + j] = v;
+                wave_sync();
+            }
         }
+        const uint32_t total = bitstreamOff + bsSize;
+        result = total > cap ? 0xFFFFFFFFu : total;
     }
-    const uint32_t total = bitstreamOff + bsSize;
-    FINISH(total > cap ? 0xFFFFFFFFu : total);
-    #undef FINISH
+    if (lane == 0 && exists) metas[blk].seqSecSize = result;
 }
 
 // ---------------------------------------------------------------------------------------------

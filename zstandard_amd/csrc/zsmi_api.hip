@@ -121,7 +121,7 @@ struct zsmi_ctx {
     static const int kMaxLanes = 8;
     Scratch lanes[kMaxLanes];
     int nLanes = 1;
-    bool overlapEntropy = true;
+    bool overlapEntropy = false;           // ZSMI_OVERLAP=1: sequences kernel on a side stream beside the literals kernel (measured slower: both want the whole LDS)
     int stopLit = 0, stopSeq = 0;          // timing aids (ZSMI_STOP_LIT / ZSMI_STOP_SEQ): end a kernel after a stage; output is then invalid
     hipEvent_t evStart = nullptr;
     PinBuf hBlocks, hChunks, hUnits;
@@ -336,7 +336,7 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         const bool overlap = c->overlapEntropy;
         hipStream_t st2 = overlap ? L.aux : st;
         if (overlap) { (void)hipEventRecord(L.evWalk, st); (void)hipStreamWaitEvent(st2, L.evWalk, 0); }
-        LAUNCH_ON(c, st2, "k_encode_sequences", k_encode_sequences, dim3(nb), dim3(64), 0, dB, (ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
+        LAUNCH_ON(c, st2, "k_encode_sequences", (k_encode_sequences<ZS_SEQ_GROUP>), dim3((nb + ZS_SEQ_GROUP - 1) / ZS_SEQ_GROUP), dim3(64 * ZS_SEQ_GROUP), 0, dB, nb, (ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
                   (uint8_t *)L.dSeqSec.p, (ZsBlockMeta *)L.dMetas.p, c->stopSeq);
         LAUNCH_ON(c, st, "k_encode_literals", k_encode_literals, dim3(nb), dim3(256), 0, (const uint8_t *)dSrc, dB, (const ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
                   (uint8_t *)L.dLits.p, (uint8_t *)L.dStreams.p, (uint8_t *)L.dLitSec.p, (ZsBlockMeta *)L.dMetas.p, c->stopLit);
