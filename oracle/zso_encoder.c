@@ -59,7 +59,7 @@ typedef uint64_t U64;
 #define WALK_LOG    10              /* the walk cuts the unit in ranges of 1 KiB (the hash tables keep their 8 KiB ranges) */
 #define WALK_SIZE   (1u << WALK_LOG)
 #define WALK_RANGES (UNIT_MAX / WALK_SIZE)
-#define MINMATCH    4
+#define MINMATCH    5               /* shortest match kept (candidates are still found by their first 4 bytes) */
 #define MAX_HASH_LOG 13
 #define TAG_BITS    3               /* RANGE_LOG + TAG_BITS = 16: one slot is a uint16 */
 #define SLOT_EMPTY  0xFFFFu

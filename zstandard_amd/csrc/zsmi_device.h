@@ -12,12 +12,12 @@
 #define ZS_WALK_LOG    10
 #define ZS_WALK_SIZE   (1u << ZS_WALK_LOG)   // the walk cuts the block in ranges of 1 KiB
 #define ZS_WALK_RANGES 64u        // per block
-#define ZS_MINMATCH    4u
+#define ZS_MINMATCH    5u         // shortest match kept (candidates are found by their first 4 bytes)
 #define ZS_WINDOW      64u        // positions looked at per walk step (one wavefront)
 #define ZS_FCAP        8u         // forward bytes compared when scoring a candidate
 #define ZS_BCAP        8u         // backward bytes compared when scoring a candidate
 #define ZS_LCAP        16u        // forward bytes a walker lane compares in its one round of loads; longer matches are extended
-#define ZS_SEQ_PER_RANGE 256u     // per walk range: 1024 / MINMATCH
+#define ZS_SEQ_PER_RANGE 256u     // record slots per walk range (1024 / 4)
 #define ZS_HUF_MAXBITS 11u
 
 // one 64 KiB block of one chunk
