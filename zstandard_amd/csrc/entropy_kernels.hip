@@ -85,24 +85,33 @@ struct SeqLds {                      // sequences kernel.  Kept under 10 KiB: 16
 // ---------------------------------------------------------------------------------------------
 // wave helpers
 // ---------------------------------------------------------------------------------------------
+// Cross-lane moves by data-parallel primitives (DPP): vector-ALU operand modifiers, no LDS round trip (a __shfl is a
+// ds_bpermute: ~100 cycles of latency each, six in a row for a scan).  Control codes (gfx9): row_shr:n = 0x110 + n
+// (zero fill with bound_ctrl), row_bcast15 = 0x142 (lane 15 of a row to the next row), row_bcast31 = 0x143.
+#define ZS_DPP(old, v, ctrl, rowMask, boundCtrl) ((uint32_t)__builtin_amdgcn_update_dpp((int)(old), (int)(v), (ctrl), (rowMask), 0xF, (boundCtrl)))
 __device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v)
 {
-    const int lane = zs_lane();
-    #pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const uint32_t t = (uint32_t)__shfl_up((int)v, d); if (lane >= d) v += t; }
+    v += ZS_DPP(0, v, 0x111, 0xF, true);
+    v += ZS_DPP(0, v, 0x112, 0xF, true);
+    v += ZS_DPP(0, v, 0x114, 0xF, true);
+    v += ZS_DPP(0, v, 0x118, 0xF, true);            // inclusive within each row of 16
+    v += ZS_DPP(0, v, 0x142, 0xA, false);           // rows 1, 3 += total of the row before
+    v += ZS_DPP(0, v, 0x143, 0xC, false);           // rows 2, 3 += total of rows 0..1
     return v;
 }
-__device__ __forceinline__ uint32_t wave_sum(uint32_t v)
-{
-    #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
-    return v;
-}
+// value of lane l, l the same for the whole wavefront
+__device__ __forceinline__ uint32_t wave_get(uint32_t v, int l) { return (uint32_t)__builtin_amdgcn_readlane((int)v, __builtin_amdgcn_readfirstlane(l)); }
+__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) { return wave_last(wave_incl_scan(v)); }
 __device__ __forceinline__ uint32_t wave_max(uint32_t v)
 {
-    #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) v = max(v, (uint32_t)__shfl_xor((int)v, d));
-    return v;
+    v = max(v, ZS_DPP(0, v, 0x111, 0xF, true));
+    v = max(v, ZS_DPP(0, v, 0x112, 0xF, true));
+    v = max(v, ZS_DPP(0, v, 0x114, 0xF, true));
+    v = max(v, ZS_DPP(0, v, 0x118, 0xF, true));
+    v = max(v, ZS_DPP(0, v, 0x142, 0xA, false));
+    v = max(v, ZS_DPP(0, v, 0x143, 0xC, false));
+    return wave_last(v);
 }
 
 // ordering point between LDS accesses of different lanes of ONE wavefront: LDS instructions of a wave execute in issue
@@ -126,7 +135,7 @@ __device__ __forceinline__ void sink_put(BitSink &b, uint64_t lo, uint32_t hi, u
 {
     const uint32_t lane = (uint32_t)zs_lane();
     const uint32_t incl = wave_incl_scan(nb);
-    const uint32_t total = (uint32_t)__shfl((int)incl, 63);
+    const uint32_t total = wave_last(incl);
     const uint32_t base = b.bitpos & 31u;
     const uint32_t nwords = (base + total + 31u) >> 5;
     for (uint32_t i = 1 + lane; i <= nwords; i += 64) b.tile[i] = 0;
@@ -493,8 +502,8 @@ __device__ __forceinline__ void loadRangesWave(const ZsRangeHdr *hdr, uint32_t *
     rngN[lane] = ns; if (rngStart) rngStart[lane] = nsIncl - ns; rngCarry[lane] = (j >= 0) ? P - Pj : P;
     if (litBase) litBase[lane] = lsIncl - lsum;
     const uint64_t has = __ballot(ns != 0);
-    const uint32_t total = (uint32_t)__shfl((int)trIncl, 63);
-    const uint32_t Plast = has ? (uint32_t)__shfl((int)P, 63 - __builtin_clzll(has)) : 0u;
+    const uint32_t total = wave_last(trIncl);
+    const uint32_t Plast = has ? wave_get(P, 63 - __builtin_clzll(has)) : 0u;
     if (lane == 63) { if (rngStart) rngStart[ZS_WALK_RANGES] = nsIncl; *lastLits = has ? total - Plast : total; *allLits = lsIncl; }
 }
 
@@ -575,10 +584,10 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
             uint64_t longm = __ballot(ll > 16);
             while (longm) {
                 const int t = __builtin_ctzll(longm); longm &= longm - 1;
-                const uint32_t l2 = (uint32_t)__shfl((int)ll, t), d2 = (uint32_t)__shfl((int)dstOff, t), s2 = (uint32_t)__shfl((int)srcPos, t);
+                const uint32_t l2 = wave_get(ll, t), d2 = wave_get(dstOff, t), s2 = wave_get(srcPos, t);
                 for (uint32_t j = lane; j < l2; j += 64) { const uint8_t c = s[s2 + j]; lits[d2 + j] = c; atomicAdd(&L.count[c], 1u); }
             }
-            done += (uint32_t)__shfl((int)incl, 63);
+            done += wave_last(incl);
         }
     }
     for (uint32_t j = tid; j < lastLits; j += 256) { const uint8_t c = s[n - lastLits + j]; lits[nlit - lastLits + j] = c; atomicAdd(&L.count[c], 1u); }
@@ -735,7 +744,7 @@ __device__ static void buildCTableWave(SeqLds &L, FseCT &ct, const int16_t *norm
         uint64_t todo = __ballot(in);
         while (todo) {
             const int leader = __builtin_ctzll(todo);
-            const uint32_t ls = (uint32_t)__shfl((int)sym, leader);
+            const uint32_t ls = wave_get(sym, leader);
             const uint64_t same = __ballot(in && sym == ls);
             if (in && sym == ls) {
                 const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1));
@@ -815,7 +824,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                     rp = seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + k;
                     const ZsSeqRec rec = *rp; off = (uint32_t)rec.off | (((uint32_t)rec.ml >> 13) & 1u) << 16; ll = rec.ll; ml = rec.ml & 0x1FFFu; if (k == 0) ll += rngCarry[rr];
                 }
-                uint32_t prev = (uint32_t)__shfl_up((int)off, 1); if (lane == 0) prev = cPrev;        // rep0 before me
+                uint32_t prev = ZS_DPP(0, off, 0x138, 0xF, true); if (lane == 0) prev = cPrev;      // wave_shr:1        // rep0 before me
                 const bool change = in && !(ll > 0 && off == prev);
                 const int j = lastFlagBelow(change);                                                  // last changing sequence before me
                 const uint32_t aSh = (uint32_t)__shfl((int)prev, max(j, 0));                          // every lane takes part: a source lane must be active
@@ -837,9 +846,9 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                 // carries for the next 64: state after the last sequence of this batch
                 const uint32_t cnt = min(64u, nseq - base);
                 const uint64_t chm = __ballot(change), rsm = __ballot(reset);
-                const uint32_t lastOff = (uint32_t)__shfl((int)off, (int)(cnt - 1));
-                if (chm) { const int jl = 63 - __builtin_clzll(chm); cA = (uint32_t)__shfl((int)prev, jl); }
-                if (rsm) { const int kl = 63 - __builtin_clzll(rsm); cB = (uint32_t)__shfl((int)a, kl); }
+                const uint32_t lastOff = wave_get(off, (int)(cnt - 1));
+                if (chm) { const int jl = 63 - __builtin_clzll(chm); cA = wave_get(prev, jl); }
+                if (rsm) { const int kl = 63 - __builtin_clzll(rsm); cB = wave_get(a, kl); }
                 cPrev = lastOff;
             }
         }

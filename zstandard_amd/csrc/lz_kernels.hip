@@ -267,8 +267,11 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
         uint32_t idx = 0;
         {   // position of the sub-th set bit
             const bool upper = sub >= clo;
-            uint32_t mm = upper ? mhi : mlo; const uint32_t skip = upper ? sub - clo : sub;
-            for (uint32_t t = 0; t < skip; t++) mm &= mm - 1;
+            uint32_t mm = upper ? mhi : mlo; const uint32_t skip = upper ? sub - clo : sub;     // skip <= 7
+            // clear the lowest skip set bits, branch free: 4, 2, 1 of them by the bits of skip
+            { uint32_t t = mm & (mm - 1); t &= t - 1; t &= t - 1; t &= t - 1; mm = (skip & 4u) ? t : mm; }
+            { uint32_t t = mm & (mm - 1); t &= t - 1; mm = (skip & 2u) ? t : mm; }
+            { const uint32_t t = mm & (mm - 1); mm = (skip & 1u) ? t : mm; }
             idx = mm ? (uint32_t)__builtin_ctz(mm) + (upper ? 32u : 0u) : 0u;
         }
         uint32_t off = active ? (uint32_t)dist[ip + idx] : 0u;
@@ -293,15 +296,19 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
                 key = ((gain + 2048) << 3) | (int)(7u - sub);
             }
         }
+        // best key of the walker's 8 lanes: data-parallel-primitive moves (xor 1, xor 2 inside a quad, then the mirrored
+        // lane of the other quad) -- no LDS round trips
         int best = key;
-        best = max(best, __shfl_xor(best, 1));
-        best = max(best, __shfl_xor(best, 2));
-        best = max(best, __shfl_xor(best, 4));
+        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x141, 0xF, 0xF, false));    // row_half_mirror: lane i <- lane 7 - i
         const uint32_t bl = (lane & ~7u) + (7u - (uint32_t)(best & 7));      // lane holding the best candidate
-        const uint32_t bq = (uint32_t)__shfl((int)q, (int)bl);
+        // its (q - ip, fwd, back) travel in one word, the distance in another
+        const uint32_t packed = (uint32_t)__shfl((int)(idx | (fwd << 8) | (back << 16)), (int)bl);
         const uint32_t boff = (uint32_t)__shfl((int)off, (int)bl);
-        uint32_t bfwd = (uint32_t)__shfl((int)fwd, (int)bl);
-        const uint32_t bback = (uint32_t)__shfl((int)back, (int)bl);
+        const uint32_t bq = ip + (packed & 0xFFu);
+        uint32_t bfwd = (packed >> 8) & 0xFFu;
+        const uint32_t bback = packed >> 16;
         const bool took = run && best != 0;
         // ---- long match: the walker's 8 lanes extend it, 128 bytes per round (LDS) ----
         bool need = took && bfwd == ZS_LCAP && (end - bq) > ZS_LCAP;
