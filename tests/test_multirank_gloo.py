@@ -53,6 +53,58 @@ def test_two_ranks_gloo():
     assert res == (True, True, True)
 
 
+def _worker_io(rank, world, port, q):
+    """scatter from rank 0 -> per-shard codec call (oracle, CPU) -> gather to rank 0: the §8e data path end to end"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch, torch.distributed as dist
+    import _oracle as O, _data as D
+    from zstandard_amd.sharding import scatter_chunks, gather_frames
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(9)
+    sizes = np.concatenate([rng.integers(0, 70000, 21), [0, 131072, 5]]).astype(np.uint32)      # known to every rank
+    total = int(sizes.astype(np.uint64).sum())
+    data = torch.from_numpy(D.zipf_log(total + 16)[:total].copy()) if rank == 0 else None        # only the root has the input
+    shard, (b, e) = scatter_chunks(data, sizes, root=0)
+    loc = sizes[b:e]
+    offs = np.zeros(len(loc), dtype=np.uint64)
+    if len(loc) > 1:
+        offs[1:] = np.cumsum(loc.astype(np.uint64))[:-1]
+    src = shard.numpy() if shard.numel() else np.zeros(1, dtype=np.uint8)
+    if len(loc):
+        arena, do, dsz = O.compress_batch(src, offs, loc, 3, 1)
+        packed = np.concatenate([arena[int(do[i]):int(do[i]) + int(dsz[i])] for i in range(len(loc))])
+    else:
+        dsz = np.zeros(0, dtype=np.uint32); packed = np.zeros(0, dtype=np.uint8)
+    out, goffs, gsizes = gather_frames(torch.from_numpy(packed.copy()), dsz, sizes, root=0)
+    dist.barrier()
+    if rank == 0:
+        full = data.numpy(); pos = 0; ok = len(gsizes) == len(sizes)
+        for i in range(len(sizes)):
+            f = out[int(goffs[i]):int(goffs[i]) + int(gsizes[i])].numpy().tobytes()
+            ok = ok and O.decompress(f, max(int(sizes[i]), 1)) == full[pos:pos + int(sizes[i])].tobytes()
+            pos += int(sizes[i])
+        q.put(ok)
+    else:
+        assert out is None and len(gsizes) == len(sizes)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_scatter_compress_gather_gloo(world):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_io, args=(r, world, port, q)) for r in range(world)]
+    for p in ps:
+        p.start()
+    res = q.get(timeout=180)
+    for p in ps:
+        p.join(timeout=60)
+    assert res is True and all(p.exitcode == 0 for p in ps)
+
+
 def test_partition_properties():
     from zstandard_amd.sharding import partition_chunks
     rng = np.random.default_rng(1)

@@ -142,6 +142,14 @@ class BatchCodec:
         if rc:
             raise RuntimeError(f"zsmi_decompressBatchDevice: error {rc}")
 
+    def pack_device(self, d_frames_ptr, dst_offsets, d_sizes_ptr, n, d_packed_ptr, d_packed_offsets_ptr):
+        """frames sitting at dst_offsets (sizes on the device) -> one contiguous run at d_packed; d_packed_offsets[n + 1] (device, uint64)"""
+        do = np.ascontiguousarray(dst_offsets, dtype=np.uint64)
+        rc = self.L.zsmi_packFramesDevice(self.ctx, ctypes.c_void_p(d_frames_ptr), self._p(do), ctypes.c_void_p(d_sizes_ptr), n,
+                                          ctypes.c_void_p(d_packed_ptr), ctypes.c_void_p(d_packed_offsets_ptr))
+        if rc:
+            raise RuntimeError(f"zsmi_packFramesDevice: error {rc}")
+
     def compress_host(self, src: np.ndarray, src_offsets, src_sizes, level=3):
         """returns (arena uint8, dst_offsets uint64, dst_sizes uint32)"""
         so = np.ascontiguousarray(src_offsets, dtype=np.uint64); ss = np.ascontiguousarray(src_sizes, dtype=np.uint32)
