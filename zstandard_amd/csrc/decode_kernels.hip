@@ -15,6 +15,15 @@
 // literal and match copies by all 64 lanes.
 #include "zsmi_device.h"
 
+// -DZS_DEC_PROFILE: cycles per phase of each item, left in the 64 spare bytes behind its literal scratch
+// (0 literals incl. Huffman table, 1 sequence tables, 2 sequence decoding, 3 sequence execution, 4 checksum, 5 whole item)
+#ifdef ZS_DEC_PROFILE
+#define PROF_T0() uint64_t prof_t_ = __builtin_readcyclecounter()
+#define PROF_ADD(k) do { const uint64_t now_ = __builtin_readcyclecounter(); if (g_prof) g_prof[k] += now_ - prof_t_; prof_t_ = now_; } while (0)
+#else
+#define PROF_T0() do {} while (0)
+#define PROF_ADD(k) do {} while (0)
+#endif
 #define ZE(code) (0u - (uint32_t)(code))
 #define E_GENERIC 1
 #define E_prefix_unknown 10
@@ -44,22 +53,29 @@ __constant__ int16_t d_ML_defaultNorm[53] = { 1,4,3,2,2,2,2,2, 2,1,1,1,1,1,1,1, 
                                              1,1,1,1,1,1,1,1, 1,1,1,1,1,1,-1,-1, -1,-1,-1,-1,-1 };
 __constant__ int16_t d_OF_defaultNorm[29] = { 1,1,1,1,1,1,2,2, 2,1,1,1,1,1,1,1, 1,1,1,1,1,1,1,1, -1,-1,-1,-1,-1 };
 
-struct SeqSym { uint16_t nextState; uint8_t nbAdd; uint8_t nbBits; uint32_t base; };   // ZStdDecompress.cs:132-146
+// one cell of a sequence decoding table (ZStdDecompress.cs:132-146).  The reference keeps baseValue and nbAdditionalBits in
+// the cell; here the cell keeps the symbol (4 bytes instead of 8: the three tables take 5 KiB of LDS, not 10) and the
+// decoder takes base / extra bits of LL and ML codes from two small LDS tables, those of an offset code from the code itself.
+struct SeqSym { uint16_t nextState; uint8_t nbBits; uint8_t sym; };
 struct SeqTab { uint32_t tableLog; SeqSym cells[512]; };
+#define ZS_LITWIN 512u      // bytes of each Huffman stream staged in LDS at a time
+#define ZS_SEQWIN 1024u     // bytes of the sequence bitstream staged in LDS at a time (a tile of 64 sequences reads < 720)
 struct DLds {
     uint16_t huf[4096];                 // byte | nbBits << 8   (HufDecompress.cs:109-113)
     uint32_t hufLog;
     SeqTab LL, ML;
     struct { uint32_t tableLog; SeqSym cells[256]; } OF;
-    uint8_t weights[256];
-    uint16_t symStart[256];
-    uint32_t rank[16];
-    int16_t norm[64];
-    uint16_t symbolNext[64];
-    uint32_t tileLL[64], tileML[64], tileOff[64];
+    union {                             // one phase at a time
+        struct { uint8_t weights[256]; uint16_t symStart[256]; uint32_t rank[16]; int16_t norm[64]; uint16_t symbolNext[64];
+                 struct { uint16_t newState; uint8_t symbol; uint8_t nbBits; } wfse[64];   // weight FSE table (tableLog <= 6)
+               } tb;                                                                        // a table is being parsed / built
+        uint32_t litWin[4][(ZS_LITWIN + 8) / 4 + 2];                                        // the Huffman streams run
+        struct { uint32_t tileLL[64], tileML[64], tileOff[64]; uint32_t win[(ZS_SEQWIN + 8) / 4 + 2]; } sq;   // sequences run
+    } u;
     uint32_t misc[16];
-    struct { uint16_t newState; uint8_t symbol; uint8_t nbBits; } wfse[64];   // weight FSE table (tableLog <= 6)
+    uint32_t llTab[36], mlTab[53];      // base | extra bits << 24 of each LL / ML code (LL_base, LL_bits, ML_base, ML_bits)
 };
+__device__ __forceinline__ uint32_t ofBaseOf(uint32_t sym) { return sym == 0 ? 0u : (sym == 1 ? 1u : ((1u << sym) - 3u)); }   // OF_base :1088
 
 __device__ __forceinline__ uint32_t rd16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
 __device__ __forceinline__ uint32_t rd24(const uint8_t *p) { return rd16(p) | ((uint32_t)p[2] << 16); }
@@ -160,25 +176,23 @@ __device__ static void buildSeqTable(SeqSym *cells, uint32_t *tableLogOut, uint1
     uint32_t highThreshold = tableSize - 1, position = 0;
     *tableLogOut = tableLog;
     for (uint32_t s = 0; s <= maxSym; s++) {
-        if (norm[s] == -1) { cells[highThreshold--].base = s; symbolNext[s] = 1; }
+        if (norm[s] == -1) { cells[highThreshold--].sym = (uint8_t)s; symbolNext[s] = 1; }
         else symbolNext[s] = (uint16_t)norm[s];
     }
     for (uint32_t s = 0; s <= maxSym; s++)
         for (int i = 0; i < norm[s]; i++) {
-            cells[position].base = s;
+            cells[position].sym = (uint8_t)s;
             position = (position + step) & tableMask;
             while (position > highThreshold) position = (position + step) & tableMask;
         }
     for (uint32_t u = 0; u < tableSize; u++) {
-        const uint32_t symbol = cells[u].base;
+        const uint32_t symbol = cells[u].sym;
         const uint32_t nextState = symbolNext[symbol]++;
         const uint32_t nb = tableLog - zs_highbit(nextState);
         cells[u].nbBits = (uint8_t)nb;
         cells[u].nextState = (uint16_t)((nextState << nb) - tableSize);
-        if (kind == 1) { cells[u].nbAdd = (uint8_t)symbol; cells[u].base = symbol == 0 ? 0 : (symbol == 1 ? 1 : (symbol == 2 ? 1 : ((1u << symbol) - 3))); }
-        else if (kind == 0) { cells[u].nbAdd = d_LL_bits[symbol]; cells[u].base = d_LL_base[symbol]; }
-        else { cells[u].nbAdd = d_ML_bits[symbol]; cells[u].base = d_ML_base[symbol]; }
     }
+    (void)kind;
 }
 
 // ---- ReadStats + table fill (EntropyCommon.cs:198-269, HufDecompress.cs:117-180) ----
@@ -195,27 +209,27 @@ __device__ static uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t sr
                 oSize = iSize - 127; iSize = (oSize + 1) / 2;
                 if (iSize + 1 > srcSize) { result = ZE(E_srcSize_wrong); break; }
                 if (oSize >= 256) { result = ZE(E_corruption_detected); break; }
-                for (uint32_t n = 0; n < oSize; n += 2) { L.weights[n] = src[1 + n / 2] >> 4; L.weights[n + 1] = src[1 + n / 2] & 15; }
+                for (uint32_t n = 0; n < oSize; n += 2) { L.u.tb.weights[n] = src[1 + n / 2] >> 4; L.u.tb.weights[n + 1] = src[1 + n / 2] & 15; }
             } else {
                 // FSE-compressed weights (FseDecompress.cs:233-332), table log <= 6
                 if (iSize + 1 > srcSize) { result = ZE(E_srcSize_wrong); break; }
                 uint32_t tableLog, maxSV = 63;
-                const uint32_t nc = readNCount(L.norm, &maxSV, &tableLog, src + 1, iSize);
+                const uint32_t nc = readNCount(L.u.tb.norm, &maxSV, &tableLog, src + 1, iSize);
                 if (isErr(nc)) { result = nc; break; }
                 if (tableLog > 6 || maxSV > 63) { result = ZE(E_tableLog_tooLarge); break; }
                 {   // FseDecompress.cs:111-181
                     const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
                     uint32_t highThreshold = tableSize - 1, position = 0;
                     for (uint32_t s = 0; s <= maxSV; s++) {
-                        if (L.norm[s] == -1) { L.wfse[highThreshold--].symbol = (uint8_t)s; L.symbolNext[s] = 1; } else L.symbolNext[s] = (uint16_t)L.norm[s];
+                        if (L.u.tb.norm[s] == -1) { L.u.tb.wfse[highThreshold--].symbol = (uint8_t)s; L.u.tb.symbolNext[s] = 1; } else L.u.tb.symbolNext[s] = (uint16_t)L.u.tb.norm[s];
                     }
                     for (uint32_t s = 0; s <= maxSV; s++)
-                        for (int i = 0; i < L.norm[s]; i++) { L.wfse[position].symbol = (uint8_t)s; position = (position + step) & tableMask; while (position > highThreshold) position = (position + step) & tableMask; }
+                        for (int i = 0; i < L.u.tb.norm[s]; i++) { L.u.tb.wfse[position].symbol = (uint8_t)s; position = (position + step) & tableMask; while (position > highThreshold) position = (position + step) & tableMask; }
                     if (position != 0) { result = ZE(E_GENERIC); break; }
                     for (uint32_t u = 0; u < tableSize; u++) {
-                        const uint32_t sy = L.wfse[u].symbol; const uint32_t ns = L.symbolNext[sy]++;
-                        L.wfse[u].nbBits = (uint8_t)(tableLog - zs_highbit(ns));
-                        L.wfse[u].newState = (uint16_t)((ns << L.wfse[u].nbBits) - tableSize);
+                        const uint32_t sy = L.u.tb.wfse[u].symbol; const uint32_t ns = L.u.tb.symbolNext[sy]++;
+                        L.u.tb.wfse[u].nbBits = (uint8_t)(tableLog - zs_highbit(ns));
+                        L.u.tb.wfse[u].newState = (uint16_t)((ns << L.u.tb.wfse[u].nbBits) - tableSize);
                     }
                 }
                 {   // two interleaved states, FseDecompress.cs:233-295
@@ -225,19 +239,19 @@ __device__ static uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t sr
                     uint32_t op = 0; bool bad = false;
                     for (;;) {
                         if (op > 253) { bad = true; break; }
-                        L.weights[op++] = L.wfse[s1].symbol; { const uint32_t nb = L.wfse[s1].nbBits; s1 = L.wfse[s1].newState + br_read(b, nb); }
-                        if (b.bitPos < 0) { L.weights[op++] = L.wfse[s2].symbol; break; }
+                        L.u.tb.weights[op++] = L.u.tb.wfse[s1].symbol; { const uint32_t nb = L.u.tb.wfse[s1].nbBits; s1 = L.u.tb.wfse[s1].newState + br_read(b, nb); }
+                        if (b.bitPos < 0) { L.u.tb.weights[op++] = L.u.tb.wfse[s2].symbol; break; }
                         if (op > 253) { bad = true; break; }
-                        L.weights[op++] = L.wfse[s2].symbol; { const uint32_t nb = L.wfse[s2].nbBits; s2 = L.wfse[s2].newState + br_read(b, nb); }
-                        if (b.bitPos < 0) { L.weights[op++] = L.wfse[s1].symbol; break; }
+                        L.u.tb.weights[op++] = L.u.tb.wfse[s2].symbol; { const uint32_t nb = L.u.tb.wfse[s2].nbBits; s2 = L.u.tb.wfse[s2].newState + br_read(b, nb); }
+                        if (b.bitPos < 0) { L.u.tb.weights[op++] = L.u.tb.wfse[s1].symbol; break; }
                     }
                     if (bad) { result = ZE(E_corruption_detected); break; }
                     oSize = op;
                 }
             }
-            for (int i = 0; i < 13; i++) L.rank[i] = 0;
+            for (int i = 0; i < 13; i++) L.u.tb.rank[i] = 0;
             uint32_t weightTotal = 0; bool bad = false;
-            for (uint32_t n = 0; n < oSize; n++) { if (L.weights[n] >= 12) { bad = true; break; } L.rank[L.weights[n]]++; weightTotal += (1u << L.weights[n]) >> 1; }
+            for (uint32_t n = 0; n < oSize; n++) { if (L.u.tb.weights[n] >= 12) { bad = true; break; } L.u.tb.rank[L.u.tb.weights[n]]++; weightTotal += (1u << L.u.tb.weights[n]) >> 1; }
             if (bad || weightTotal == 0) { result = ZE(E_corruption_detected); break; }
             const uint32_t tableLog = zs_highbit(weightTotal) + 1;
             if (tableLog > 12) { result = ZE(E_corruption_detected); break; }
@@ -245,11 +259,11 @@ __device__ static uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t sr
                 const uint32_t total = 1u << tableLog, rest = total - weightTotal;
                 const uint32_t verif = 1u << zs_highbit(rest), lastWeight = zs_highbit(rest) + 1;
                 if (verif != rest) { result = ZE(E_corruption_detected); break; }
-                L.weights[oSize] = (uint8_t)lastWeight; L.rank[lastWeight]++;
+                L.u.tb.weights[oSize] = (uint8_t)lastWeight; L.u.tb.rank[lastWeight]++;
             }
-            if ((L.rank[1] < 2) || (L.rank[1] & 1)) { result = ZE(E_corruption_detected); break; }
+            if ((L.u.tb.rank[1] < 2) || (L.u.tb.rank[1] & 1)) { result = ZE(E_corruption_detected); break; }
             L.hufLog = tableLog;
-            { uint32_t next = 0; for (uint32_t n = 1; n < tableLog + 1; n++) { const uint32_t cur = next; next += L.rank[n] << (n - 1); L.rank[n] = cur; } }
+            { uint32_t next = 0; for (uint32_t n = 1; n < tableLog + 1; n++) { const uint32_t cur = next; next += L.u.tb.rank[n] << (n - 1); L.u.tb.rank[n] = cur; } }
             L.misc[1] = oSize + 1;
             result = iSize + 1;
         } while (0);
@@ -259,12 +273,12 @@ __device__ static uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t sr
     const uint32_t res = L.misc[0];
     if (isErr(res)) return res;
     const uint32_t nbSymbols = L.misc[1], tableLog = L.hufLog;
-    if (lane == 0) for (uint32_t n = 0; n < nbSymbols; n++) { const uint32_t w = L.weights[n]; L.symStart[n] = (uint16_t)L.rank[w]; if (w) L.rank[w] += (1u << w) >> 1; }
+    if (lane == 0) for (uint32_t n = 0; n < nbSymbols; n++) { const uint32_t w = L.u.tb.weights[n]; L.u.tb.symStart[n] = (uint16_t)L.u.tb.rank[w]; if (w) L.u.tb.rank[w] += (1u << w) >> 1; }
     __syncthreads();
     for (uint32_t n = 0; n < nbSymbols; n++) {            // uniform loop; lanes fill one symbol's cells together
-        const uint32_t w = L.weights[n];
+        const uint32_t w = L.u.tb.weights[n];
         if (!w) continue;
-        const uint32_t length = (1u << w) >> 1, startAt = L.symStart[n];
+        const uint32_t length = (1u << w) >> 1, startAt = L.u.tb.symStart[n];
         const uint16_t e = (uint16_t)(n | ((tableLog + 1 - w) << 8));
         for (uint32_t u = lane; u < length; u += 64) L.huf[startAt + u] = e;
     }
@@ -272,18 +286,95 @@ __device__ static uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t sr
     return res;
 }
 
-// one Huffman stream, run by a single lane (HufDecompress.cs:222-264)
-__device__ static bool hufDecodeStream(const DLds &L, uint8_t *out, uint32_t n, const uint8_t *src, uint32_t size)
+// ---- stream windows in LDS.  The serial decoders (Huffman: one lane per stream; sequences: lane 0) read their backward
+//      bitstreams from LDS: a global load inside such a dependent chain costs a full memory round trip per ~64 bits
+//      (and on gfx9 a wait for it also waits for the stores in flight).  All 64 lanes stage the bytes. ----
+// win[] <- stream bytes [base - 8, base + W); bytes outside [0, size) read as 0 (bits below the stream start are 0, BitStream.cs:412)
+__device__ static void stageWindow(uint32_t *win, const uint8_t *src, uint32_t size, int64_t base, uint32_t W)
 {
-    BitR b; br_init(b, src, size);
-    if (b.err) return false;
-    const uint32_t dtLog = L.hufLog;
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t e = L.huf[br_look(b, dtLog)];
-        out[i] = (uint8_t)e;
-        b.bitPos -= (e >> 8);
+    const uint32_t lane = (uint32_t)zs_lane();
+    for (uint32_t j = lane; j < (W + 8) / 4 + 2; j += 64) {
+        const int64_t p = base - 8 + 4 * (int64_t)j;
+        uint32_t v = 0;
+        if (p >= 0 && p + 4 <= (int64_t)size) v = zs_load32(src + p);
+        else for (int k = 0; k < 4; k++) { const int64_t q = p + k; if (q >= 0 && q < (int64_t)size) v |= (uint32_t)src[q] << (8 * k); }
+        win[j] = v;
     }
-    return b.bitPos == 0;          // EndOfDStream (BitStream.cs:494): every bit consumed, none over-read
+}
+__device__ __forceinline__ uint64_t wave_get64(uint64_t v, int l) { return (uint64_t)wave_get((uint32_t)v, l) | ((uint64_t)wave_get((uint32_t)(v >> 32), l) << 32); }
+// 8 window bytes from byte offset o (aligned dword reads, shifted into place)
+__device__ __forceinline__ uint64_t win64(const uint32_t *win, uint32_t o)
+{
+    const uint32_t *d = win + (o >> 2);
+    const uint32_t w0 = d[0], w1 = d[1], w2 = d[2], sh = o & 3u;
+    return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32);
+}
+// the bit container of a serial decoder: c holds the next bits at its top, avail of them are valid, bitPos = unread bits
+struct BitC { uint64_t c; uint32_t avail; int64_t bitPos; };
+__device__ __forceinline__ void bc_refill(BitC &b, const uint32_t *win, int64_t base)
+{
+    if (b.bitPos <= 0) { b.c = 0; b.avail = 64; return; }               // past the start: zeros (the caller rejects the stream)
+    const int64_t bh = (b.bitPos - 1) >> 3;                             // byte holding the next bit
+    const uint64_t raw = win64(win, (uint32_t)(bh - base + 1));         // stream bytes [bh - 7, bh]
+    const uint32_t sh = 7u - (uint32_t)((b.bitPos - 1) & 7);
+    b.c = raw << sh; b.avail = 64 - sh;
+}
+__device__ __forceinline__ bool bc_init(BitC &b, const uint8_t *src, uint32_t size)   // BitStream.cs:322-378
+{
+    b.c = 0; b.avail = 0; b.bitPos = 0;
+    if (size == 0) return false;
+    const uint32_t last = src[size - 1];
+    if (last == 0) return false;
+    b.bitPos = (int64_t)size * 8 - (int64_t)(8 - zs_highbit(last));    // bits below the end mark
+    return true;
+}
+__device__ __forceinline__ int64_t bc_windowBase(const BitC &b, uint32_t W)
+{
+    const int64_t bh = (b.bitPos > 0) ? ((b.bitPos - 1) >> 3) : 0;
+    return (bh + 1 > (int64_t)W) ? bh + 1 - (int64_t)W : 0;
+}
+
+// the Huffman streams of one block (HufDecompress.cs:222-358): stream k on lane k (nStreams = 1 or 4), in rounds of
+// "stage ZS_LITWIN bytes of every stream, decode until a stream needs more".  8 decoded bytes go out per store.
+__device__ static bool hufDecodeStreams(DLds &L, uint32_t nStreams, uint8_t *out, uint32_t n, const uint8_t *src, uint32_t size)
+{
+    const uint32_t lane = (uint32_t)zs_lane();
+    const bool mine = lane < nStreams;
+    BitC b; b.c = 0; b.avail = 0; b.bitPos = 0;
+    const bool okInit = !mine || bc_init(b, src, size);
+    if (__ballot(!okInit)) return false;
+    const uint32_t dtLog = L.hufLog;
+    uint32_t i = 0, nacc = 0; uint64_t acc = 0;
+    bool done = !mine || n == 0;
+    for (;;) {
+        const int64_t base = bc_windowBase(b, ZS_LITWIN);
+        for (uint32_t k = 0; k < nStreams; k++) {
+            const uint64_t sp = (uint64_t)wave_get((uint32_t)(uintptr_t)src, (int)k) | ((uint64_t)wave_get((uint32_t)((uintptr_t)src >> 32), (int)k) << 32);
+            const int64_t bs = (int64_t)((uint64_t)wave_get((uint32_t)base, (int)k) | ((uint64_t)wave_get((uint32_t)((uint64_t)base >> 32), (int)k) << 32));
+            stageWindow(L.u.litWin[k], reinterpret_cast<const uint8_t *>(sp), wave_get(size, (int)k), bs, ZS_LITWIN);
+        }
+        wave_sync();
+        if (!done) {
+            const uint32_t *win = L.u.litWin[lane];
+            while (i < n) {
+                if (b.avail < dtLog) {
+                    if (b.bitPos > 0 && base > 0 && ((b.bitPos - 1) >> 3) < base + 8) break;      // window used up: next round
+                    bc_refill(b, win, base);
+                }
+                const uint32_t e = L.huf[(uint32_t)(b.c >> (64 - dtLog))];
+                const uint32_t nb = e >> 8;
+                b.c <<= nb; b.avail -= nb; b.bitPos -= nb;
+                acc |= (uint64_t)(e & 0xFFu) << (8 * nacc);
+                i++;
+                if (++nacc == 8) { __builtin_memcpy(out + i - 8, &acc, 8); acc = 0; nacc = 0; }
+            }
+            if (i == n) done = true;
+        }
+        wave_sync();
+        if (!__ballot(!done)) break;
+    }
+    for (uint32_t k = 0; k < nacc; k++) out[i - nacc + k] = (uint8_t)(acc >> (8 * k));
+    return !__ballot(mine && b.bitPos != 0);          // EndOfDStream (BitStream.cs:494): every bit consumed, none over-read
 }
 
 // XXH64 seed 0 (XxHash.cs:896-1161), single lane
@@ -315,9 +406,10 @@ __device__ static uint64_t xxh64(const uint8_t *p, uint64_t len)
 struct DState { uint32_t rep[3]; uint32_t litEntropy, fseEntropy; uint32_t llRepeatOk; };
 
 __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, uint64_t frameStart, uint64_t op, uint64_t oend,
-                                       const uint8_t *src, uint32_t srcSize, uint8_t *litBuf, uint64_t windowSize)
+                                       const uint8_t *src, uint32_t srcSize, uint8_t *litBuf, uint64_t windowSize, uint64_t *g_prof)
 {
     const uint32_t lane = (uint32_t)zs_lane();
+    PROF_T0(); (void)g_prof;
     if (srcSize >= (1u << 17)) return ZE(E_srcSize_wrong);
     if (srcSize < 3) return ZE(E_corruption_detected);
     // ---- literals (DecodeLiteralsBlock :683-821) ----
@@ -339,13 +431,16 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                 if (!single && litSize == 0) return ZE(E_corruption_detected);
                 if (!single && litCSize == 0) return ZE(E_corruption_detected);
                 const uint32_t h = readHufTable(L, cs, csz);
+#ifdef ZS_DEC_PROFILE
+                { const uint64_t now_ = __builtin_readcyclecounter(); if (g_prof) g_prof[6] += now_ - prof_t_; }
+#endif
                 if (isErr(h)) return ZE(E_corruption_detected);
                 if (h >= csz) return ZE(E_corruption_detected);
                 cs += h; csz -= h;
             }
             bool ok = true;
             if (single) {
-                if (lane == 0) ok = hufDecodeStream(L, litBuf, litSize, cs, csz);
+                ok = hufDecodeStreams(L, 1, litBuf, litSize, cs, csz);
             } else {
                 if (csz < 10) return ZE(E_corruption_detected);
                 const uint32_t l1 = rd16(cs), l2 = rd16(cs + 2), l3 = rd16(cs + 4);
@@ -353,12 +448,11 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                 const uint32_t l4 = csz - (l1 + l2 + l3 + 6);
                 const uint32_t seg = (litSize + 3) / 4;
                 if (3 * seg > litSize) return ZE(E_corruption_detected);
-                if (lane < 4) {
-                    const uint32_t off = 6 + (lane > 0 ? l1 : 0) + (lane > 1 ? l2 : 0) + (lane > 2 ? l3 : 0);
-                    const uint32_t len = lane == 0 ? l1 : (lane == 1 ? l2 : (lane == 2 ? l3 : l4));
-                    const uint32_t cnt = lane < 3 ? seg : litSize - 3 * seg;
-                    ok = hufDecodeStream(L, litBuf + lane * seg, cnt, cs + off, len);
-                }
+                const uint32_t sl = min(lane, 3u);
+                const uint32_t off = 6 + (sl > 0 ? l1 : 0) + (sl > 1 ? l2 : 0) + (sl > 2 ? l3 : 0);
+                const uint32_t len = sl == 0 ? l1 : (sl == 1 ? l2 : (sl == 2 ? l3 : l4));
+                const uint32_t cnt = sl < 3 ? seg : litSize - 3 * seg;
+                ok = hufDecodeStreams(L, 4, litBuf + sl * seg, cnt, cs + off, len);
             }
             if (__ballot(!ok)) return ZE(E_corruption_detected);
             __syncthreads();
@@ -381,6 +475,7 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
             }
         }
     }
+    PROF_ADD(0);
     const uint8_t *ip = src + litCSizeTot;
     uint32_t remaining = srcSize - litCSizeTot;
     // ---- sequence headers (DecodeSeqHeaders :1110-1180) ----
@@ -408,24 +503,21 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                         if (!left) { err = ZE(E_srcSize_wrong); break; }
                         const uint32_t symbol = *p;
                         if (symbol > maxS) { err = ZE(E_corruption_detected); break; }
-                        *tl = 0; cells[0].nbBits = 0; cells[0].nextState = 0;
-                        if (t == 1) { cells[0].nbAdd = (uint8_t)symbol; cells[0].base = symbol == 0 ? 0 : (symbol <= 2 ? 1 : ((1u << symbol) - 3)); }
-                        else if (t == 0) { cells[0].nbAdd = d_LL_bits[symbol]; cells[0].base = d_LL_base[symbol]; }
-                        else { cells[0].nbAdd = d_ML_bits[symbol]; cells[0].base = d_ML_base[symbol]; }
+                        *tl = 0; cells[0].nbBits = 0; cells[0].nextState = 0; cells[0].sym = (uint8_t)symbol;
                         p += 1;
                     } else if (type == 0) {
                         const int16_t *dn = t == 0 ? d_LL_defaultNorm : (t == 1 ? d_OF_defaultNorm : d_ML_defaultNorm);
                         const uint32_t dmax = t == 0 ? 35 : (t == 1 ? 28 : 52);
-                        for (uint32_t i = 0; i <= dmax; i++) L.norm[i] = dn[i];
-                        buildSeqTable(cells, tl, L.symbolNext, L.norm, dmax, t == 1 ? 5 : 6, t);
+                        for (uint32_t i = 0; i <= dmax; i++) L.u.tb.norm[i] = dn[i];
+                        buildSeqTable(cells, tl, L.u.tb.symbolNext, L.u.tb.norm, dmax, t == 1 ? 5 : 6, t);
                     } else if (type == 3) {
                         if (!st.fseEntropy) { err = ZE(E_corruption_detected); break; }
                     } else {
                         uint32_t tableLog, max = maxS;
-                        const uint32_t h = readNCount(L.norm, &max, &tableLog, p, left);
+                        const uint32_t h = readNCount(L.u.tb.norm, &max, &tableLog, p, left);
                         if (isErr(h)) { err = ZE(E_corruption_detected); break; }
                         if (tableLog > maxLog) { err = ZE(E_corruption_detected); break; }
-                        buildSeqTable(cells, tl, L.symbolNext, L.norm, max, tableLog, t);
+                        buildSeqTable(cells, tl, L.u.tb.symbolNext, L.u.tb.norm, max, tableLog, t);
                         p += h;
                     }
                 }
@@ -437,34 +529,48 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
             remaining = (uint32_t)(iend - ip);
         }
     }
+    PROF_ADD(1);
     // ---- sequences (decompressSequences_body :1555-1608) ----
     const uint64_t ostart = op;
     uint32_t litPos = 0;
     if (nbSeq) {
         st.fseEntropy = 1;
-        const bool longOff = windowSize > (1ull << 25);
-        BitR b; uint32_t sLL = 0, sOF = 0, sML = 0;
+        // the bitstream is read by lane 0 from an LDS window (stageWindow); one tile of 64 sequences reads < 720 bytes of it
+        BitC b; b.c = 0; b.avail = 0; b.bitPos = 0;
+        uint32_t sLL = 0, sOF = 0, sML = 0;
         uint32_t rep0 = st.rep[0], rep1 = st.rep[1], rep2 = st.rep[2];
-        if (lane == 0) {
-            br_init(b, ip, remaining);
-            if (!b.err) { sLL = br_read(b, L.LL.tableLog); sOF = br_read(b, L.OF.tableLog); sML = br_read(b, L.ML.tableLog); }
-            L.misc[0] = b.err;
-        }
+        if (!bc_init(b, ip, remaining)) return ZE(E_corruption_detected);             // same bytes for every lane: uniform
+        int64_t base = bc_windowBase(b, ZS_SEQWIN);
+        stageWindow(L.u.sq.win, ip, remaining, base, ZS_SEQWIN);
         __syncthreads();
-        if (L.misc[0]) return ZE(E_corruption_detected);
-        (void)longOff;
+        #define SEQ_RD(dst, nbits) do { const uint32_t nb_ = (nbits); uint32_t v_ = 0; \
+                if (nb_) { if (b.avail < nb_) bc_refill(b, L.u.sq.win, base); v_ = (uint32_t)(b.c >> (64 - nb_)); b.c <<= nb_; b.avail -= nb_; b.bitPos -= nb_; } \
+                (dst) = v_; } while (0)
+        if (lane == 0) { SEQ_RD(sLL, L.LL.tableLog); SEQ_RD(sOF, L.OF.tableLog); SEQ_RD(sML, L.ML.tableLog); }
         uint32_t left = nbSeq;
         while (left) {
             const uint32_t T = min(64u, left);
+            {   // keep a tile's worth of stream below the cursor inside the window
+                const int64_t bp0 = (int64_t)((uint64_t)wave_get((uint32_t)b.bitPos, 0) | ((uint64_t)wave_get((uint32_t)((uint64_t)b.bitPos >> 32), 0) << 32));
+                const int64_t bh = (bp0 > 0) ? ((bp0 - 1) >> 3) : 0;
+                if (base > 0 && bh < base + 736) {
+                    __syncthreads();
+                    base = (bh + 1 > (int64_t)ZS_SEQWIN) ? bh + 1 - (int64_t)ZS_SEQWIN : 0;
+                    stageWindow(L.u.sq.win, ip, remaining, base, ZS_SEQWIN);
+                    __syncthreads();
+                }
+            }
             if (lane == 0) {
                 uint32_t bad = 0;
                 for (uint32_t t = 0; t < T; t++) {
                     if (b.bitPos < 0) { bad = 1; break; }            // stream exhausted before all sequences (:1582, :1594)
                     const SeqSym eLL = L.LL.cells[sLL], eOF = L.OF.cells[sOF], eML = L.ML.cells[sML];
-                    uint32_t offset;
-                    if (eOF.nbAdd == 0) offset = 0; else offset = eOF.base + br_read(b, eOF.nbAdd);
-                    if (eOF.nbAdd <= 1) {
-                        offset += (eLL.base == 0);
+                    const uint32_t tLL = L.llTab[eLL.sym], tML = L.mlTab[eML.sym];
+                    const uint32_t llBase = tLL & 0xFFFFFFu, llAdd = tLL >> 24, mlBase = tML & 0xFFFFFFu, mlAdd = tML >> 24, ofAdd = eOF.sym;
+                    uint32_t offset, x;
+                    if (ofAdd == 0) offset = 0; else { SEQ_RD(x, ofAdd); offset = ofBaseOf(ofAdd) + x; }
+                    if (ofAdd <= 1) {
+                        offset += (llBase == 0);
                         if (offset) {
                             uint32_t temp = (offset == 3) ? rep0 - 1 : (offset == 1 ? rep1 : rep2);
                             temp += !temp;
@@ -472,26 +578,25 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                             rep1 = rep0; rep0 = offset = temp;
                         } else offset = rep0;
                     } else { rep2 = rep1; rep1 = rep0; rep0 = offset; }
-                    const uint32_t ml = eML.base + (eML.nbAdd ? br_read(b, eML.nbAdd) : 0);
-                    const uint32_t ll = eLL.base + (eLL.nbAdd ? br_read(b, eLL.nbAdd) : 0);
-                    sLL = eLL.nextState + br_read(b, eLL.nbBits);
-                    sML = eML.nextState + br_read(b, eML.nbBits);
-                    sOF = eOF.nextState + br_read(b, eOF.nbBits);
-                    L.tileLL[t] = ll; L.tileML[t] = ml; L.tileOff[t] = offset;
+                    SEQ_RD(x, mlAdd); const uint32_t ml = mlBase + x;
+                    SEQ_RD(x, llAdd); const uint32_t ll = llBase + x;
+                    SEQ_RD(x, eLL.nbBits); sLL = eLL.nextState + x;
+                    SEQ_RD(x, eML.nbBits); sML = eML.nextState + x;
+                    SEQ_RD(x, eOF.nbBits); sOF = eOF.nextState + x;
+                    L.u.sq.tileLL[t] = ll; L.u.sq.tileML[t] = ml; L.u.sq.tileOff[t] = offset;
                 }
                 L.misc[0] = bad;
             }
             __syncthreads();
+            PROF_ADD(2);
             if (L.misc[0]) return ZE(E_corruption_detected);
             // execute the tile (ExecSequence :1265-1352).  Lane t owns sequence t: output positions by prefix sums, the checks
             // of the reference in its order (the first failing sequence decides), then all literal runs at once, then all
             // matches whose source lies before this tile's output at once, then the matches that read this tile's own output
             // one after the other.
             {
-                const uint32_t ll = (lane < T) ? L.tileLL[lane] : 0u, ml = (lane < T) ? L.tileML[lane] : 0u, off = (lane < T) ? L.tileOff[lane] : 0u;
-                uint32_t incl = ll + ml, inclL = ll;
-                #pragma unroll
-                for (int d = 1; d < 64; d <<= 1) { const uint32_t a = (uint32_t)__shfl_up((int)incl, d), c = (uint32_t)__shfl_up((int)inclL, d); if ((int)lane >= d) { incl += a; inclL += c; } }
+                const uint32_t ll = (lane < T) ? L.u.sq.tileLL[lane] : 0u, ml = (lane < T) ? L.u.sq.tileML[lane] : 0u, off = (lane < T) ? L.u.sq.tileOff[lane] : 0u;
+                const uint32_t incl = wave_incl_scan(ll + ml), inclL = wave_incl_scan(ll);
                 const uint64_t outStart = op + (incl - ll - ml);              // where my literals go
                 const uint32_t litStart = litPos + (inclL - ll);
                 const uint64_t mdst = outStart + ll;                          // where my match goes
@@ -502,7 +607,7 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                     else if (off > mdst - frameStart) err = E_corruption_detected;
                 }
                 const uint64_t em = __ballot(err != 0);
-                if (em) return ZE((uint32_t)__shfl((int)err, __builtin_ctzll(em)));
+                if (em) return ZE(wave_get(err, __builtin_ctzll(em)));
                 const uint64_t tileStart = op;
                 // literals
                 if (ll && ll <= 16) {
@@ -513,8 +618,8 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                 }
                 for (uint64_t lm = __ballot(ll > 16); lm; lm &= lm - 1) {
                     const int t = __builtin_ctzll(lm);
-                    const uint32_t l2 = (uint32_t)__shfl((int)ll, t), s2 = (uint32_t)__shfl((int)litStart, t);
-                    const uint64_t d2 = (uint64_t)__shfl((long long)outStart, t);
+                    const uint32_t l2 = wave_get(ll, t), s2 = wave_get(litStart, t);
+                    const uint64_t d2 = wave_get64(outStart, t);
                     for (uint32_t j = lane; j < l2; j += 64) dstBase[d2 + j] = litPtr[s2 + j];
                 }
                 __syncthreads();
@@ -528,26 +633,28 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                 }
                 for (uint64_t lm = __ballot(indep && ml > 32); lm; lm &= lm - 1) {
                     const int t = __builtin_ctzll(lm);
-                    const uint32_t m2 = (uint32_t)__shfl((int)ml, t);
-                    const uint64_t s2 = (uint64_t)__shfl((long long)msrc, t), d2 = (uint64_t)__shfl((long long)mdst, t);
+                    const uint32_t m2 = wave_get(ml, t);
+                    const uint64_t s2 = wave_get64(msrc, t), d2 = wave_get64(mdst, t);
                     for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j];
                 }
                 __syncthreads();
                 // matches reading this tile's own output (earlier sequences are complete by then), in order
                 for (uint64_t dm = __ballot(ml && !indep); dm; dm &= dm - 1) {
                     const int t = __builtin_ctzll(dm);
-                    const uint32_t m2 = (uint32_t)__shfl((int)ml, t), o2 = (uint32_t)__shfl((int)off, t);
-                    const uint64_t s2 = (uint64_t)__shfl((long long)msrc, t), d2 = (uint64_t)__shfl((long long)mdst, t);
+                    const uint32_t m2 = wave_get(ml, t), o2 = wave_get(off, t);
+                    const uint64_t s2 = wave_get64(msrc, t), d2 = wave_get64(mdst, t);
                     if (o2 >= m2) { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j]; }
                     else { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + (j % o2)]; }      // period = offset
                     __syncthreads();
                 }
-                op += (uint32_t)__shfl((int)incl, 63);
-                litPos += (uint32_t)__shfl((int)inclL, 63);
+                op += wave_last(incl);
+                litPos += wave_last(inclL);
             }
+            PROF_ADD(3);
             left -= T;
         }
-        st.rep[0] = (uint32_t)__shfl((int)rep0, 0); st.rep[1] = (uint32_t)__shfl((int)rep1, 0); st.rep[2] = (uint32_t)__shfl((int)rep2, 0);
+        #undef SEQ_RD
+        st.rep[0] = wave_get(rep0, 0); st.rep[1] = wave_get(rep1, 0); st.rep[2] = wave_get(rep2, 0);
     }
     {
         const uint32_t lastLL = litSize - litPos;
@@ -569,6 +676,14 @@ k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
     const uint8_t *src = srcAll + it.srcOff;
     uint8_t *dstBase = dstAll + it.dstOff;
     uint8_t *litBuf = litScratchAll + (size_t)blockIdx.x * ((1u << 17) + 64);
+    if (lane < 36) L.llTab[lane] = d_LL_base[lane] | ((uint32_t)d_LL_bits[lane] << 24);
+    if (lane < 53) L.mlTab[lane] = d_ML_base[lane] | ((uint32_t)d_ML_bits[lane] << 24);
+    __syncthreads();
+    uint64_t *g_prof = nullptr;
+#ifdef ZS_DEC_PROFILE
+    if (lane == 0) { g_prof = reinterpret_cast<uint64_t *>(litBuf + (1u << 17)); for (int k = 0; k < 8; k++) g_prof[k] = 0; }
+    const uint64_t prof_start_ = __builtin_readcyclecounter();
+#endif
     uint32_t srcSize = it.srcSize;
     uint64_t ipos = 0, op = 0;
     const uint64_t oend = it.dstCap;
@@ -619,7 +734,7 @@ k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
             if (cBlockSize > srcSize - ipos) DONE(ZE(E_srcSize_wrong));
             uint32_t decoded;
             if (btype == 2) {
-                decoded = decodeBlock(L, st, dstBase, frameStart, op, oend, src + ipos, cBlockSize, litBuf, windowSize);
+                decoded = decodeBlock(L, st, dstBase, frameStart, op, oend, src + ipos, cBlockSize, litBuf, windowSize, g_prof);
                 if (isErr(decoded)) DONE(decoded);
             } else if (btype == 0) {
                 if (cBlockSize > oend - op) DONE(ZE(E_dstSize_tooSmall));
@@ -647,6 +762,9 @@ k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
     if (srcSize != ipos) DONE(ZE(E_srcSize_wrong));
     result = (uint32_t)op;
 finish:
+#ifdef ZS_DEC_PROFILE
+    if (g_prof) g_prof[5] = __builtin_readcyclecounter() - prof_start_;
+#endif
     if (lane == 0) dstSizes[blockIdx.x] = result;
     #undef DONE
 }
