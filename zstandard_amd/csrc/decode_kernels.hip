@@ -290,14 +290,14 @@ __device__ static uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t sr
 //      bitstreams from LDS: a global load inside such a dependent chain costs a full memory round trip per ~64 bits
 //      (and on gfx9 a wait for it also waits for the stores in flight).  All 64 lanes stage the bytes. ----
 // win[] <- stream bytes [base - 8, base + W); bytes outside [0, size) read as 0 (bits below the stream start are 0, BitStream.cs:412)
-__device__ static void stageWindow(uint32_t *win, const uint8_t *src, uint32_t size, int64_t base, uint32_t W)
+__device__ static void stageWindow(uint32_t *win, const uint8_t *src, uint32_t size, int32_t base, uint32_t W)
 {
     const uint32_t lane = (uint32_t)zs_lane();
     for (uint32_t j = lane; j < (W + 8) / 4 + 2; j += 64) {
-        const int64_t p = base - 8 + 4 * (int64_t)j;
+        const int32_t p = base - 8 + 4 * (int32_t)j;
         uint32_t v = 0;
-        if (p >= 0 && p + 4 <= (int64_t)size) v = zs_load32(src + p);
-        else for (int k = 0; k < 4; k++) { const int64_t q = p + k; if (q >= 0 && q < (int64_t)size) v |= (uint32_t)src[q] << (8 * k); }
+        if (p >= 0 && p + 4 <= (int32_t)size) v = zs_load32(src + p);
+        else for (int k = 0; k < 4; k++) { const int32_t q = p + k; if (q >= 0 && q < (int32_t)size) v |= (uint32_t)src[q] << (8 * k); }
         win[j] = v;
     }
 }
@@ -310,11 +310,11 @@ __device__ __forceinline__ uint64_t win64(const uint32_t *win, uint32_t o)
     return (uint64_t)__builtin_amdgcn_alignbyte(w1, w0, sh) | ((uint64_t)__builtin_amdgcn_alignbyte(w2, w1, sh) << 32);
 }
 // the bit container of a serial decoder: c holds the next bits at its top, avail of them are valid, bitPos = unread bits
-struct BitC { uint64_t c; uint32_t avail; int64_t bitPos; };
-__device__ __forceinline__ void bc_refill(BitC &b, const uint32_t *win, int64_t base)
+struct BitC { uint64_t c; uint32_t avail; int32_t bitPos; };      // streams are < 2^28 bytes (a block is < 128 KiB)
+__device__ __forceinline__ void bc_refill(BitC &b, const uint32_t *win, int32_t base)
 {
     if (b.bitPos <= 0) { b.c = 0; b.avail = 64; return; }               // past the start: zeros (the caller rejects the stream)
-    const int64_t bh = (b.bitPos - 1) >> 3;                             // byte holding the next bit
+    const int32_t bh = (b.bitPos - 1) >> 3;                             // byte holding the next bit
     const uint64_t raw = win64(win, (uint32_t)(bh - base + 1));         // stream bytes [bh - 7, bh]
     const uint32_t sh = 7u - (uint32_t)((b.bitPos - 1) & 7);
     b.c = raw << sh; b.avail = 64 - sh;
@@ -325,13 +325,20 @@ __device__ __forceinline__ bool bc_init(BitC &b, const uint8_t *src, uint32_t si
     if (size == 0) return false;
     const uint32_t last = src[size - 1];
     if (last == 0) return false;
-    b.bitPos = (int64_t)size * 8 - (int64_t)(8 - zs_highbit(last));    // bits below the end mark
+    b.bitPos = (int32_t)(size * 8 - (8 - zs_highbit(last)));           // bits below the end mark
     return true;
 }
-__device__ __forceinline__ int64_t bc_windowBase(const BitC &b, uint32_t W)
+__device__ __forceinline__ int32_t bc_windowBase(const BitC &b, uint32_t W)
 {
-    const int64_t bh = (b.bitPos > 0) ? ((b.bitPos - 1) >> 3) : 0;
-    return (bh + 1 > (int64_t)W) ? bh + 1 - (int64_t)W : 0;
+    const int32_t bh = (b.bitPos > 0) ? ((b.bitPos - 1) >> 3) : 0;
+    return (bh + 1 > (int32_t)W) ? bh + 1 - (int32_t)W : 0;
+}
+// n bits (n <= 32) from the top of the container, no availability check; n = 0 gives 0 (bit-field extract of width 0)
+__device__ __forceinline__ uint32_t bc_take(BitC &b, uint32_t n)
+{
+    const uint32_t v = __builtin_amdgcn_ubfe((uint32_t)(b.c >> 32), 32u - n, n);
+    b.c <<= n; b.avail -= n; b.bitPos -= (int32_t)n;
+    return v;
 }
 
 // the Huffman streams of one block (HufDecompress.cs:222-358): stream k on lane k (nStreams = 1 or 4), in rounds of
@@ -344,36 +351,33 @@ __device__ static bool hufDecodeStreams(DLds &L, uint32_t nStreams, uint8_t *out
     const bool okInit = !mine || bc_init(b, src, size);
     if (__ballot(!okInit)) return false;
     const uint32_t dtLog = L.hufLog;
-    uint32_t i = 0, nacc = 0; uint64_t acc = 0;
+    uint32_t i = 0;
     bool done = !mine || n == 0;
     for (;;) {
-        const int64_t base = bc_windowBase(b, ZS_LITWIN);
+        const int32_t base = bc_windowBase(b, ZS_LITWIN);
         for (uint32_t k = 0; k < nStreams; k++) {
-            const uint64_t sp = (uint64_t)wave_get((uint32_t)(uintptr_t)src, (int)k) | ((uint64_t)wave_get((uint32_t)((uintptr_t)src >> 32), (int)k) << 32);
-            const int64_t bs = (int64_t)((uint64_t)wave_get((uint32_t)base, (int)k) | ((uint64_t)wave_get((uint32_t)((uint64_t)base >> 32), (int)k) << 32));
-            stageWindow(L.u.litWin[k], reinterpret_cast<const uint8_t *>(sp), wave_get(size, (int)k), bs, ZS_LITWIN);
+            const uint64_t sp = wave_get64((uint64_t)(uintptr_t)src, (int)k);
+            stageWindow(L.u.litWin[k], reinterpret_cast<const uint8_t *>(sp), wave_get(size, (int)k), (int32_t)wave_get((uint32_t)base, (int)k), ZS_LITWIN);
         }
         wave_sync();
         if (!done) {
             const uint32_t *win = L.u.litWin[lane];
+            const uint32_t sh = 32u - dtLog;
             while (i < n) {
                 if (b.avail < dtLog) {
                     if (b.bitPos > 0 && base > 0 && ((b.bitPos - 1) >> 3) < base + 8) break;      // window used up: next round
                     bc_refill(b, win, base);
                 }
-                const uint32_t e = L.huf[(uint32_t)(b.c >> (64 - dtLog))];
+                const uint32_t e = L.huf[(uint32_t)(b.c >> 32) >> sh];
                 const uint32_t nb = e >> 8;
-                b.c <<= nb; b.avail -= nb; b.bitPos -= nb;
-                acc |= (uint64_t)(e & 0xFFu) << (8 * nacc);
-                i++;
-                if (++nacc == 8) { __builtin_memcpy(out + i - 8, &acc, 8); acc = 0; nacc = 0; }
+                b.c <<= nb; b.avail -= nb; b.bitPos -= (int32_t)nb;
+                out[i++] = (uint8_t)e;
             }
             if (i == n) done = true;
         }
         wave_sync();
         if (!__ballot(!done)) break;
     }
-    for (uint32_t k = 0; k < nacc; k++) out[i - nacc + k] = (uint8_t)(acc >> (8 * k));
     return !__ballot(mine && b.bitPos != 0);          // EndOfDStream (BitStream.cs:494): every bit consumed, none over-read
 }
 
@@ -540,22 +544,21 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
         uint32_t sLL = 0, sOF = 0, sML = 0;
         uint32_t rep0 = st.rep[0], rep1 = st.rep[1], rep2 = st.rep[2];
         if (!bc_init(b, ip, remaining)) return ZE(E_corruption_detected);             // same bytes for every lane: uniform
-        int64_t base = bc_windowBase(b, ZS_SEQWIN);
+        int32_t base = bc_windowBase(b, ZS_SEQWIN);
         stageWindow(L.u.sq.win, ip, remaining, base, ZS_SEQWIN);
         __syncthreads();
-        #define SEQ_RD(dst, nbits) do { const uint32_t nb_ = (nbits); uint32_t v_ = 0; \
-                if (nb_) { if (b.avail < nb_) bc_refill(b, L.u.sq.win, base); v_ = (uint32_t)(b.c >> (64 - nb_)); b.c <<= nb_; b.avail -= nb_; b.bitPos -= nb_; } \
-                (dst) = v_; } while (0)
-        if (lane == 0) { SEQ_RD(sLL, L.LL.tableLog); SEQ_RD(sOF, L.OF.tableLog); SEQ_RD(sML, L.ML.tableLog); }
+        // one availability check per group of reads (the container holds >= 57 bits after a refill)
+        #define SEQ_NEED(nbits) do { if (b.avail < (nbits)) bc_refill(b, L.u.sq.win, base); } while (0)
+        if (lane == 0) { SEQ_NEED(L.LL.tableLog + L.OF.tableLog + L.ML.tableLog); sLL = bc_take(b, L.LL.tableLog); sOF = bc_take(b, L.OF.tableLog); sML = bc_take(b, L.ML.tableLog); }
         uint32_t left = nbSeq;
         while (left) {
             const uint32_t T = min(64u, left);
             {   // keep a tile's worth of stream below the cursor inside the window
-                const int64_t bp0 = (int64_t)((uint64_t)wave_get((uint32_t)b.bitPos, 0) | ((uint64_t)wave_get((uint32_t)((uint64_t)b.bitPos >> 32), 0) << 32));
-                const int64_t bh = (bp0 > 0) ? ((bp0 - 1) >> 3) : 0;
+                const int32_t bp0 = (int32_t)wave_get((uint32_t)b.bitPos, 0);
+                const int32_t bh = (bp0 > 0) ? ((bp0 - 1) >> 3) : 0;
                 if (base > 0 && bh < base + 736) {
                     __syncthreads();
-                    base = (bh + 1 > (int64_t)ZS_SEQWIN) ? bh + 1 - (int64_t)ZS_SEQWIN : 0;
+                    base = (bh + 1 > (int32_t)ZS_SEQWIN) ? bh + 1 - (int32_t)ZS_SEQWIN : 0;
                     stageWindow(L.u.sq.win, ip, remaining, base, ZS_SEQWIN);
                     __syncthreads();
                 }
@@ -567,8 +570,16 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                     const SeqSym eLL = L.LL.cells[sLL], eOF = L.OF.cells[sOF], eML = L.ML.cells[sML];
                     const uint32_t tLL = L.llTab[eLL.sym], tML = L.mlTab[eML.sym];
                     const uint32_t llBase = tLL & 0xFFFFFFu, llAdd = tLL >> 24, mlBase = tML & 0xFFFFFFu, mlAdd = tML >> 24, ofAdd = eOF.sym;
-                    uint32_t offset, x;
-                    if (ofAdd == 0) offset = 0; else { SEQ_RD(x, ofAdd); offset = ofBaseOf(ofAdd) + x; }
+                    uint32_t offset, ml, ll;
+                    if (ofAdd + mlAdd + llAdd <= 57u) {               // the usual case: all extra bits from one container
+                        SEQ_NEED(ofAdd + mlAdd + llAdd);
+                        offset = ofAdd ? ofBaseOf(ofAdd) + bc_take(b, ofAdd) : 0u;
+                        ml = mlBase + bc_take(b, mlAdd);
+                        ll = llBase + bc_take(b, llAdd);
+                    } else {
+                        SEQ_NEED(ofAdd); offset = ofBaseOf(ofAdd) + bc_take(b, ofAdd);
+                        SEQ_NEED(mlAdd + llAdd); ml = mlBase + bc_take(b, mlAdd); ll = llBase + bc_take(b, llAdd);
+                    }
                     if (ofAdd <= 1) {
                         offset += (llBase == 0);
                         if (offset) {
@@ -578,11 +589,10 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                             rep1 = rep0; rep0 = offset = temp;
                         } else offset = rep0;
                     } else { rep2 = rep1; rep1 = rep0; rep0 = offset; }
-                    SEQ_RD(x, mlAdd); const uint32_t ml = mlBase + x;
-                    SEQ_RD(x, llAdd); const uint32_t ll = llBase + x;
-                    SEQ_RD(x, eLL.nbBits); sLL = eLL.nextState + x;
-                    SEQ_RD(x, eML.nbBits); sML = eML.nextState + x;
-                    SEQ_RD(x, eOF.nbBits); sOF = eOF.nextState + x;
+                    SEQ_NEED((uint32_t)eLL.nbBits + eML.nbBits + eOF.nbBits);
+                    sLL = eLL.nextState + bc_take(b, eLL.nbBits);
+                    sML = eML.nextState + bc_take(b, eML.nbBits);
+                    sOF = eOF.nextState + bc_take(b, eOF.nbBits);
                     L.u.sq.tileLL[t] = ll; L.u.sq.tileML[t] = ml; L.u.sq.tileOff[t] = offset;
                 }
                 L.misc[0] = bad;
@@ -608,6 +618,8 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                 }
                 const uint64_t em = __ballot(err != 0);
                 if (em) return ZE(wave_get(err, __builtin_ctzll(em)));
+                // the copies below hand bytes from lane to lane through global memory inside ONE wavefront: its memory
+                // instructions execute in order, so a wavefront-scope fence (no drain of the stores in flight) is all that is needed
                 const uint64_t tileStart = op;
                 // literals
                 if (ll && ll <= 16) {
@@ -622,7 +634,7 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                     const uint64_t d2 = wave_get64(outStart, t);
                     for (uint32_t j = lane; j < l2; j += 64) dstBase[d2 + j] = litPtr[s2 + j];
                 }
-                __syncthreads();
+                wave_sync();
                 // matches reading only output that existed before this tile
                 const uint64_t msrc = mdst - off;
                 const bool indep = ml && (msrc + ml <= tileStart);
@@ -637,7 +649,7 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                     const uint64_t s2 = wave_get64(msrc, t), d2 = wave_get64(mdst, t);
                     for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j];
                 }
-                __syncthreads();
+                wave_sync();
                 // matches reading this tile's own output (earlier sequences are complete by then), in order
                 for (uint64_t dm = __ballot(ml && !indep); dm; dm &= dm - 1) {
                     const int t = __builtin_ctzll(dm);
@@ -645,7 +657,7 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                     const uint64_t s2 = wave_get64(msrc, t), d2 = wave_get64(mdst, t);
                     if (o2 >= m2) { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j]; }
                     else { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + (j % o2)]; }      // period = offset
-                    __syncthreads();
+                    wave_sync();
                 }
                 op += wave_last(incl);
                 litPos += wave_last(inclL);
@@ -653,7 +665,7 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
             PROF_ADD(3);
             left -= T;
         }
-        #undef SEQ_RD
+        #undef SEQ_NEED
         st.rep[0] = wave_get(rep0, 0); st.rep[1] = wave_get(rep1, 0); st.rep[2] = wave_get(rep2, 0);
     }
     {
