@@ -32,7 +32,15 @@ assert (d_osz.cpu().numpy() == cs).all()
 assert torch.equal(d_out, d_src), "decoded bytes differ from the input"
 comp = int(fsz.astype(np.uint64).sum())
 # CPU baseline: oracle D on all host cores over a bounded sample
-m = min(n, 4096); cores = os.cpu_count() or 1
+def usable_cores():
+    k = len(os.sched_getaffinity(0))
+    try:
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max": k = min(k, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return min(k, 64)
+m = min(n, 4096); cores = usable_cores()
 fr = d_frames.cpu().numpy()
 L = O.lib(); import ctypes
 dst = np.empty(m * cs, dtype=np.uint8); dsz = np.zeros(m, dtype=np.uint32); vp = ctypes.c_void_p
