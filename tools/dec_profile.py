@@ -19,8 +19,9 @@ stride = (1 << 17) + 64
 buf = np.zeros(n * stride, dtype=np.uint8)
 rc = Z.zsmi_dbg_copyScratch(bc.ctx, 5, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(n * stride)); assert rc == 0, rc
 prof = np.stack([buf[i * stride + (1 << 17): i * stride + (1 << 17) + 64].view(np.uint64) for i in range(n)])
-names = ["literals", "seq tables", "seq decode", "seq execute", "checksum", "whole item", "  huf table", "-"]
+names = ["literals", "seq tables", "seq decode", "seq execute", "checksum", "whole item", "  huf table", "  huf symbol loops"]
 m = prof.mean(axis=0)
 for k, nm in enumerate(names):
     print(f"{nm:12s} {m[k]:12.0f} ticks  {100 * m[k] / m[5]:5.1f} %")
+print("literals per frame (mean):", float(np.mean([0])) )
 print("s_memtime ticks at 100 MHz: whole item = %.1f us" % (m[5] / 100.0))

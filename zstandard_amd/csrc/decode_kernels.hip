@@ -343,8 +343,9 @@ __device__ __forceinline__ uint32_t bc_take(BitC &b, uint32_t n)
 
 // the Huffman streams of one block (HufDecompress.cs:222-358): stream k on lane k (nStreams = 1 or 4), in rounds of
 // "stage ZS_LITWIN bytes of every stream, decode until a stream needs more".  8 decoded bytes go out per store.
-__device__ static bool hufDecodeStreams(DLds &L, uint32_t nStreams, uint8_t *out, uint32_t n, const uint8_t *src, uint32_t size)
+__device__ __forceinline__ bool hufDecodeStreams(DLds &L, uint32_t nStreams, uint8_t *out, uint32_t n, const uint8_t *src, uint32_t size, uint64_t *g_prof)
 {
+    (void)g_prof;
     const uint32_t lane = (uint32_t)zs_lane();
     const bool mine = lane < nStreams;
     BitC b; b.c = 0; b.avail = 0; b.bitPos = 0;
@@ -360,9 +361,30 @@ __device__ static bool hufDecodeStreams(DLds &L, uint32_t nStreams, uint8_t *out
             stageWindow(L.u.litWin[k], reinterpret_cast<const uint8_t *>(sp), wave_get(size, (int)k), (int32_t)wave_get((uint32_t)base, (int)k), ZS_LITWIN);
         }
         wave_sync();
+#ifdef ZS_DEC_PROFILE
+        const uint64_t t7_ = __builtin_readcyclecounter();
+#endif
         if (!done) {
             const uint32_t *win = L.u.litWin[lane];
             const uint32_t sh = 32u - dtLog;
+            // bulk: a refill leaves >= 57 bits and 4 symbols take <= 4 * 12: four symbols per refill without a check between
+            // them, one 4-byte store.  Not near the head of the stream (bits below it read as 0) nor at the window edge.
+            while (i + 4 <= n) {
+                const int32_t bh = (b.bitPos - 1) >> 3;
+                if (b.bitPos < 64 || (base > 0 && bh < base + 16)) break;
+                uint64_t c = win64(win, (uint32_t)(bh - base + 1)) << (7u - (uint32_t)((b.bitPos - 1) & 7));
+                uint32_t used = 0, pack = 0;
+                #pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t e = L.huf[(uint32_t)(c >> 32) >> sh];
+                    const uint32_t nb = e >> 8;
+                    c <<= nb; used += nb; pack |= (e & 0xFFu) << (8 * k);
+                }
+                b.bitPos -= (int32_t)used;
+                __builtin_memcpy(out + i, &pack, 4);
+                i += 4;
+            }
+            b.avail = 0;                                                 // the careful loop below refills first
             while (i < n) {
                 if (b.avail < dtLog) {
                     if (b.bitPos > 0 && base > 0 && ((b.bitPos - 1) >> 3) < base + 8) break;      // window used up: next round
@@ -376,6 +398,9 @@ __device__ static bool hufDecodeStreams(DLds &L, uint32_t nStreams, uint8_t *out
             if (i == n) done = true;
         }
         wave_sync();
+#ifdef ZS_DEC_PROFILE
+        if (g_prof) g_prof[7] += __builtin_readcyclecounter() - t7_;
+#endif
         if (!__ballot(!done)) break;
     }
     return !__ballot(mine && b.bitPos != 0);          // EndOfDStream (BitStream.cs:494): every bit consumed, none over-read
@@ -442,10 +467,10 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                 if (h >= csz) return ZE(E_corruption_detected);
                 cs += h; csz -= h;
             }
-            bool ok = true;
-            if (single) {
-                ok = hufDecodeStreams(L, 1, litBuf, litSize, cs, csz);
-            } else {
+            // one call site (the function is inlined: a call would turn its stores into flat stores, whose completion
+            // every LDS read of the symbol loop would then wait for)
+            uint32_t nStreams = 1, sOff = 0, sLen = csz, sCnt = litSize, sOut = 0;
+            if (!single) {
                 if (csz < 10) return ZE(E_corruption_detected);
                 const uint32_t l1 = rd16(cs), l2 = rd16(cs + 2), l3 = rd16(cs + 4);
                 if (l1 + l2 + l3 + 6 > csz) return ZE(E_corruption_detected);
@@ -453,11 +478,13 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                 const uint32_t seg = (litSize + 3) / 4;
                 if (3 * seg > litSize) return ZE(E_corruption_detected);
                 const uint32_t sl = min(lane, 3u);
-                const uint32_t off = 6 + (sl > 0 ? l1 : 0) + (sl > 1 ? l2 : 0) + (sl > 2 ? l3 : 0);
-                const uint32_t len = sl == 0 ? l1 : (sl == 1 ? l2 : (sl == 2 ? l3 : l4));
-                const uint32_t cnt = sl < 3 ? seg : litSize - 3 * seg;
-                ok = hufDecodeStreams(L, 4, litBuf + sl * seg, cnt, cs + off, len);
+                nStreams = 4;
+                sOff = 6 + (sl > 0 ? l1 : 0) + (sl > 1 ? l2 : 0) + (sl > 2 ? l3 : 0);
+                sLen = sl == 0 ? l1 : (sl == 1 ? l2 : (sl == 2 ? l3 : l4));
+                sCnt = sl < 3 ? seg : litSize - 3 * seg;
+                sOut = sl * seg;
             }
+            const bool ok = hufDecodeStreams(L, nStreams, litBuf + sOut, sCnt, cs + sOff, sLen, g_prof);
             if (__ballot(!ok)) return ZE(E_corruption_detected);
             __syncthreads();
             litPtr = litBuf; st.litEntropy = 1; litCSizeTot = litCSize + lhSize;
@@ -573,14 +600,14 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                     uint32_t offset, ml, ll;
                     if (ofAdd + mlAdd + llAdd <= 57u) {               // the usual case: all extra bits from one container
                         SEQ_NEED(ofAdd + mlAdd + llAdd);
-                        offset = ofAdd ? ofBaseOf(ofAdd) + bc_take(b, ofAdd) : 0u;
+                        offset = ofBaseOf(ofAdd) + bc_take(b, ofAdd);      // ofBaseOf(0) = 0 and 0 bits read: offset code 0
                         ml = mlBase + bc_take(b, mlAdd);
                         ll = llBase + bc_take(b, llAdd);
                     } else {
                         SEQ_NEED(ofAdd); offset = ofBaseOf(ofAdd) + bc_take(b, ofAdd);
                         SEQ_NEED(mlAdd + llAdd); ml = mlBase + bc_take(b, mlAdd); ll = llBase + bc_take(b, llAdd);
                     }
-                    if (ofAdd <= 1) {
+                    if (ofAdd <= 1) {                                  // recent offsets (:1509-1530)
                         offset += (llBase == 0);
                         if (offset) {
                             uint32_t temp = (offset == 3) ? rep0 - 1 : (offset == 1 ? rep1 : rep2);
