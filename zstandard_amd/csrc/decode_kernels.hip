@@ -169,30 +169,64 @@ __device__ static uint32_t readNCount(int16_t *norm, uint32_t *maxSVPtr, uint32_
     return (uint32_t)(ip - istart);
 }
 
-// ---- BuildFSETable (ZStdDecompress.cs:958-1034), lane 0.  kind: 0 LL, 1 OF, 2 ML ----
-__device__ static void buildSeqTable(SeqSym *cells, uint32_t *tableLogOut, uint16_t *symbolNext, const int16_t *norm, uint32_t maxSym, uint32_t tableLog, int kind)
+// ---- BuildFSETable (ZStdDecompress.cs:958-1034) by all 64 lanes; lane s owns symbol s (maxSym <= 52).
+// The reference walks the cells in the order p_k = (k * step) & mask, skipping the low-probability area at the top, and
+// hands them to the symbols in turn; step is odd, so p_k is a permutation: the k-th visit is valid iff p_k <= highThreshold
+// and takes the j-th entry of the expanded symbol list, j = valid visits before k.  Then nextState numbers go to the cells
+// of a symbol in ascending cell order. ----
+__device__ static void buildSeqTableWave(DLds &L, SeqSym *cells, uint32_t *tableLogOut, uint32_t maxSym, uint32_t tableLog)
 {
+    const uint32_t lane = (uint32_t)zs_lane();
     const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
-    uint32_t highThreshold = tableSize - 1, position = 0;
-    *tableLogOut = tableLog;
-    for (uint32_t s = 0; s <= maxSym; s++) {
-        if (norm[s] == -1) { cells[highThreshold--].sym = (uint8_t)s; symbolNext[s] = 1; }
-        else symbolNext[s] = (uint16_t)norm[s];
-    }
-    for (uint32_t s = 0; s <= maxSym; s++)
-        for (int i = 0; i < norm[s]; i++) {
-            cells[position].sym = (uint8_t)s;
-            position = (position + step) & tableMask;
-            while (position > highThreshold) position = (position + step) & tableMask;
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint16_t *cumul = L.u.tb.symStart, *symbolNext = L.u.tb.symbolNext;              // scratch of this phase
+    const int n = (lane <= maxSym) ? (int)L.u.tb.norm[lane] : 0;
+    const bool low = n == -1;
+    const uint64_t lowMask = __ballot(low);
+    const uint32_t highThreshold = tableSize - 1 - (uint32_t)__popcll(lowMask);
+    if (low) cells[tableSize - 1 - (uint32_t)__popcll(lowMask & below)].sym = (uint8_t)lane;   // :975-978, symbols ascending take cells descending
+    const uint32_t cnt = n > 0 ? (uint32_t)n : 0u;
+    const uint32_t incl = wave_incl_scan(cnt);
+    cumul[lane] = (uint16_t)(incl - cnt);
+    symbolNext[lane] = (uint16_t)(low ? 1 : cnt);
+    if (lane == 0) *tableLogOut = tableLog;
+    wave_sync();
+    uint32_t validBefore = 0;
+    for (uint32_t base = 0; base < tableSize; base += 64) {
+        const uint32_t k = base + lane, p = (k * step) & tableMask;
+        const bool valid = k < tableSize && p <= highThreshold;
+        const uint64_t vm = __ballot(valid);
+        if (valid) {
+            const uint32_t j = validBefore + (uint32_t)__popcll(vm & below);
+            uint32_t lo = 0, hi = maxSym + 1;                                        // last symbol whose first entry index is <= j
+            while (hi - lo > 1) { const uint32_t mid = (lo + hi) >> 1; if (cumul[mid] <= j) lo = mid; else hi = mid; }
+            cells[p].sym = (uint8_t)lo;
         }
-    for (uint32_t u = 0; u < tableSize; u++) {
-        const uint32_t symbol = cells[u].sym;
-        const uint32_t nextState = symbolNext[symbol]++;
-        const uint32_t nb = tableLog - zs_highbit(nextState);
-        cells[u].nbBits = (uint8_t)nb;
-        cells[u].nextState = (uint16_t)((nextState << nb) - tableSize);
+        validBefore += (uint32_t)__popcll(vm);
     }
-    (void)kind;
+    wave_sync();
+    for (uint32_t base = 0; base < tableSize; base += 64) {
+        const uint32_t u = base + lane;
+        const bool in = u < tableSize;
+        const uint32_t sym = in ? cells[u].sym : 0xFFFFu;
+        uint64_t todo = __ballot(in);
+        while (todo) {
+            const int leader = __builtin_ctzll(todo);
+            const uint32_t ls = wave_get(sym, leader);
+            const uint64_t same = __ballot(in && sym == ls);
+            if (in && sym == ls) {
+                const uint32_t nextState = (uint32_t)symbolNext[ls] + (uint32_t)__popcll(same & below);     // :1021-1023
+                const uint32_t nb = tableLog - zs_highbit(nextState);
+                cells[u].nbBits = (uint8_t)nb;
+                cells[u].nextState = (uint16_t)((nextState << nb) - tableSize);
+            }
+            wave_sync();
+            if (lane == (uint32_t)leader) symbolNext[ls] = (uint16_t)(symbolNext[ls] + (uint32_t)__popcll(same));
+            wave_sync();
+            todo &= ~same;
+        }
+    }
+    wave_sync();
 }
 
 // ---- ReadStats + table fill (EntropyCommon.cs:198-269, HufDecompress.cs:117-180) ----
@@ -522,41 +556,44 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
             }
             if (ip + 4 > iend) return ZE(E_srcSize_wrong);
             const uint32_t modes = *ip++;
-            if (lane == 0) {
-                uint32_t err = 0; const uint8_t *p = ip;
-                for (int t = 0; t < 3 && !err; t++) {
-                    const uint32_t type = (modes >> (6 - 2 * t)) & 3;
-                    const uint32_t maxS = t == 0 ? 35 : (t == 1 ? 31 : 52), maxLog = t == 1 ? 8 : 9;
-                    SeqSym *cells = t == 0 ? L.LL.cells : (t == 1 ? L.OF.cells : L.ML.cells);
-                    uint32_t *tl = t == 0 ? &L.LL.tableLog : (t == 1 ? &L.OF.tableLog : &L.ML.tableLog);
+            uint32_t consumed = 0;
+            for (int t = 0; t < 3; t++) {
+                const uint32_t type = (modes >> (6 - 2 * t)) & 3;
+                const uint32_t maxS = t == 0 ? 35 : (t == 1 ? 31 : 52), maxLog = t == 1 ? 8 : 9;
+                SeqSym *cells = t == 0 ? L.LL.cells : (t == 1 ? L.OF.cells : L.ML.cells);
+                uint32_t *tl = t == 0 ? &L.LL.tableLog : (t == 1 ? &L.OF.tableLog : &L.ML.tableLog);
+                const int16_t *dn = t == 0 ? d_LL_defaultNorm : (t == 1 ? d_OF_defaultNorm : d_ML_defaultNorm);
+                const uint32_t dmax = t == 0 ? 35 : (t == 1 ? 28 : 52);
+                if (lane == 0) {                                   // parse (serial, small): what to build and how many bytes it took
+                    uint32_t err = 0, adv = 0, bmax = 0, blog = 0;
+                    const uint8_t *p = ip + consumed;
                     const uint32_t left = (uint32_t)(iend - p);
                     if (type == 1) {
-                        if (!left) { err = ZE(E_srcSize_wrong); break; }
-                        const uint32_t symbol = *p;
-                        if (symbol > maxS) { err = ZE(E_corruption_detected); break; }
-                        *tl = 0; cells[0].nbBits = 0; cells[0].nextState = 0; cells[0].sym = (uint8_t)symbol;
-                        p += 1;
-                    } else if (type == 0) {
-                        const int16_t *dn = t == 0 ? d_LL_defaultNorm : (t == 1 ? d_OF_defaultNorm : d_ML_defaultNorm);
-                        const uint32_t dmax = t == 0 ? 35 : (t == 1 ? 28 : 52);
-                        for (uint32_t i = 0; i <= dmax; i++) L.u.tb.norm[i] = dn[i];
-                        buildSeqTable(cells, tl, L.u.tb.symbolNext, L.u.tb.norm, dmax, t == 1 ? 5 : 6, t);
-                    } else if (type == 3) {
-                        if (!st.fseEntropy) { err = ZE(E_corruption_detected); break; }
-                    } else {
-                        uint32_t tableLog, max = maxS;
+                        if (!left) err = ZE(E_srcSize_wrong);
+                        else {
+                            const uint32_t symbol = *p;
+                            if (symbol > maxS) err = ZE(E_corruption_detected);
+                            else { *tl = 0; cells[0].nbBits = 0; cells[0].nextState = 0; cells[0].sym = (uint8_t)symbol; adv = 1; }
+                        }
+                    } else if (type == 0) { bmax = dmax; blog = t == 1 ? 5 : 6; }
+                    else if (type == 3) { if (!st.fseEntropy) err = ZE(E_corruption_detected); }
+                    else {
+                        uint32_t tableLog = 0, max = maxS;
                         const uint32_t h = readNCount(L.u.tb.norm, &max, &tableLog, p, left);
-                        if (isErr(h)) { err = ZE(E_corruption_detected); break; }
-                        if (tableLog > maxLog) { err = ZE(E_corruption_detected); break; }
-                        buildSeqTable(cells, tl, L.u.tb.symbolNext, L.u.tb.norm, max, tableLog, t);
-                        p += h;
+                        if (isErr(h) || tableLog > maxLog) err = ZE(E_corruption_detected);
+                        else { bmax = max; blog = tableLog; adv = h; }
                     }
+                    L.misc[0] = err; L.misc[1] = adv; L.misc[3] = bmax; L.misc[4] = blog;
                 }
-                L.misc[0] = err; L.misc[1] = (uint32_t)(p - ip);
+                __syncthreads();
+                if (L.misc[0]) return ZE(E_corruption_detected);
+                consumed += L.misc[1];
+                const uint32_t bmax = L.misc[3], blog = L.misc[4];
+                if (type == 0) { if (lane <= dmax) L.u.tb.norm[lane] = dn[lane]; wave_sync(); }
+                if (type == 0 || type == 2) buildSeqTableWave(L, cells, tl, bmax, blog);
+                __syncthreads();
             }
-            __syncthreads();
-            if (L.misc[0]) return ZE(E_corruption_detected);
-            ip += L.misc[1];
+            ip += consumed;
             remaining = (uint32_t)(iend - ip);
         }
     }
