@@ -31,8 +31,12 @@ def alphabet_data() -> bytes:
 
 
 def fixtures():
-    z = np.load(os.path.join(GOLDEN, "libzstd_fixtures.npz"))
-    return {k[6:]: (z[k].tobytes(), z["data_" + k[6:]].tobytes()) for k in z.files if k.startswith("frame_")}
+    """libzstd 1.4.8 frames (tests/golden/gen_fixtures.py, gen_fixtures2.py): name -> (frame, content)"""
+    out = {}
+    for fn in ("libzstd_fixtures.npz", "libzstd_fixtures2.npz"):
+        z = np.load(os.path.join(GOLDEN, fn))
+        out.update({k[6:]: (z[k].tobytes(), z["data_" + k[6:]].tobytes()) for k in z.files if k.startswith("frame_")})
+    return out
 
 
 def mixed_inputs(seed=7):

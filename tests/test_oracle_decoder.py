@@ -49,14 +49,13 @@ def test_fixture_coverage():
     for frame, want in D.fixtures().values():
         _, st = O.decode_stats(frame, len(want))
         tot += st
-    must = {0: "raw literals", 2: "huffman literals", 3: "treeless literals", 4: "1-stream", 5: "4-stream",
+    must = {0: "raw literals", 1: "rle literals", 2: "huffman literals", 3: "treeless literals", 4: "1-stream", 5: "4-stream",
             6: "direct weights", 7: "fse weights", 8: "LL predefined", 9: "LL rle", 10: "LL fse", 11: "LL repeat",
-            12: "OF predefined", 13: "OF rle", 14: "OF fse", 16: "ML predefined", 17: "ML rle", 18: "ML fse",
-            20: "raw block", 21: "rle block", 22: "compressed block", 24: "skippable", 25: "checksum",
-            26: "nbSeq==0", 28: "repcode", 29: "multi-block"}
+            12: "OF predefined", 13: "OF rle", 14: "OF fse", 15: "OF repeat", 16: "ML predefined", 17: "ML rle", 18: "ML fse",
+            19: "ML repeat", 20: "raw block", 21: "rle block", 22: "compressed block", 24: "skippable", 25: "checksum",
+            26: "nbSeq==0", 27: ">= 0x7F00 sequences", 28: "repcode", 29: "multi-block"}
     missing = [v for k, v in must.items() if tot[k] == 0]
     assert not missing, missing
-    # known holes (no generator in this image produces them): RLE literals, OF/ML repeat, >= 0x7F00 sequences
 
 
 def test_get_decompressed_size_semantics():
