@@ -3,7 +3,7 @@
 for v in zstandard_amd/lib/variants/*.so; do
   cp "$v" zstandard_amd/lib/libzsmi.so
   echo "== $(basename $v)"
-  timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | python -c "
+  timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-cpu-baseline $BENCH_ARGS 2>/dev/null | python -c "
 import sys, json
 for l in sys.stdin:
     if l.startswith('{'):

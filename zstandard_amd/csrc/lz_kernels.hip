@@ -33,6 +33,9 @@ __device__ __forceinline__ uint32_t zs_slot_entry(uint32_t hh, int hashLog, uint
 #ifndef ZS_CAND_U
 #define ZS_CAND_U 4                // steps of 64 positions per trip (loads in flight per lane)
 #endif
+#ifndef ZS_CAND_U_BIG
+#define ZS_CAND_U_BIG 8
+#endif
 #ifndef ZS_CAND_MINWG
 #define ZS_CAND_MINWG 2            // small-unit kernel: 64 KiB of LDS, so two workgroups share a CU if the registers allow
 #endif
@@ -65,7 +68,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
 
     // U steps per trip.  The loads of trip t+1 are issued before trip t is worked on (registers double-buffered),
     // so the table walk of a trip runs under the memory latency of the next one.
-    constexpr uint32_t U = ZS_CAND_U;
+    constexpr uint32_t U = (NR > 8) ? ZS_CAND_U_BIG : ZS_CAND_U;      // the 128 KiB shape runs one workgroup per CU: more loads in flight per wavefront
     if (half == 0) {
         uint32_t v[U], vn[U];
         #pragma unroll
