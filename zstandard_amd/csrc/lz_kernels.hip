@@ -144,12 +144,19 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
                     const uint32_t hh = v[u] * 2654435761u;
                     const uint32_t h = hh >> (32 - hashLog);
                     const uint32_t tagv = zs_slot_entry(hh, hashLog, 0);
+                    // slot ^ tagv < 8192 <=> same tag, and then it is the position in the range.  The empty slot 0xFFFF would pass
+                    // as (tag 7, position 8191): with tag 7 the limit drops to 8191.  The nearest range = the largest key.
+                    const uint32_t limit = ZS_RANGE_SIZE - (tagv == (7u << ZS_RANGE_LOG) ? 1u : 0u);
                     uint32_t c[NR - 1];
                     #pragma unroll
                     for (uint32_t q = 0; q < NR - 1; q++) c[q] = (q < wave) ? (uint32_t)tables[((size_t)q << hashLog) + h] : ZS_SLOT_EMPTY;
+                    uint32_t best = 0;
                     #pragma unroll
-                    for (uint32_t q = 0; q < NR - 1; q++)
-                        if (c[q] != ZS_SLOT_EMPTY && ((c[q] ^ tagv) >> ZS_RANGE_LOG) == 0) cand[u] = (q << ZS_RANGE_LOG) + (c[q] & (ZS_RANGE_SIZE - 1)) + 1;
+                    for (uint32_t q = 0; q < NR - 1; q++) {
+                        const uint32_t x = c[q] ^ tagv;
+                        best = max(best, (x < limit) ? x + (q << ZS_RANGE_LOG) + 1u : 0u);
+                    }
+                    cand[u] = best;
                 }
             }
             uint32_t cv[U];
