@@ -53,7 +53,7 @@ struct FseCT {                       // encoding table of one symbol type
 struct K3Lds {                       // literals kernel
     uint32_t count[256];             // literal histogram
     uint8_t  nbBits[256];
-    uint16_t code[256];
+    uint32_t codeNb[256];            // code | nbBits << 16
     uint32_t leafW[256];
     uint16_t leafSym[256];
     uint8_t  lenOfRank[256];
@@ -436,7 +436,7 @@ __device__ static void huffCodesAndWeights(K3Lds &L, uint32_t maxSym, uint32_t t
     __syncthreads();
     if (nb) {
         for (uint32_t v = 0; v < wave; v++) idx += L.u.pm.S[v * 16 + w];
-        L.code[tid] = (uint16_t)((L.rankStart[w] >> (w - 1)) + idx);
+        L.codeNb[tid] = ((L.rankStart[w] >> (w - 1)) + idx) | (nb << 16);
     }
     __syncthreads();
 }
@@ -450,12 +450,16 @@ __device__ static uint32_t huffEncodeStream(K3Lds &L, uint32_t *tile, uint8_t *t
     while (remaining) {
         const uint32_t T = min(512u, remaining);
         uint64_t lo = 0; uint32_t hi = 0, nb = 0;
+        // lane l takes symbols k = 8l .. 8l+7 of the tile, i.e. the 8 literals ending at position from + remaining - 1 - 8l, last first
+        const uint32_t k0 = lane * 8;
+        uint64_t eight = 0;
+        if (k0 + 8 <= T) eight = zs_load64(lits + from + remaining - 8 - k0);
+        else for (uint32_t j = 0; j < 8; j++) if (k0 + j < T) eight |= (uint64_t)lits[from + remaining - 1 - k0 - j] << (8 * (7 - j));
         #pragma unroll
         for (uint32_t j = 0; j < 8; j++) {
-            const uint32_t k = lane * 8 + j;
-            if (k < T) {
-                const uint32_t sym = lits[from + remaining - 1 - k];
-                const uint32_t c = L.code[sym], b = L.nbBits[sym];
+            if (k0 + j < T) {
+                const uint32_t sym = (uint32_t)(eight >> (8 * (7 - j))) & 0xFFu;
+                const uint32_t cn = L.codeNb[sym], c = cn & 0xFFFFu, b = cn >> 16;
                 if (nb < 64) { lo |= (uint64_t)c << nb; if (nb + b > 64) hi |= c >> (64 - nb); }
                 else hi |= c << (nb - 64);
                 nb += b;
@@ -987,7 +991,9 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                         outp[0] = 0;
                         t = 1;
                     }
-                    // operands of step t+1 are read before the dependent table lookup of step t; lanes whose tile is shorter idle
+                    // operands of step t+1 are read before the dependent table lookup of step t; lanes whose tile is shorter idle.
+                    // The chain is the critical path of the workgroup: its wavefront issues ahead of the others on its SIMD.
+                    __builtin_amdgcn_s_setprio(3);
                     uint2 cur = op[t];
                     for (; t < Tmax; t++) {
                         const uint2 nxt = op[t + 1];
@@ -998,6 +1004,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                         }
                         cur = nxt;
                     }
+                    __builtin_amdgcn_s_setprio(0);
                 } else {
                     for (uint32_t t = 0; t < Tg; t++) outp[t] = 0;
                 }
