@@ -24,7 +24,16 @@
 #define PROF_T0() do {} while (0)
 #define PROF_ADD(k) do {} while (0)
 #endif
+// Synchronisation inside one item is wavefront-local.  wave_sync() orders LDS traffic between the lanes (LDS instructions of
+// a wavefront execute in issue order).  Bytes handed from lane to lane through GLOBAL memory additionally need the stores to
+// have completed before the loads are issued (loads and stores of a wavefront may complete out of order with respect to
+// each other): wave_mem_sync() waits for the outstanding vector-memory operations of the wavefront.
+__device__ __forceinline__ void wave_mem_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
+#ifdef ZS_DEC_ERRLINE                     // debugging aid: an error result carries the source line that raised it
+#define ZE(code) (0xFF000000u | (uint32_t)__LINE__)
+#else
 #define ZE(code) (0u - (uint32_t)(code))
+#endif
 #define E_GENERIC 1
 #define E_prefix_unknown 10
 #define E_frameParameter_unsupported 14
@@ -36,7 +45,11 @@
 #define E_tableLog_tooLarge 44
 #define E_dstSize_tooSmall 70
 #define E_srcSize_wrong 72
+#ifdef ZS_DEC_ERRLINE
+__device__ __forceinline__ bool isErr(uint32_t v) { return v >= 0xFF000000u; }
+#else
 __device__ __forceinline__ bool isErr(uint32_t v) { return v > ZE(120); }
+#endif
 
 struct ZsDecItem { uint64_t srcOff; uint64_t dstOff; uint32_t srcSize; uint32_t dstCap; };
 
@@ -121,7 +134,7 @@ __device__ __forceinline__ uint32_t br_look(BitR &b, uint32_t n)
 __device__ __forceinline__ uint32_t br_read(BitR &b, uint32_t n) { const uint32_t v = br_look(b, n); b.bitPos -= n; return v; }
 
 // ---- ReadNCount (EntropyCommon.cs:79-188), lane 0 ----
-__device__ static uint32_t readNCount(int16_t *norm, uint32_t *maxSVPtr, uint32_t *tableLogPtr, const uint8_t *hdr, uint32_t hbSize)
+__device__ __forceinline__ uint32_t readNCount(int16_t *norm, uint32_t *maxSVPtr, uint32_t *tableLogPtr, const uint8_t *hdr, uint32_t hbSize)
 {
     const uint8_t *const istart = hdr; const uint8_t *const iend = istart + hbSize; const uint8_t *ip = istart;
     int nbBits, remaining, threshold, bitCount; uint32_t bitStream, charnum = 0; int previous0 = 0;
@@ -174,7 +187,7 @@ __device__ static uint32_t readNCount(int16_t *norm, uint32_t *maxSVPtr, uint32_
 // hands them to the symbols in turn; step is odd, so p_k is a permutation: the k-th visit is valid iff p_k <= highThreshold
 // and takes the j-th entry of the expanded symbol list, j = valid visits before k.  Then nextState numbers go to the cells
 // of a symbol in ascending cell order. ----
-__device__ static void buildSeqTableWave(DLds &L, SeqSym *cells, uint32_t *tableLogOut, uint32_t maxSym, uint32_t tableLog)
+__device__ __forceinline__ void buildSeqTableWave(DLds &L, SeqSym *cells, uint32_t *tableLogOut, uint32_t maxSym, uint32_t tableLog)
 {
     const uint32_t lane = (uint32_t)zs_lane();
     const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
@@ -231,7 +244,7 @@ __device__ static void buildSeqTableWave(DLds &L, SeqSym *cells, uint32_t *table
 
 // ---- ReadStats + table fill (EntropyCommon.cs:198-269, HufDecompress.cs:117-180) ----
 // lane 0 parses the weights; all lanes fill the table.  returns header size or error.
-__device__ static uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t srcSize)
+__device__ __forceinline__ uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t srcSize)
 {
     const uint32_t lane = (uint32_t)zs_lane();
     if (lane == 0) {
@@ -303,12 +316,12 @@ __device__ static uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t sr
         } while (0);
         L.misc[0] = result;
     }
-    __syncthreads();
+    wave_sync();
     const uint32_t res = L.misc[0];
     if (isErr(res)) return res;
     const uint32_t nbSymbols = L.misc[1], tableLog = L.hufLog;
     if (lane == 0) for (uint32_t n = 0; n < nbSymbols; n++) { const uint32_t w = L.u.tb.weights[n]; L.u.tb.symStart[n] = (uint16_t)L.u.tb.rank[w]; if (w) L.u.tb.rank[w] += (1u << w) >> 1; }
-    __syncthreads();
+    wave_sync();
     for (uint32_t n = 0; n < nbSymbols; n++) {            // uniform loop; lanes fill one symbol's cells together
         const uint32_t w = L.u.tb.weights[n];
         if (!w) continue;
@@ -316,7 +329,7 @@ __device__ static uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t sr
         const uint16_t e = (uint16_t)(n | ((tableLog + 1 - w) << 8));
         for (uint32_t u = lane; u < length; u += 64) L.huf[startAt + u] = e;
     }
-    __syncthreads();
+    wave_sync();
     return res;
 }
 
@@ -324,7 +337,7 @@ __device__ static uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t sr
 //      bitstreams from LDS: a global load inside such a dependent chain costs a full memory round trip per ~64 bits
 //      (and on gfx9 a wait for it also waits for the stores in flight).  All 64 lanes stage the bytes. ----
 // win[] <- stream bytes [base - 8, base + W); bytes outside [0, size) read as 0 (bits below the stream start are 0, BitStream.cs:412)
-__device__ static void stageWindow(uint32_t *win, const uint8_t *src, uint32_t size, int32_t base, uint32_t W)
+__device__ __forceinline__ void stageWindow(uint32_t *win, const uint8_t *src, uint32_t size, int32_t base, uint32_t W)
 {
     const uint32_t lane = (uint32_t)zs_lane();
     for (uint32_t j = lane; j < (W + 8) / 4 + 2; j += 64) {
@@ -465,10 +478,139 @@ __device__ static uint64_t xxh64(const uint8_t *p, uint64_t len)
     return h64;
 }
 
-// ---- one compressed block (ZSTD_decompressBlock_internal :1868-1909). returns decoded size or error ----
 struct DState { uint32_t rep[3]; uint32_t litEntropy, fseEntropy; uint32_t llRepeatOk; };
 
-__device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, uint64_t frameStart, uint64_t op, uint64_t oend,
+// ---- one tile of <= 64 decoded sequences (L.u.sq.tile*) -> output bytes.  Returns 0 or an error; advances op / litPos. ----
+__device__ __forceinline__ uint32_t execTile(DLds &L, uint32_t T, uint8_t *dstBase, uint64_t frameStart, uint64_t oend,
+                                             const uint8_t *litPtr, uint32_t litSize, uint64_t &op, uint32_t &litPos)
+{
+    const uint32_t lane = (uint32_t)zs_lane();
+    // execute the tile (ExecSequence :1265-1352).  Lane t owns sequence t: output positions by prefix sums, the checks
+    // of the reference in its order (the first failing sequence decides), then all literal runs at once, then all
+    // matches whose source lies before this tile's output at once, then the matches that read this tile's own output
+    // one after the other.
+    {
+        const uint32_t ll = (lane < T) ? L.u.sq.tileLL[lane] : 0u, ml = (lane < T) ? L.u.sq.tileML[lane] : 0u, off = (lane < T) ? L.u.sq.tileOff[lane] : 0u;
+        const uint32_t incl = wave_incl_scan(ll + ml), inclL = wave_incl_scan(ll);
+        const uint64_t outStart = op + (incl - ll - ml);              // where my literals go
+        const uint32_t litStart = litPos + (inclL - ll);
+        const uint64_t mdst = outStart + ll;                          // where my match goes
+        uint32_t err = 0;
+        if (lane < T) {
+            if ((uint64_t)ll + ml > oend - outStart || outStart > oend) err = E_dstSize_tooSmall;
+            else if (ll > litSize - litStart || litStart > litSize) err = E_corruption_detected;
+            else if (off > mdst - frameStart) err = E_corruption_detected;
+        }
+        const uint64_t em = __ballot(err != 0);
+        if (em) return ZE(wave_get(err, __builtin_ctzll(em)));
+        const uint64_t tileStart = op;
+        // literals
+        if (ll && ll <= 16) {
+            if (litStart + 16 <= litSize) {
+                const uint64_t a = zs_load64(litPtr + litStart), c = zs_load64(litPtr + litStart + 8);
+                for (uint32_t j = 0; j < ll; j++) dstBase[outStart + j] = (uint8_t)(j < 8 ? a >> (8 * j) : c >> (8 * (j - 8)));
+            } else for (uint32_t j = 0; j < ll; j++) dstBase[outStart + j] = litPtr[litStart + j];
+        }
+        for (uint64_t lm = __ballot(ll > 16); lm; lm &= lm - 1) {
+            const int t = __builtin_ctzll(lm);
+            const uint32_t l2 = wave_get(ll, t), s2 = wave_get(litStart, t);
+            const uint64_t d2 = wave_get64(outStart, t);
+            for (uint32_t j = lane; j < l2; j += 64) dstBase[d2 + j] = litPtr[s2 + j];
+        }
+        wave_mem_sync();
+        // matches reading only output that existed before this tile
+        const uint64_t msrc = mdst - off;
+        const bool indep = ml && (msrc + ml <= tileStart);
+        if (indep && ml <= 32) {
+            uint32_t j = 0;
+            for (; j + 8 <= ml; j += 8) { const uint64_t v = zs_load64(dstBase + msrc + j); __builtin_memcpy(dstBase + mdst + j, &v, 8); }
+            for (; j < ml; j++) dstBase[mdst + j] = dstBase[msrc + j];
+        }
+        for (uint64_t lm = __ballot(indep && ml > 32); lm; lm &= lm - 1) {
+            const int t = __builtin_ctzll(lm);
+            const uint32_t m2 = wave_get(ml, t);
+            const uint64_t s2 = wave_get64(msrc, t), d2 = wave_get64(mdst, t);
+            for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j];
+        }
+        wave_mem_sync();
+        // matches reading this tile's own output (earlier sequences are complete by then), in order
+        for (uint64_t dm = __ballot(ml && !indep); dm; dm &= dm - 1) {
+            const int t = __builtin_ctzll(dm);
+            const uint32_t m2 = wave_get(ml, t), o2 = wave_get(off, t);
+            const uint64_t s2 = wave_get64(msrc, t), d2 = wave_get64(mdst, t);
+            if (o2 >= m2) { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j]; }
+            else { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + (j % o2)]; }      // period = offset
+            wave_mem_sync();
+        }
+        op += wave_last(incl);
+        litPos += wave_last(inclL);
+    }
+    return 0;
+}
+
+// ---- sequence headers (DecodeSeqHeaders :1110-1180): number of sequences, the three tables.  ip / remaining move past them.
+//      Returns 0 or an error code. ----
+__device__ __forceinline__ uint32_t seqHeaders(DLds &L, const DState &st, const uint8_t *&ip, uint32_t &remaining, uint32_t &nbSeq)
+{
+    const uint32_t lane = (uint32_t)zs_lane();
+    {
+        if (remaining < 1) return ZE(E_srcSize_wrong);
+        const uint8_t *const iend = ip + remaining;
+        nbSeq = *ip++;
+        if (nbSeq) {
+            if (nbSeq > 0x7F) {
+                if (nbSeq == 0xFF) { if (ip + 2 > iend) return ZE(E_srcSize_wrong); nbSeq = rd16(ip) + 0x7F00; ip += 2; }
+                else { if (ip >= iend) return ZE(E_srcSize_wrong); nbSeq = ((nbSeq - 0x80) << 8) + *ip++; }
+            }
+            if (ip + 4 > iend) return ZE(E_srcSize_wrong);
+            const uint32_t modes = *ip++;
+            uint32_t consumed = 0;
+            for (int t = 0; t < 3; t++) {
+                const uint32_t type = (modes >> (6 - 2 * t)) & 3;
+                const uint32_t maxS = t == 0 ? 35 : (t == 1 ? 31 : 52), maxLog = t == 1 ? 8 : 9;
+                SeqSym *cells = t == 0 ? L.LL.cells : (t == 1 ? L.OF.cells : L.ML.cells);
+                uint32_t *tl = t == 0 ? &L.LL.tableLog : (t == 1 ? &L.OF.tableLog : &L.ML.tableLog);
+                const int16_t *dn = t == 0 ? d_LL_defaultNorm : (t == 1 ? d_OF_defaultNorm : d_ML_defaultNorm);
+                const uint32_t dmax = t == 0 ? 35 : (t == 1 ? 28 : 52);
+                if (lane == 0) {                                   // parse (serial, small): what to build and how many bytes it took
+                    uint32_t err = 0, adv = 0, bmax = 0, blog = 0;
+                    const uint8_t *p = ip + consumed;
+                    const uint32_t left = (uint32_t)(iend - p);
+                    if (type == 1) {
+                        if (!left) err = ZE(E_srcSize_wrong);
+                        else {
+                            const uint32_t symbol = *p;
+                            if (symbol > maxS) err = ZE(E_corruption_detected);
+                            else { *tl = 0; cells[0].nbBits = 0; cells[0].nextState = 0; cells[0].sym = (uint8_t)symbol; adv = 1; }
+                        }
+                    } else if (type == 0) { bmax = dmax; blog = t == 1 ? 5 : 6; }
+                    else if (type == 3) { if (!st.fseEntropy) err = ZE(E_corruption_detected); }
+                    else {
+                        uint32_t tableLog = 0, max = maxS;
+                        const uint32_t h = readNCount(L.u.tb.norm, &max, &tableLog, p, left);
+                        if (isErr(h) || tableLog > maxLog) err = ZE(E_corruption_detected);
+                        else { bmax = max; blog = tableLog; adv = h; }
+                    }
+                    L.misc[0] = err; L.misc[1] = adv; L.misc[3] = bmax; L.misc[4] = blog;
+                }
+                wave_sync();
+                if (L.misc[0]) return ZE(E_corruption_detected);
+                consumed += L.misc[1];
+                const uint32_t bmax = L.misc[3], blog = L.misc[4];
+                if (type == 0) { if (lane <= dmax) L.u.tb.norm[lane] = dn[lane]; wave_sync(); }
+                if (type == 0 || type == 2) buildSeqTableWave(L, cells, tl, bmax, blog);
+                wave_sync();
+            }
+            ip += consumed;
+            remaining = (uint32_t)(iend - ip);
+        }
+    }
+    return 0;
+}
+
+// ---- one compressed block (ZSTD_decompressBlock_internal :1868-1909). returns decoded size or error ----
+
+__device__ __forceinline__ uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, uint64_t frameStart, uint64_t op, uint64_t oend,
                                        const uint8_t *src, uint32_t srcSize, uint8_t *litBuf, uint64_t windowSize, uint64_t *g_prof)
 {
     const uint32_t lane = (uint32_t)zs_lane();
@@ -520,7 +662,7 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
             }
             const bool ok = hufDecodeStreams(L, nStreams, litBuf + sOut, sCnt, cs + sOff, sLen, g_prof);
             if (__ballot(!ok)) return ZE(E_corruption_detected);
-            __syncthreads();
+            wave_mem_sync();
             litPtr = litBuf; st.litEntropy = 1; litCSizeTot = litCSize + lhSize;
         } else {
             uint32_t lhSize;
@@ -535,7 +677,7 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                 if (litSize > (1u << 17)) return ZE(E_corruption_detected);
                 const uint8_t v = src[lhSize];
                 for (uint32_t j = lane; j < litSize; j += 64) litBuf[j] = v;
-                __syncthreads();
+                wave_mem_sync();
                 litPtr = litBuf; litCSizeTot = lhSize + 1;
             }
         }
@@ -543,60 +685,8 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
     PROF_ADD(0);
     const uint8_t *ip = src + litCSizeTot;
     uint32_t remaining = srcSize - litCSizeTot;
-    // ---- sequence headers (DecodeSeqHeaders :1110-1180) ----
     uint32_t nbSeq;
-    {
-        if (remaining < 1) return ZE(E_srcSize_wrong);
-        const uint8_t *const iend = ip + remaining;
-        nbSeq = *ip++;
-        if (nbSeq) {
-            if (nbSeq > 0x7F) {
-                if (nbSeq == 0xFF) { if (ip + 2 > iend) return ZE(E_srcSize_wrong); nbSeq = rd16(ip) + 0x7F00; ip += 2; }
-                else { if (ip >= iend) return ZE(E_srcSize_wrong); nbSeq = ((nbSeq - 0x80) << 8) + *ip++; }
-            }
-            if (ip + 4 > iend) return ZE(E_srcSize_wrong);
-            const uint32_t modes = *ip++;
-            uint32_t consumed = 0;
-            for (int t = 0; t < 3; t++) {
-                const uint32_t type = (modes >> (6 - 2 * t)) & 3;
-                const uint32_t maxS = t == 0 ? 35 : (t == 1 ? 31 : 52), maxLog = t == 1 ? 8 : 9;
-                SeqSym *cells = t == 0 ? L.LL.cells : (t == 1 ? L.OF.cells : L.ML.cells);
-                uint32_t *tl = t == 0 ? &L.LL.tableLog : (t == 1 ? &L.OF.tableLog : &L.ML.tableLog);
-                const int16_t *dn = t == 0 ? d_LL_defaultNorm : (t == 1 ? d_OF_defaultNorm : d_ML_defaultNorm);
-                const uint32_t dmax = t == 0 ? 35 : (t == 1 ? 28 : 52);
-                if (lane == 0) {                                   // parse (serial, small): what to build and how many bytes it took
-                    uint32_t err = 0, adv = 0, bmax = 0, blog = 0;
-                    const uint8_t *p = ip + consumed;
-                    const uint32_t left = (uint32_t)(iend - p);
-                    if (type == 1) {
-                        if (!left) err = ZE(E_srcSize_wrong);
-                        else {
-                            const uint32_t symbol = *p;
-                            if (symbol > maxS) err = ZE(E_corruption_detected);
-                            else { *tl = 0; cells[0].nbBits = 0; cells[0].nextState = 0; cells[0].sym = (uint8_t)symbol; adv = 1; }
-                        }
-                    } else if (type == 0) { bmax = dmax; blog = t == 1 ? 5 : 6; }
-                    else if (type == 3) { if (!st.fseEntropy) err = ZE(E_corruption_detected); }
-                    else {
-                        uint32_t tableLog = 0, max = maxS;
-                        const uint32_t h = readNCount(L.u.tb.norm, &max, &tableLog, p, left);
-                        if (isErr(h) || tableLog > maxLog) err = ZE(E_corruption_detected);
-                        else { bmax = max; blog = tableLog; adv = h; }
-                    }
-                    L.misc[0] = err; L.misc[1] = adv; L.misc[3] = bmax; L.misc[4] = blog;
-                }
-                __syncthreads();
-                if (L.misc[0]) return ZE(E_corruption_detected);
-                consumed += L.misc[1];
-                const uint32_t bmax = L.misc[3], blog = L.misc[4];
-                if (type == 0) { if (lane <= dmax) L.u.tb.norm[lane] = dn[lane]; wave_sync(); }
-                if (type == 0 || type == 2) buildSeqTableWave(L, cells, tl, bmax, blog);
-                __syncthreads();
-            }
-            ip += consumed;
-            remaining = (uint32_t)(iend - ip);
-        }
-    }
+    { const uint32_t e = seqHeaders(L, st, ip, remaining, nbSeq); if (e) return e; }
     PROF_ADD(1);
     // ---- sequences (decompressSequences_body :1555-1608) ----
     const uint64_t ostart = op;
@@ -610,7 +700,7 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
         if (!bc_init(b, ip, remaining)) return ZE(E_corruption_detected);             // same bytes for every lane: uniform
         int32_t base = bc_windowBase(b, ZS_SEQWIN);
         stageWindow(L.u.sq.win, ip, remaining, base, ZS_SEQWIN);
-        __syncthreads();
+        wave_sync();
         // one availability check per group of reads (the container holds >= 57 bits after a refill)
         #define SEQ_NEED(nbits) do { if (b.avail < (nbits)) bc_refill(b, L.u.sq.win, base); } while (0)
         if (lane == 0) { SEQ_NEED(L.LL.tableLog + L.OF.tableLog + L.ML.tableLog); sLL = bc_take(b, L.LL.tableLog); sOF = bc_take(b, L.OF.tableLog); sML = bc_take(b, L.ML.tableLog); }
@@ -621,10 +711,10 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                 const int32_t bp0 = (int32_t)wave_get((uint32_t)b.bitPos, 0);
                 const int32_t bh = (bp0 > 0) ? ((bp0 - 1) >> 3) : 0;
                 if (base > 0 && bh < base + 736) {
-                    __syncthreads();
+                    wave_sync();
                     base = (bh + 1 > (int32_t)ZS_SEQWIN) ? bh + 1 - (int32_t)ZS_SEQWIN : 0;
                     stageWindow(L.u.sq.win, ip, remaining, base, ZS_SEQWIN);
-                    __syncthreads();
+                    wave_sync();
                 }
             }
             if (lane == 0) {
@@ -661,71 +751,10 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
                 }
                 L.misc[0] = bad;
             }
-            __syncthreads();
+            wave_sync();
             PROF_ADD(2);
             if (L.misc[0]) return ZE(E_corruption_detected);
-            // execute the tile (ExecSequence :1265-1352).  Lane t owns sequence t: output positions by prefix sums, the checks
-            // of the reference in its order (the first failing sequence decides), then all literal runs at once, then all
-            // matches whose source lies before this tile's output at once, then the matches that read this tile's own output
-            // one after the other.
-            {
-                const uint32_t ll = (lane < T) ? L.u.sq.tileLL[lane] : 0u, ml = (lane < T) ? L.u.sq.tileML[lane] : 0u, off = (lane < T) ? L.u.sq.tileOff[lane] : 0u;
-                const uint32_t incl = wave_incl_scan(ll + ml), inclL = wave_incl_scan(ll);
-                const uint64_t outStart = op + (incl - ll - ml);              // where my literals go
-                const uint32_t litStart = litPos + (inclL - ll);
-                const uint64_t mdst = outStart + ll;                          // where my match goes
-                uint32_t err = 0;
-                if (lane < T) {
-                    if ((uint64_t)ll + ml > oend - outStart || outStart > oend) err = E_dstSize_tooSmall;
-                    else if (ll > litSize - litStart || litStart > litSize) err = E_corruption_detected;
-                    else if (off > mdst - frameStart) err = E_corruption_detected;
-                }
-                const uint64_t em = __ballot(err != 0);
-                if (em) return ZE(wave_get(err, __builtin_ctzll(em)));
-                // the copies below hand bytes from lane to lane through global memory inside ONE wavefront: its memory
-                // instructions execute in order, so a wavefront-scope fence (no drain of the stores in flight) is all that is needed
-                const uint64_t tileStart = op;
-                // literals
-                if (ll && ll <= 16) {
-                    if (litStart + 16 <= litSize) {
-                        const uint64_t a = zs_load64(litPtr + litStart), c = zs_load64(litPtr + litStart + 8);
-                        for (uint32_t j = 0; j < ll; j++) dstBase[outStart + j] = (uint8_t)(j < 8 ? a >> (8 * j) : c >> (8 * (j - 8)));
-                    } else for (uint32_t j = 0; j < ll; j++) dstBase[outStart + j] = litPtr[litStart + j];
-                }
-                for (uint64_t lm = __ballot(ll > 16); lm; lm &= lm - 1) {
-                    const int t = __builtin_ctzll(lm);
-                    const uint32_t l2 = wave_get(ll, t), s2 = wave_get(litStart, t);
-                    const uint64_t d2 = wave_get64(outStart, t);
-                    for (uint32_t j = lane; j < l2; j += 64) dstBase[d2 + j] = litPtr[s2 + j];
-                }
-                wave_sync();
-                // matches reading only output that existed before this tile
-                const uint64_t msrc = mdst - off;
-                const bool indep = ml && (msrc + ml <= tileStart);
-                if (indep && ml <= 32) {
-                    uint32_t j = 0;
-                    for (; j + 8 <= ml; j += 8) { const uint64_t v = zs_load64(dstBase + msrc + j); __builtin_memcpy(dstBase + mdst + j, &v, 8); }
-                    for (; j < ml; j++) dstBase[mdst + j] = dstBase[msrc + j];
-                }
-                for (uint64_t lm = __ballot(indep && ml > 32); lm; lm &= lm - 1) {
-                    const int t = __builtin_ctzll(lm);
-                    const uint32_t m2 = wave_get(ml, t);
-                    const uint64_t s2 = wave_get64(msrc, t), d2 = wave_get64(mdst, t);
-                    for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j];
-                }
-                wave_sync();
-                // matches reading this tile's own output (earlier sequences are complete by then), in order
-                for (uint64_t dm = __ballot(ml && !indep); dm; dm &= dm - 1) {
-                    const int t = __builtin_ctzll(dm);
-                    const uint32_t m2 = wave_get(ml, t), o2 = wave_get(off, t);
-                    const uint64_t s2 = wave_get64(msrc, t), d2 = wave_get64(mdst, t);
-                    if (o2 >= m2) { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j]; }
-                    else { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + (j % o2)]; }      // period = offset
-                    wave_sync();
-                }
-                op += wave_last(incl);
-                litPos += wave_last(inclL);
-            }
+            { const uint32_t e = execTile(L, T, dstBase, frameStart, oend, litPtr, litSize, op, litPos); if (e) return e; }
             PROF_ADD(3);
             left -= T;
         }
@@ -738,23 +767,33 @@ __device__ static uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, ui
         for (uint32_t j = lane; j < lastLL; j += 64) dstBase[op + j] = litPtr[litPos + j];
         op += lastLL;
     }
-    __syncthreads();
+    wave_mem_sync();
     return (uint32_t)(op - ostart);
 }
 
-extern "C" __global__ void __launch_bounds__(64)
-k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint8_t *dstAll,
+#ifndef ZS_DEC_GROUP
+#define ZS_DEC_GROUP 2             // items (= wavefronts) per workgroup
+#endif
+// every synchronisation inside an item is wavefront-local (wave_sync): the wavefronts of a workgroup run independently.
+// Every function that touches the LDS workspace is force-inlined: through a call the workspace reference becomes a generic
+// pointer and its accesses flat_* instructions, which complete out of order with the ds_* accesses of the inlined code.
+template <int F>
+__global__ void __launch_bounds__(64 * F)
+k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, uint8_t *dstAll,
                 uint32_t *__restrict__ dstSizes, uint8_t *__restrict__ litScratchAll)
 {
-    __shared__ DLds L;
-    const ZsDecItem it = items[blockIdx.x];
+    __shared__ DLds LS[F];
+    const uint32_t item = blockIdx.x * F + (threadIdx.x >> 6);
+    if (item >= nItems) return;
+    DLds &L = LS[threadIdx.x >> 6];
+    const ZsDecItem it = items[item];
     const uint32_t lane = (uint32_t)zs_lane();
     const uint8_t *src = srcAll + it.srcOff;
     uint8_t *dstBase = dstAll + it.dstOff;
-    uint8_t *litBuf = litScratchAll + (size_t)blockIdx.x * ((1u << 17) + 64);
+    uint8_t *litBuf = litScratchAll + (size_t)item * ((1u << 17) + 64);
     if (lane < 36) L.llTab[lane] = d_LL_base[lane] | ((uint32_t)d_LL_bits[lane] << 24);
     if (lane < 53) L.mlTab[lane] = d_ML_base[lane] | ((uint32_t)d_ML_bits[lane] << 24);
-    __syncthreads();
+    wave_sync();
     uint64_t *g_prof = nullptr;
 #ifdef ZS_DEC_PROFILE
     if (lane == 0) { g_prof = reinterpret_cast<uint64_t *>(litBuf + (1u << 17)); for (int k = 0; k < 8; k++) g_prof[k] = 0; }
@@ -823,14 +862,14 @@ k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
                 decoded = cSize;
             }
             op += decoded; ipos += cBlockSize;
-            __syncthreads();
+            wave_mem_sync();
             if (lastBlock) break;
         }
         if (fcs != ~0ull && (op - frameStart) != fcs) DONE(ZE(E_corruption_detected));
         if (checksumFlag) {
             if (srcSize - ipos < 4) DONE(ZE(E_checksum_wrong));
             if (lane == 0) L.misc[2] = (uint32_t)xxh64(dstBase + frameStart, op - frameStart);
-            __syncthreads();
+            wave_sync();
             if (rd32(src + ipos) != L.misc[2]) DONE(ZE(E_checksum_wrong));
             ipos += 4;
         }
@@ -841,6 +880,6 @@ finish:
 #ifdef ZS_DEC_PROFILE
     if (g_prof) g_prof[5] = __builtin_readcyclecounter() - prof_start_;
 #endif
-    if (lane == 0) dstSizes[blockIdx.x] = result;
+    if (lane == 0) dstSizes[item] = result;
     #undef DONE
 }

@@ -338,7 +338,7 @@ __device__ static uint32_t fseCompressWeights(K3Lds &L, uint8_t *dst, uint32_t c
 
 // Huffman table description (inverse of ReadStats, EntropyCommon.cs:198-269).  One lane; L.weights[0..maxSym) and the
 // histogram of those weights are already filled.
-__device__ static uint32_t writeHuffHeader(K3Lds &L, uint8_t *dst, uint32_t cap, uint32_t maxSym, uint32_t tableLog)
+__device__ __forceinline__ uint32_t writeHuffHeader(K3Lds &L, uint8_t *dst, uint32_t cap, uint32_t maxSym, uint32_t tableLog)
 {
     uint8_t *weights = L.weights;
     if (maxSym >= 2 && cap > 1) {
@@ -442,7 +442,7 @@ __device__ static void huffCodesAndWeights(K3Lds &L, uint32_t maxSym, uint32_t t
 }
 
 // one Huffman stream of lits[from .. from+len) into tmp (4-byte aligned); last symbol first. returns bytes.
-__device__ static uint32_t huffEncodeStream(K3Lds &L, uint32_t *tile, uint8_t *tmp, const uint8_t *lits, uint32_t from, uint32_t len)
+__device__ __forceinline__ uint32_t huffEncodeStream(K3Lds &L, uint32_t *tile, uint8_t *tmp, const uint8_t *lits, uint32_t from, uint32_t len)
 {
     const uint32_t lane = (uint32_t)zs_lane();
     BitSink sink; sink_init(sink, tmp, tile);

@@ -370,8 +370,8 @@ extern "C" int zsmi_decompressBatchDevice(zsmi_ctx *c, const void *dSrc, const u
     if (!c->dLitScratch.reserve((size_t)cap * ((1u << 17) + 64))) return ZSMI_error_memory_allocation;
     for (uint32_t i0 = 0; i0 < n; i0 += cap) {
         const uint32_t cnt = std::min(cap, n - i0);
-        LAUNCH(c, "k_decode_frames", k_decode_frames, dim3(cnt), dim3(64), 0, (const uint8_t *)dSrc, (const ZsDecItem *)c->dItems.p + i0, (uint8_t *)dDst,
-               dDstSizes + i0, (uint8_t *)c->dLitScratch.p);
+        LAUNCH(c, "k_decode_frames", (k_decode_frames<ZS_DEC_GROUP>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc,
+               (const ZsDecItem *)c->dItems.p + i0, cnt, (uint8_t *)dDst, dDstSizes + i0, (uint8_t *)c->dLitScratch.p);
     }
     return hipGetLastError() == hipSuccess ? 0 : ZSMI_error_GENERIC;
 }
