@@ -98,6 +98,34 @@ def test_decode_errors_match_oracle(codec):
             assert (0x100000000 - sz) == code == oracle_code
 
 
+def test_decode_damaged_own_frames_match_oracle(codec):
+    """frames of the batch shape (one frame, one compressed block: the decoder's fast path) with one byte damaged at random
+    places: the HIP decoder fails exactly where oracle D fails, and where D still decodes, the bytes agree"""
+    data = D.zipf_log(1 << 20, seed_lo=31)
+    rng = np.random.default_rng(17)
+    frames, caps = [], []
+    for i in range(8):
+        c = data[i * 32768:(i + 1) * 32768].tobytes()
+        f = O.compress(c, 3)
+        frames.append(f); caps.append(len(c))                                   # undamaged: must decode
+        for _ in range(40):
+            b = bytearray(f); pos = int(rng.integers(0, len(f))); b[pos] ^= int(rng.integers(1, 256))
+            frames.append(bytes(b)); caps.append(len(c))
+    res = _decompress_many(codec, frames, caps)
+    nerr = 0
+    for fr, cap, (sz, got) in zip(frames, caps, res):
+        try:
+            want = O.decompress(fr, cap)
+        except O.OracleError:
+            want = None
+        if want is None:
+            nerr += 1
+            assert sz > ERR
+        else:
+            assert sz == len(want) and got == want
+    assert nerr > 100                                                            # most single-byte damage is detected
+
+
 def test_decode_truncations(codec):
     frame, want = D.fixtures()["small_text_l3"]
     frames = [frame[:c] for c in range(1, len(frame))]

@@ -1,0 +1,421 @@
+// Fast decode path for the shape the batch codec itself produces and BASELINE config 4 names: an item that is exactly
+// one frame with one compressed block, no checksum.  The serial entropy decoders run lane-parallel ACROSS frames:
+//
+//   k_dec_prep      one wavefront per item : headers, Huffman table, sequence tables (all lanes, same code as the general
+//                                            decoder) -> tables + a descriptor in global memory; decides fast / general
+//   k_dec_huffman   one wavefront per 16 items: lane 4g + k decodes Huffman stream k of item g (64 streams at once)
+//   k_dec_sequences one wavefront per 16 items: lane g decodes the sequences of item g (FSE states, recent offsets)
+//   k_dec_execute   one wavefront per item : literal / match copies of the decoded sequences (execTile of the general decoder)
+//
+// Anything unusual -- another frame shape, a table the fast kernels do not hold (Huffman log 12, > 16384 sequences),
+// a stream that does not end exactly, a failed check while executing -- clears the item's fast flag, and the general
+// kernel (k_decode_frames, same reference semantics and error codes) decodes it afterwards from scratch.  So the fast
+// path only ever has to be right about VALID frames; the error behaviour stays that of decode_kernels.hip.
+//
+// Reference functions restated: see decode_kernels.hip (same helpers: readHufTable, seqHeaders, execTile, BitC readers).
+#include "zsmi_device.h"
+
+#define ZS_FAST_HUFLOG   11u                      // Huffman tables the fast kernel holds: 2^11 entries per item
+#define ZS_FAST_MAXSEQ   16384u                   // sequences per block the fast path buffers (8 bytes each)
+#define ZS_FAST_HUFWIN   128u                     // bytes of each Huffman stream staged in LDS at a time
+#define ZS_FAST_SEQWIN   256u                     // bytes of each sequence bitstream staged in LDS at a time
+#define ZS_FAST_GROUP    16u                      // items per wavefront of the Huffman kernel (4 lanes each)
+#ifndef ZS_FAST_SEQGROUP
+#define ZS_FAST_SEQGROUP 4u                       // items per wavefront of the sequences kernel (5 KiB of tables each); measured 4: 4.7 ms, 8: 5.2, 16: 5.1
+#endif
+
+struct ZsFastDesc {                               // per item, global memory, written by k_dec_prep
+    uint32_t fast;                                // 1: the fast kernels own this item; any of them may clear it
+    uint32_t litType;                             // 0 raw (bytes in the source), 1 RLE, 2 Huffman
+    uint32_t litSize;
+    uint32_t litSrc;                              // raw: offset of the literals in the item's source; RLE: the byte
+    uint32_t hufLog, nStreams;
+    uint32_t sOff[4], sLen[4], sCnt[4], sOut[4];  // Huffman streams: source offset, bytes, symbols, offset in the literal scratch
+    uint32_t nbSeq, seqOff, seqSize;              // sequence bitstream inside the item's source
+    uint32_t llLog, ofLog, mlLog;
+    uint32_t contentSize, hasContentSize;
+    uint32_t pad[2];
+};
+#define ZS_FAST_HUFTAB_BYTES (2u << ZS_FAST_HUFLOG)                       // uint16 entries
+#define ZS_FAST_SEQTAB_BYTES ((512u + 256u + 512u) * 4u)                  // LL, OF, ML cells
+// one decoded sequence, 8 bytes (one store by the decoding lane): literal length 18 bits, match length 18 bits, offset 28 bits
+typedef uint64_t ZsFastSeq;
+__device__ __forceinline__ ZsFastSeq zs_fastseq(uint32_t ll, uint32_t ml, uint32_t off) { return (uint64_t)ll | ((uint64_t)ml << 18) | ((uint64_t)off << 36); }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_dec_prep
+// ---------------------------------------------------------------------------------------------------------------------
+template <int F>
+__global__ void __launch_bounds__(64 * F)
+k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems,
+           ZsFastDesc *__restrict__ descs, uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ seqTabs)
+{
+    __shared__ DLds LS[F];
+    const uint32_t item = blockIdx.x * F + (threadIdx.x >> 6);
+    if (item >= nItems) return;
+    DLds &L = LS[threadIdx.x >> 6];
+    const ZsDecItem it = items[item];
+    const uint32_t lane = (uint32_t)zs_lane();
+    const uint8_t *src = srcAll + it.srcOff;
+    const uint32_t srcSize = it.srcSize;
+    ZsFastDesc d;
+    d.fast = 0; d.litType = 0; d.litSize = 0; d.litSrc = 0; d.hufLog = 0; d.nStreams = 0;
+    for (int k = 0; k < 4; k++) { d.sOff[k] = d.sLen[k] = d.sCnt[k] = d.sOut[k] = 0; }
+    d.nbSeq = d.seqOff = d.seqSize = 0; d.llLog = d.ofLog = d.mlLog = 0; d.contentSize = 0; d.hasContentSize = 0; d.pad[0] = d.pad[1] = 0;
+    if (lane < 36) L.llTab[lane] = d_LL_base[lane] | ((uint32_t)d_LL_bits[lane] << 24);
+    if (lane < 53) L.mlTab[lane] = d_ML_base[lane] | ((uint32_t)d_ML_bits[lane] << 24);
+    wave_sync();
+    do {
+        // ---- frame header (:389-499): one frame, no dictionary, no checksum ----
+        if (srcSize < 5 + 1 + 3 || rd32(src) != 0xFD2FB528u) break;
+        const uint32_t fhd = src[4];
+        const uint32_t dictIDCode = fhd & 3, checksumFlag = (fhd >> 2) & 1, singleSegment = (fhd >> 5) & 1, fcsID = fhd >> 6;
+        if (dictIDCode || checksumFlag || (fhd & 0x08)) break;
+        const uint32_t fcsSize = fcsID == 0 ? 0 : (fcsID == 1 ? 2 : (fcsID == 2 ? 4 : 8));
+        const uint32_t fhs = 5 + !singleSegment + fcsSize + (singleSegment && !fcsID);
+        if (srcSize < fhs + 3) break;
+        uint32_t pos = 5;
+        if (!singleSegment) { const uint32_t wl = src[pos++]; if ((wl >> 3) + 10 > 30) break; }
+        uint64_t fcs = ~0ull;
+        if (fcsID == 0) { if (singleSegment) fcs = src[pos]; } else if (fcsID == 1) fcs = rd16(src + pos) + 256; else if (fcsID == 2) fcs = rd32(src + pos); else fcs = zs_load64(src + pos);
+        if (fcs != ~0ull && fcs > 0xFFFFFFFFull) break;
+        d.hasContentSize = fcs != ~0ull; d.contentSize = (uint32_t)fcs;
+        // ---- the one block (:646-659): last, compressed, filling the rest of the item ----
+        const uint32_t bh = rd24(src + fhs);
+        const uint32_t lastBlock = bh & 1, btype = (bh >> 1) & 3, cSize = bh >> 3;
+        if (!lastBlock || btype != 2 || cSize >= (1u << 17) || cSize < 3) break;
+        if ((uint64_t)fhs + 3 + cSize != srcSize) break;
+        const uint32_t b0 = fhs + 3;                               // block payload offset in the item
+        const uint8_t *bs = src + b0;
+        // ---- literals section header (:683-821) ----
+        uint32_t litCSizeTot;
+        {
+            const uint32_t type = bs[0] & 3, lhl = (bs[0] >> 2) & 3;
+            if (type == 3) break;                                   // treeless: not in a first block
+            if (type == 2) {
+                if (cSize < 5) break;
+                const uint32_t lhc = rd32(bs);
+                uint32_t lhSize, litSize, litCSize; bool single = false;
+                if (lhl < 2) { single = !lhl; lhSize = 3; litSize = (lhc >> 4) & 0x3FF; litCSize = (lhc >> 14) & 0x3FF; }
+                else if (lhl == 2) { lhSize = 4; litSize = (lhc >> 4) & 0x3FFF; litCSize = lhc >> 18; }
+                else { lhSize = 5; litSize = (lhc >> 4) & 0x3FFFF; litCSize = (lhc >> 22) + ((uint32_t)bs[4] << 10); }
+                if (litSize > (1u << 17) || litCSize + lhSize > cSize) break;
+                if (!single && (litSize == 0 || litCSize == 0)) break;
+                const uint32_t h = readHufTable(L, bs + lhSize, litCSize);
+                if (isErr(h) || h >= litCSize || L.hufLog > ZS_FAST_HUFLOG) break;
+                const uint32_t cs0 = b0 + lhSize + h, csz = litCSize - h;
+                d.litType = 2; d.litSize = litSize; d.hufLog = L.hufLog;
+                if (single) { d.nStreams = 1; d.sOff[0] = cs0; d.sLen[0] = csz; d.sCnt[0] = litSize; d.sOut[0] = 0; }
+                else {
+                    if (csz < 10) break;
+                    const uint8_t *cs = src + cs0;
+                    const uint32_t l1 = rd16(cs), l2 = rd16(cs + 2), l3 = rd16(cs + 4);
+                    if (l1 + l2 + l3 + 6 > csz) break;
+                    const uint32_t seg = (litSize + 3) / 4;
+                    if (3 * seg > litSize) break;
+                    d.nStreams = 4;
+                    d.sOff[0] = cs0 + 6; d.sOff[1] = d.sOff[0] + l1; d.sOff[2] = d.sOff[1] + l2; d.sOff[3] = d.sOff[2] + l3;
+                    d.sLen[0] = l1; d.sLen[1] = l2; d.sLen[2] = l3; d.sLen[3] = csz - (l1 + l2 + l3 + 6);
+                    for (uint32_t k = 0; k < 4; k++) { d.sCnt[k] = k < 3 ? seg : litSize - 3 * seg; d.sOut[k] = k * seg; }
+                }
+                litCSizeTot = litCSize + lhSize;
+                // the table leaves for the Huffman kernel
+                uint16_t *ht = reinterpret_cast<uint16_t *>(hufTabs + (size_t)item * ZS_FAST_HUFTAB_BYTES);
+                for (uint32_t i = lane; i < (1u << L.hufLog); i += 64) ht[i] = L.huf[i];
+            } else {
+                uint32_t lhSize, litSize;
+                if (lhl == 1) { lhSize = 2; litSize = rd16(bs) >> 4; }
+                else if (lhl == 3) { lhSize = 3; litSize = rd24(bs) >> 4; }
+                else { lhSize = 1; litSize = bs[0] >> 3; }
+                if (type == 0) { if (litSize + lhSize > cSize) break; d.litType = 0; d.litSrc = b0 + lhSize; litCSizeTot = lhSize + litSize; }
+                else { if (lhSize + 1 > cSize || litSize > (1u << 17)) break; d.litType = 1; d.litSrc = bs[lhSize]; litCSizeTot = lhSize + 1; }
+                d.litSize = litSize;
+            }
+        }
+        if (litCSizeTot > cSize) break;
+        // ---- sequence headers + tables (:1110-1180), then the tables leave for the sequences kernel ----
+        const uint8_t *ip = bs + litCSizeTot; uint32_t remaining = cSize - litCSizeTot, nbSeq = 0;
+        DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = 0; st.llRepeatOk = 0;
+        if (seqHeaders(L, st, ip, remaining, nbSeq)) break;
+        if (nbSeq > ZS_FAST_MAXSEQ) break;
+        if (nbSeq == 0 && remaining != 0) break;
+        d.nbSeq = nbSeq; d.seqOff = (uint32_t)(ip - src); d.seqSize = remaining;
+        if (nbSeq) {
+            d.llLog = L.LL.tableLog; d.ofLog = L.OF.tableLog; d.mlLog = L.ML.tableLog;
+            uint32_t *stab = reinterpret_cast<uint32_t *>(seqTabs + (size_t)item * ZS_FAST_SEQTAB_BYTES);
+            for (uint32_t i = lane; i < (1u << d.llLog); i += 64) stab[i] = *reinterpret_cast<const uint32_t *>(&L.LL.cells[i]);
+            for (uint32_t i = lane; i < (1u << d.ofLog); i += 64) stab[512 + i] = *reinterpret_cast<const uint32_t *>(&L.OF.cells[i]);
+            for (uint32_t i = lane; i < (1u << d.mlLog); i += 64) stab[768 + i] = *reinterpret_cast<const uint32_t *>(&L.ML.cells[i]);
+        }
+        d.fast = 1;
+    } while (0);
+    if (lane == 0) descs[item] = d;
+}
+
+// A lane stages the window of ITS OWN stream: win[] <- stream bytes [base - 8, base + W), zero outside [0, size).
+// All the loads of a window are independent, so they overlap (a loop over streams with one load each serialises a memory
+// round trip per stream: that was 90 % of these kernels' time).
+template <uint32_t W>
+__device__ __forceinline__ void stageOwnWindow(uint32_t *win, const uint8_t *src, uint32_t size, int32_t base)
+{
+    constexpr uint32_t N = (W + 8) / 4 + 2;
+    if (size >= 4) {
+        // branch free, so that the loads of a batch are issued together: every dword comes from a clamped address and is
+        // shifted / zeroed where it sticks out of the stream
+        const int32_t last = (int32_t)size - 4;
+        #pragma unroll
+        for (uint32_t j0 = 0; j0 < N; j0 += 16) {
+            uint32_t v[16];
+            #pragma unroll
+            for (uint32_t u = 0; u < 16; u++) {
+                const int32_t p = base - 8 + 4 * (int32_t)(j0 + u);
+                const int32_t q = min(max(p, 0), last);
+                v[u] = (j0 + u < N) ? zs_load32(src + q) : 0u;
+            }
+            #pragma unroll
+            for (uint32_t u = 0; u < 16; u++) {
+                if (j0 + u < N) {
+                    const int32_t p = base - 8 + 4 * (int32_t)(j0 + u);
+                    const int32_t q = min(max(p, 0), last);
+                    const int32_t dlt = p - q;                                         // < 0: sticks out below, > 0: above
+                    uint32_t x = v[u];
+                    x = (dlt < 0) ? ((dlt > -4) ? x << (8 * (uint32_t)(-dlt)) : 0u) : ((dlt > 0) ? ((dlt < 4) ? x >> (8 * (uint32_t)dlt) : 0u) : x);
+                    win[j0 + u] = x;
+                }
+            }
+        }
+    } else {
+        for (uint32_t j = 0; j < N; j++) {
+            const int32_t p = base - 8 + 4 * (int32_t)j;
+            uint32_t v = 0;
+            for (int q = 0; q < 4; q++) { const int32_t r = p + q; if (r >= 0 && r < (int32_t)size) v |= (uint32_t)src[r] << (8 * q); }
+            win[j] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_dec_huffman : lane 4g + k = stream k of item g.  Tables in LDS (16 x 4 KiB), stream windows in LDS, refilled in rounds
+// by all lanes; symbol loop of the general decoder (four symbols per refill, then the careful tail).
+// ---------------------------------------------------------------------------------------------------------------------
+struct HufLds { uint16_t huf[ZS_FAST_GROUP][1u << ZS_FAST_HUFLOG]; uint32_t win[64][(ZS_FAST_HUFWIN + 8) / 4 + 2]; };
+
+__global__ void __launch_bounds__(64)
+k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
+              const uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ litScratchAll)
+{
+    __shared__ HufLds H;
+    const uint32_t lane = (uint32_t)zs_lane();
+    const uint32_t g = lane >> 2, k = lane & 3u;
+    const uint32_t item = blockIdx.x * ZS_FAST_GROUP + g;
+    bool mine = false; uint32_t dtLog = 1, n = 0, size = 0;
+    const uint8_t *src = srcAll; uint8_t *out = litScratchAll;
+    if (item < nItems) {
+        const ZsFastDesc *d = descs + item;
+        if (d->fast && d->litType == 2 && k < d->nStreams) {
+            mine = true; dtLog = d->hufLog; n = d->sCnt[k]; size = d->sLen[k];
+            src = srcAll + items[item].srcOff + d->sOff[k];
+            out = litScratchAll + (size_t)item * ((1u << 17) + 64) + d->sOut[k];
+        }
+    }
+    if (!__ballot(mine)) return;
+    // tables of the items that need them
+    for (uint32_t gg = 0; gg < ZS_FAST_GROUP; gg++) {
+        const uint32_t it2 = blockIdx.x * ZS_FAST_GROUP + gg;
+        const uint32_t log2 = wave_get(mine ? dtLog : 0u, (int)(gg * 4));        // stream 0 of the item exists whenever any does
+        if (!log2) continue;
+        const uint32_t *ht = reinterpret_cast<const uint32_t *>(hufTabs + (size_t)it2 * ZS_FAST_HUFTAB_BYTES);
+        uint32_t *dstw = reinterpret_cast<uint32_t *>(H.huf[gg]);
+        {   // <= 16 dwords per lane, the loads issued together
+            const uint32_t words = (1u << log2) / 2;
+            uint32_t v[16];
+            #pragma unroll
+            for (uint32_t u = 0; u < 16; u++) v[u] = (lane + 64 * u < words) ? ht[lane + 64 * u] : 0u;
+            #pragma unroll
+            for (uint32_t u = 0; u < 16; u++) if (lane + 64 * u < words) dstw[lane + 64 * u] = v[u];
+        }
+    }
+    BitC b; b.c = 0; b.avail = 0; b.bitPos = 0;
+    bool ok = !mine || bc_init(b, src, size);
+    uint32_t i = 0;
+    bool done = !mine || !ok || n == 0;
+    const uint16_t *huf = H.huf[g];
+    const uint32_t *win = H.win[lane];
+    const uint32_t sh = 32u - dtLog;
+    for (;;) {
+        const int32_t base = bc_windowBase(b, ZS_FAST_HUFWIN);
+        wave_sync();
+        if (!done) stageOwnWindow<ZS_FAST_HUFWIN>(H.win[lane], src, size, base);
+        wave_sync();
+        if (!done) {
+            while (i + 4 <= n) {
+                const int32_t bh = (b.bitPos - 1) >> 3;
+                if (b.bitPos < 64 || (base > 0 && bh < base + 16)) break;
+                uint64_t c = win64(win, (uint32_t)(bh - base + 1)) << (7u - (uint32_t)((b.bitPos - 1) & 7));
+                uint32_t used = 0, pack = 0;
+                #pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t e = huf[(uint32_t)(c >> 32) >> sh];
+                    const uint32_t nb = e >> 8;
+                    c <<= nb; used += nb; pack |= (e & 0xFFu) << (8 * q);
+                }
+                b.bitPos -= (int32_t)used;
+                __builtin_memcpy(out + i, &pack, 4);
+                i += 4;
+            }
+            b.avail = 0;
+            while (i < n) {
+                if (b.avail < dtLog) {
+                    if (b.bitPos > 0 && base > 0 && ((b.bitPos - 1) >> 3) < base + 8) break;
+                    bc_refill(b, win, base);
+                }
+                const uint32_t e = huf[(uint32_t)(b.c >> 32) >> sh];
+                const uint32_t nb = e >> 8;
+                b.c <<= nb; b.avail -= nb; b.bitPos -= (int32_t)nb;
+                out[i++] = (uint8_t)e;
+            }
+            if (i == n) done = true;
+        }
+        if (!__ballot(!done)) break;
+    }
+    // a stream must end exactly (BitStream.cs:494); otherwise the general decoder takes the item
+    if (mine && (!ok || b.bitPos != 0)) descs[item].fast = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_dec_sequences : lane g = item g of the group.  Tables in LDS (16 x 5 KiB), bitstream windows in LDS.
+// The per-sequence code is decodeBlock's (:1473-1553); results go to global memory, 12 bytes a sequence.
+// ---------------------------------------------------------------------------------------------------------------------
+struct SeqDecLds { uint32_t cells[ZS_FAST_SEQGROUP][1280]; uint32_t win[ZS_FAST_SEQGROUP][(ZS_FAST_SEQWIN + 8) / 4 + 2]; uint32_t llTab[36], mlTab[53]; };
+
+__global__ void __launch_bounds__(64)
+k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
+                const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll)
+{
+    __shared__ SeqDecLds S;
+    const uint32_t lane = (uint32_t)zs_lane();
+    const uint32_t item = blockIdx.x * ZS_FAST_SEQGROUP + lane;
+    bool mine = false; uint32_t nbSeq = 0, size = 0, llLog = 0, ofLog = 0, mlLog = 0;
+    const uint8_t *src = srcAll;
+    if (lane < ZS_FAST_SEQGROUP && item < nItems) {
+        const ZsFastDesc *d = descs + item;
+        if (d->fast && d->nbSeq) { mine = true; nbSeq = d->nbSeq; size = d->seqSize; llLog = d->llLog; ofLog = d->ofLog; mlLog = d->mlLog; src = srcAll + items[item].srcOff + d->seqOff; }
+    }
+    if (!__ballot(mine)) return;
+    if (lane < 36) S.llTab[lane] = d_LL_base[lane] | ((uint32_t)d_LL_bits[lane] << 24);
+    if (lane < 53) S.mlTab[lane] = d_ML_base[lane] | ((uint32_t)d_ML_bits[lane] << 24);
+    for (uint32_t gg = 0; gg < ZS_FAST_SEQGROUP; gg++) {
+        if (!wave_get(mine ? 1u : 0u, (int)gg)) continue;
+        const uint32_t *st = reinterpret_cast<const uint32_t *>(seqTabs + (size_t)(blockIdx.x * ZS_FAST_SEQGROUP + gg) * ZS_FAST_SEQTAB_BYTES);
+        const uint32_t a = 1u << wave_get(llLog, (int)gg), o = 1u << wave_get(ofLog, (int)gg), m = 1u << wave_get(mlLog, (int)gg);
+        {   // the three tables: every load issued before the first LDS store (up to 8 + 4 + 8 dwords per lane)
+            uint32_t va[8], vo[4], vm[8];
+            #pragma unroll
+            for (uint32_t u = 0; u < 8; u++) va[u] = (lane + 64 * u < a) ? st[lane + 64 * u] : 0u;
+            #pragma unroll
+            for (uint32_t u = 0; u < 4; u++) vo[u] = (lane + 64 * u < o) ? st[512 + lane + 64 * u] : 0u;
+            #pragma unroll
+            for (uint32_t u = 0; u < 8; u++) vm[u] = (lane + 64 * u < m) ? st[768 + lane + 64 * u] : 0u;
+            #pragma unroll
+            for (uint32_t u = 0; u < 8; u++) if (lane + 64 * u < a) S.cells[gg][lane + 64 * u] = va[u];
+            #pragma unroll
+            for (uint32_t u = 0; u < 4; u++) if (lane + 64 * u < o) S.cells[gg][512 + lane + 64 * u] = vo[u];
+            #pragma unroll
+            for (uint32_t u = 0; u < 8; u++) if (lane + 64 * u < m) S.cells[gg][768 + lane + 64 * u] = vm[u];
+        }
+    }
+    BitC b; b.c = 0; b.avail = 0; b.bitPos = 0;
+    bool ok = !mine || bc_init(b, src, size);
+    const uint32_t *cells = S.cells[lane & (ZS_FAST_SEQGROUP - 1)];
+    const uint32_t *win = S.win[lane & (ZS_FAST_SEQGROUP - 1)];
+    ZsFastSeq *outp = seqOutAll + (size_t)item * ZS_FAST_MAXSEQ;
+    uint32_t sLL = 0, sOF = 0, sML = 0, rep0 = 1, rep1 = 4, rep2 = 8, t = 0;
+    bool started = false, done = !mine || !ok;
+    #define FSEQ_NEED(nbits) do { if (b.avail < (nbits)) bc_refill(b, win, base); } while (0)
+    for (;;) {
+        const int32_t base = bc_windowBase(b, ZS_FAST_SEQWIN);
+        wave_sync();
+        if (!done) stageOwnWindow<ZS_FAST_SEQWIN>(S.win[lane & (ZS_FAST_SEQGROUP - 1)], src, size, base);
+        wave_sync();
+        if (!done) {
+            if (!started) { FSEQ_NEED(llLog + ofLog + mlLog); sLL = bc_take(b, llLog); sOF = bc_take(b, ofLog); sML = bc_take(b, mlLog); started = true; }
+            while (t < nbSeq) {
+                // a sequence reads < 12 bytes of stream: stop for a refill while that much is still inside the window
+                if (b.bitPos > 0 && base > 0 && ((b.bitPos - 1) >> 3) < base + 24) break;
+                if (b.bitPos < 0) { ok = false; break; }                 // stream exhausted before all sequences (:1582, :1594)
+                const uint32_t cLL = cells[sLL], cOF = cells[512 + sOF], cML = cells[768 + sML];
+                const uint32_t tLL = S.llTab[(cLL >> 24) & 0xFFu], tML = S.mlTab[(cML >> 24) & 0xFFu];
+                const uint32_t llBase = tLL & 0xFFFFFFu, llAdd = tLL >> 24, mlBase = tML & 0xFFFFFFu, mlAdd = tML >> 24, ofAdd = (cOF >> 24) & 0xFFu;
+                uint32_t offset, ml, ll;
+                if (ofAdd + mlAdd + llAdd <= 57u) {
+                    FSEQ_NEED(ofAdd + mlAdd + llAdd);
+                    offset = ofBaseOf(ofAdd) + bc_take(b, ofAdd);
+                    ml = mlBase + bc_take(b, mlAdd);
+                    ll = llBase + bc_take(b, llAdd);
+                } else {
+                    FSEQ_NEED(ofAdd); offset = ofBaseOf(ofAdd) + bc_take(b, ofAdd);
+                    FSEQ_NEED(mlAdd + llAdd); ml = mlBase + bc_take(b, mlAdd); ll = llBase + bc_take(b, llAdd);
+                }
+                if (ofAdd <= 1) {                                        // recent offsets (:1509-1530)
+                    offset += (llBase == 0);
+                    if (offset) {
+                        uint32_t temp = (offset == 3) ? rep0 - 1 : (offset == 1 ? rep1 : rep2);
+                        temp += !temp;
+                        if (offset != 1) rep2 = rep1;
+                        rep1 = rep0; rep0 = offset = temp;
+                    } else offset = rep0;
+                } else { rep2 = rep1; rep1 = rep0; rep0 = offset; }
+                const uint32_t nL = (cLL >> 16) & 0xFFu, nM = (cML >> 16) & 0xFFu, nO = (cOF >> 16) & 0xFFu;
+                FSEQ_NEED(nL + nM + nO);
+                sLL = (cLL & 0xFFFFu) + bc_take(b, nL);
+                sML = (cML & 0xFFFFu) + bc_take(b, nM);
+                sOF = (cOF & 0xFFFFu) + bc_take(b, nO);
+                if ((ll | ml) >> 18 || offset >> 28) { ok = false; break; }      // does not fit the record: the general decoder takes the item
+                outp[t++] = zs_fastseq(ll, ml, offset);
+            }
+            if (t == nbSeq || !ok) done = true;
+        }
+        if (!__ballot(!done)) break;
+    }
+    #undef FSEQ_NEED
+    if (mine && !ok) descs[item].fast = 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_dec_execute : one wavefront per item: the decoded sequences, 64 at a time, through execTile; last literals; size check.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int F>
+__global__ void __launch_bounds__(64 * F)
+k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
+              const ZsFastSeq *__restrict__ seqAll, uint8_t *__restrict__ litScratchAll, uint8_t *dstAll, uint32_t *__restrict__ dstSizes)
+{
+    __shared__ uint32_t tiles[F][3][64];
+    const uint32_t w = threadIdx.x >> 6, lane = (uint32_t)zs_lane();
+    const uint32_t item = blockIdx.x * F + w;
+    if (item >= nItems) return;
+    const ZsFastDesc d = descs[item];
+    if (!d.fast) return;
+    const ZsDecItem it = items[item];
+    uint8_t *dstBase = dstAll + it.dstOff;
+    const uint64_t oend = it.dstCap;
+    uint8_t *litBuf = litScratchAll + (size_t)item * ((1u << 17) + 64);
+    const uint8_t *litPtr = litBuf;
+    if (d.litType == 0) litPtr = srcAll + it.srcOff + d.litSrc;
+    else if (d.litType == 1) { for (uint32_t j = lane; j < d.litSize; j += 64) litBuf[j] = (uint8_t)d.litSrc; wave_mem_sync(); }
+    const ZsFastSeq *seqs = seqAll + (size_t)item * ZS_FAST_MAXSEQ;
+    uint64_t op = 0; uint32_t litPos = 0; bool bad = false;
+    for (uint32_t t0 = 0; t0 < d.nbSeq; t0 += 64) {
+        const uint32_t T = min(64u, d.nbSeq - t0);
+        if (lane < T) { const ZsFastSeq r = seqs[t0 + lane]; tiles[w][0][lane] = (uint32_t)r & 0x3FFFFu; tiles[w][1][lane] = (uint32_t)(r >> 18) & 0x3FFFFu; tiles[w][2][lane] = (uint32_t)(r >> 36); }
+        wave_sync();
+        if (execTile(tiles[w][0], tiles[w][1], tiles[w][2], T, dstBase, 0, oend, litPtr, d.litSize, op, litPos)) { bad = true; break; }
+        wave_sync();
+    }
+    if (!bad) {
+        const uint32_t lastLL = d.litSize - litPos;
+        if (lastLL > oend - op) bad = true;
+        else { for (uint32_t j = lane; j < lastLL; j += 64) dstBase[op + j] = litPtr[litPos + j]; op += lastLL; }
+    }
+    if (!bad && d.hasContentSize && op != d.contentSize) bad = true;
+    if (lane == 0) { if (bad) descs[item].fast = 0; else dstSizes[item] = (uint32_t)op; }
+}

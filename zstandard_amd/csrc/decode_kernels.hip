@@ -481,8 +481,8 @@ __device__ static uint64_t xxh64(const uint8_t *p, uint64_t len)
 struct DState { uint32_t rep[3]; uint32_t litEntropy, fseEntropy; uint32_t llRepeatOk; };
 
 // ---- one tile of <= 64 decoded sequences (L.u.sq.tile*) -> output bytes.  Returns 0 or an error; advances op / litPos. ----
-__device__ __forceinline__ uint32_t execTile(DLds &L, uint32_t T, uint8_t *dstBase, uint64_t frameStart, uint64_t oend,
-                                             const uint8_t *litPtr, uint32_t litSize, uint64_t &op, uint32_t &litPos)
+__device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint32_t *tileML, const uint32_t *tileOff, uint32_t T, uint8_t *dstBase,
+                                             uint64_t frameStart, uint64_t oend, const uint8_t *litPtr, uint32_t litSize, uint64_t &op, uint32_t &litPos)
 {
     const uint32_t lane = (uint32_t)zs_lane();
     // execute the tile (ExecSequence :1265-1352).  Lane t owns sequence t: output positions by prefix sums, the checks
@@ -490,7 +490,7 @@ __device__ __forceinline__ uint32_t execTile(DLds &L, uint32_t T, uint8_t *dstBa
     // matches whose source lies before this tile's output at once, then the matches that read this tile's own output
     // one after the other.
     {
-        const uint32_t ll = (lane < T) ? L.u.sq.tileLL[lane] : 0u, ml = (lane < T) ? L.u.sq.tileML[lane] : 0u, off = (lane < T) ? L.u.sq.tileOff[lane] : 0u;
+        const uint32_t ll = (lane < T) ? tileLL[lane] : 0u, ml = (lane < T) ? tileML[lane] : 0u, off = (lane < T) ? tileOff[lane] : 0u;
         const uint32_t incl = wave_incl_scan(ll + ml), inclL = wave_incl_scan(ll);
         const uint64_t outStart = op + (incl - ll - ml);              // where my literals go
         const uint32_t litStart = litPos + (inclL - ll);
@@ -754,7 +754,7 @@ __device__ __forceinline__ uint32_t decodeBlock(DLds &L, DState &st, uint8_t *ds
             wave_sync();
             PROF_ADD(2);
             if (L.misc[0]) return ZE(E_corruption_detected);
-            { const uint32_t e = execTile(L, T, dstBase, frameStart, oend, litPtr, litSize, op, litPos); if (e) return e; }
+            { const uint32_t e = execTile(L.u.sq.tileLL, L.u.sq.tileML, L.u.sq.tileOff, T, dstBase, frameStart, oend, litPtr, litSize, op, litPos); if (e) return e; }
             PROF_ADD(3);
             left -= T;
         }
@@ -780,11 +780,12 @@ __device__ __forceinline__ uint32_t decodeBlock(DLds &L, DState &st, uint8_t *ds
 template <int F>
 __global__ void __launch_bounds__(64 * F)
 k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, uint8_t *dstAll,
-                uint32_t *__restrict__ dstSizes, uint8_t *__restrict__ litScratchAll)
+                uint32_t *__restrict__ dstSizes, uint8_t *__restrict__ litScratchAll, const uint32_t *__restrict__ doneFlags, uint32_t flagStride)
 {
     __shared__ DLds LS[F];
     const uint32_t item = blockIdx.x * F + (threadIdx.x >> 6);
     if (item >= nItems) return;
+    if (doneFlags && doneFlags[(size_t)item * flagStride]) return;        // the fast path (decode_fast.hip) has decoded this item
     DLds &L = LS[threadIdx.x >> 6];
     const ZsDecItem it = items[item];
     const uint32_t lane = (uint32_t)zs_lane();

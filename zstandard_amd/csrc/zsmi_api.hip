@@ -6,6 +6,7 @@
 #include "lz_kernels.hip"
 #include "entropy_kernels.hip"
 #include "decode_kernels.hip"
+#include "decode_fast.hip"
 #include "../../include/zsmi.h"
 
 #include <cstdio>
@@ -130,7 +131,8 @@ struct zsmi_ctx {
     std::vector<uint64_t> planKey;       // copy of (srcOffsets, srcSizes, dstOffsets) the device-side plan was built from
     uint64_t planBlocks = 0; uint32_t planMaxChunkBlocks = 1;
     // decompress workspace
-    DevBuf dItems, dLitScratch;
+    DevBuf dItems, dLitScratch, dFastDesc, dHufTabs, dSeqTabs, dSeqOut;     // decode: items, literal scratch, fast-path tables and sequences
+    bool decodeFast = true;              // ZSMI_DEC_FAST=0: general kernel only
     PinBuf hItems;
     // staging for host-buffer calls
     DevBuf sSrc, sDst, sSizes;
@@ -170,6 +172,7 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     (void)hipFuncSetAttribute((const void *)k_lz_walk<128, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_UNIT_MAX));
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_OVERLAP")) c->overlapEntropy = atoi(e) != 0;
+    if (const char *e = getenv("ZSMI_DEC_FAST")) c->decodeFast = atoi(e) != 0;
     if (const char *e = getenv("ZSMI_STOP_LIT")) c->stopLit = atoi(e);
     if (const char *e = getenv("ZSMI_STOP_SEQ")) c->stopSeq = atoi(e);
     if (const char *e = getenv("ZSMI_LANES")) { long v = atol(e); if (v >= 1 && v <= zsmi_ctx::kMaxLanes) c->nLanes = (int)v; }
@@ -186,7 +189,7 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
 {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dUnits, &c->dItems, &c->dLitScratch, &c->sSrc, &c->sDst, &c->sSizes }) b->release();
+    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dUnits, &c->dItems, &c->dLitScratch, &c->dFastDesc, &c->dHufTabs, &c->dSeqTabs, &c->dSeqOut, &c->sSrc, &c->sDst, &c->sSizes }) b->release();
     for (int i = 0; i < zsmi_ctx::kMaxLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
         if (L.stream) (void)hipStreamSynchronize(L.stream);
@@ -368,10 +371,28 @@ extern "C" int zsmi_decompressBatchDevice(zsmi_ctx *c, const void *dSrc, const u
     if (hipMemcpyAsync(c->dItems.p, hi, sizeof(ZsDecItem) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
     const uint32_t cap = std::min<uint32_t>(n, 8192);
     if (!c->dLitScratch.reserve((size_t)cap * ((1u << 17) + 64))) return ZSMI_error_memory_allocation;
+    const bool fast = c->decodeFast;
+    if (fast && (!c->dFastDesc.reserve((size_t)cap * sizeof(ZsFastDesc)) || !c->dHufTabs.reserve((size_t)cap * ZS_FAST_HUFTAB_BYTES) ||
+                 !c->dSeqTabs.reserve((size_t)cap * ZS_FAST_SEQTAB_BYTES) || !c->dSeqOut.reserve((size_t)cap * ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)))) return ZSMI_error_memory_allocation;
     for (uint32_t i0 = 0; i0 < n; i0 += cap) {
         const uint32_t cnt = std::min(cap, n - i0);
+        const ZsDecItem *dI = (const ZsDecItem *)c->dItems.p + i0;
+        const uint32_t *doneFlags = nullptr;
+        if (fast) {
+            // items that are one frame with one compressed block: entropy decoding lane-parallel across 16 items per wavefront
+            // (decode_fast.hip); whatever those kernels do not take or reject is left to the general kernel below
+            ZsFastDesc *dD = (ZsFastDesc *)c->dFastDesc.p;
+            const uint32_t groups = (cnt + ZS_FAST_GROUP - 1) / ZS_FAST_GROUP;
+            LAUNCH(c, "k_dec_prep", (k_dec_prep<ZS_DEC_GROUP>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc, dI, cnt, dD,
+                   (uint8_t *)c->dHufTabs.p, (uint8_t *)c->dSeqTabs.p);
+            LAUNCH(c, "k_dec_huffman", k_dec_huffman, dim3(groups), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p);
+            LAUNCH(c, "k_dec_sequences", k_dec_sequences, dim3((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p);
+            LAUNCH(c, "k_dec_execute", (k_dec_execute<4>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const ZsFastSeq *)c->dSeqOut.p,
+                   (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0);
+            doneFlags = &dD->fast;
+        }
         LAUNCH(c, "k_decode_frames", (k_decode_frames<ZS_DEC_GROUP>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc,
-               (const ZsDecItem *)c->dItems.p + i0, cnt, (uint8_t *)dDst, dDstSizes + i0, (uint8_t *)c->dLitScratch.p);
+               dI, cnt, (uint8_t *)dDst, dDstSizes + i0, (uint8_t *)c->dLitScratch.p, doneFlags, (uint32_t)(sizeof(ZsFastDesc) / sizeof(uint32_t)));
     }
     return hipGetLastError() == hipSuccess ? 0 : ZSMI_error_GENERIC;
 }
