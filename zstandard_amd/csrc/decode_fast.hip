@@ -38,9 +38,13 @@ struct ZsFastDesc {                               // per item, global memory, wr
 };
 #define ZS_FAST_HUFTAB_BYTES (2u << ZS_FAST_HUFLOG)                       // uint16 entries
 #define ZS_FAST_SEQTAB_BYTES ((512u + 256u + 512u) * 4u)                  // LL, OF, ML cells
-// one decoded sequence, 8 bytes (one store by the decoding lane): literal length 18 bits, match length 18 bits, offset 28 bits
+// what the sequences kernel leaves per sequence, 8 bytes: where its extra bits start in the bitstream (bit position, 20 bits)
+// and its three codes (LL 6 bits at 20, ML 6 bits at 26, OF 5 bits at 32).  The execute kernel turns that into lengths and
+// offsets, 64 sequences at a time on 64 lanes; only the FSE state chain stays serial.
 typedef uint64_t ZsFastSeq;
-__device__ __forceinline__ ZsFastSeq zs_fastseq(uint32_t ll, uint32_t ml, uint32_t off) { return (uint64_t)ll | ((uint64_t)ml << 18) | ((uint64_t)off << 36); }
+__device__ __forceinline__ ZsFastSeq zs_fastseq(uint32_t bitPos, uint32_t symLL, uint32_t symML, uint32_t symOF)
+{ return (uint64_t)(bitPos | (symLL << 20) | (symML << 26)) | ((uint64_t)symOF << 32); }
+__device__ __forceinline__ uint32_t zs_fastcell(uint32_t next, uint32_t nb, uint32_t add, uint32_t sym) { return next | (nb << 16) | (add << 20) | (sym << 25); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_dec_prep
@@ -143,9 +147,10 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
         if (nbSeq) {
             d.llLog = L.LL.tableLog; d.ofLog = L.OF.tableLog; d.mlLog = L.ML.tableLog;
             uint32_t *stab = reinterpret_cast<uint32_t *>(seqTabs + (size_t)item * ZS_FAST_SEQTAB_BYTES);
-            for (uint32_t i = lane; i < (1u << d.llLog); i += 64) stab[i] = *reinterpret_cast<const uint32_t *>(&L.LL.cells[i]);
-            for (uint32_t i = lane; i < (1u << d.ofLog); i += 64) stab[512 + i] = *reinterpret_cast<const uint32_t *>(&L.OF.cells[i]);
-            for (uint32_t i = lane; i < (1u << d.mlLog); i += 64) stab[768 + i] = *reinterpret_cast<const uint32_t *>(&L.ML.cells[i]);
+            // fast-path cell: nextState bits 0-15, nbBits 16-19, extra bits of the code 20-24, symbol 25-31
+            for (uint32_t i = lane; i < (1u << d.llLog); i += 64) { const SeqSym c = L.LL.cells[i]; stab[i] = zs_fastcell(c.nextState, c.nbBits, L.llTab[c.sym] >> 24, c.sym); }
+            for (uint32_t i = lane; i < (1u << d.ofLog); i += 64) { const SeqSym c = L.OF.cells[i]; stab[512 + i] = zs_fastcell(c.nextState, c.nbBits, c.sym, c.sym); }
+            for (uint32_t i = lane; i < (1u << d.mlLog); i += 64) { const SeqSym c = L.ML.cells[i]; stab[768 + i] = zs_fastcell(c.nextState, c.nbBits, L.mlTab[c.sym] >> 24, c.sym); }
         }
         d.fast = 1;
     } while (0);
@@ -286,7 +291,7 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
 // k_dec_sequences : lane g = item g of the group.  Tables in LDS (16 x 5 KiB), bitstream windows in LDS.
 // The per-sequence code is decodeBlock's (:1473-1553); results go to global memory, 12 bytes a sequence.
 // ---------------------------------------------------------------------------------------------------------------------
-struct SeqDecLds { uint32_t cells[ZS_FAST_SEQGROUP][1280]; uint32_t win[ZS_FAST_SEQGROUP][(ZS_FAST_SEQWIN + 8) / 4 + 2]; uint32_t llTab[36], mlTab[53]; };
+struct SeqDecLds { uint32_t cells[ZS_FAST_SEQGROUP][1280]; uint32_t win[ZS_FAST_SEQGROUP][(ZS_FAST_SEQWIN + 8) / 4 + 2]; };
 
 __global__ void __launch_bounds__(64)
 k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
@@ -302,8 +307,6 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
         if (d->fast && d->nbSeq) { mine = true; nbSeq = d->nbSeq; size = d->seqSize; llLog = d->llLog; ofLog = d->ofLog; mlLog = d->mlLog; src = srcAll + items[item].srcOff + d->seqOff; }
     }
     if (!__ballot(mine)) return;
-    if (lane < 36) S.llTab[lane] = d_LL_base[lane] | ((uint32_t)d_LL_bits[lane] << 24);
-    if (lane < 53) S.mlTab[lane] = d_ML_base[lane] | ((uint32_t)d_ML_bits[lane] << 24);
     for (uint32_t gg = 0; gg < ZS_FAST_SEQGROUP; gg++) {
         if (!wave_get(mine ? 1u : 0u, (int)gg)) continue;
         const uint32_t *st = reinterpret_cast<const uint32_t *>(seqTabs + (size_t)(blockIdx.x * ZS_FAST_SEQGROUP + gg) * ZS_FAST_SEQTAB_BYTES);
@@ -329,7 +332,7 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
     const uint32_t *cells = S.cells[lane & (ZS_FAST_SEQGROUP - 1)];
     const uint32_t *win = S.win[lane & (ZS_FAST_SEQGROUP - 1)];
     ZsFastSeq *outp = seqOutAll + (size_t)item * ZS_FAST_MAXSEQ;
-    uint32_t sLL = 0, sOF = 0, sML = 0, rep0 = 1, rep1 = 4, rep2 = 8, t = 0;
+    uint32_t sLL = 0, sOF = 0, sML = 0, t = 0;
     bool started = false, done = !mine || !ok;
     #define FSEQ_NEED(nbits) do { if (b.avail < (nbits)) bc_refill(b, win, base); } while (0)
     for (;;) {
@@ -344,34 +347,15 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
                 if (b.bitPos > 0 && base > 0 && ((b.bitPos - 1) >> 3) < base + 24) break;
                 if (b.bitPos < 0) { ok = false; break; }                 // stream exhausted before all sequences (:1582, :1594)
                 const uint32_t cLL = cells[sLL], cOF = cells[512 + sOF], cML = cells[768 + sML];
-                const uint32_t tLL = S.llTab[(cLL >> 24) & 0xFFu], tML = S.mlTab[(cML >> 24) & 0xFFu];
-                const uint32_t llBase = tLL & 0xFFFFFFu, llAdd = tLL >> 24, mlBase = tML & 0xFFFFFFu, mlAdd = tML >> 24, ofAdd = (cOF >> 24) & 0xFFu;
-                uint32_t offset, ml, ll;
-                if (ofAdd + mlAdd + llAdd <= 57u) {
-                    FSEQ_NEED(ofAdd + mlAdd + llAdd);
-                    offset = ofBaseOf(ofAdd) + bc_take(b, ofAdd);
-                    ml = mlBase + bc_take(b, mlAdd);
-                    ll = llBase + bc_take(b, llAdd);
-                } else {
-                    FSEQ_NEED(ofAdd); offset = ofBaseOf(ofAdd) + bc_take(b, ofAdd);
-                    FSEQ_NEED(mlAdd + llAdd); ml = mlBase + bc_take(b, mlAdd); ll = llBase + bc_take(b, llAdd);
-                }
-                if (ofAdd <= 1) {                                        // recent offsets (:1509-1530)
-                    offset += (llBase == 0);
-                    if (offset) {
-                        uint32_t temp = (offset == 3) ? rep0 - 1 : (offset == 1 ? rep1 : rep2);
-                        temp += !temp;
-                        if (offset != 1) rep2 = rep1;
-                        rep1 = rep0; rep0 = offset = temp;
-                    } else offset = rep0;
-                } else { rep2 = rep1; rep1 = rep0; rep0 = offset; }
-                const uint32_t nL = (cLL >> 16) & 0xFFu, nM = (cML >> 16) & 0xFFu, nO = (cOF >> 16) & 0xFFu;
-                FSEQ_NEED(nL + nM + nO);
-                sLL = (cLL & 0xFFFFu) + bc_take(b, nL);
-                sML = (cML & 0xFFFFu) + bc_take(b, nM);
-                sOF = (cOF & 0xFFFFu) + bc_take(b, nO);
-                if ((ll | ml) >> 18 || offset >> 28) { ok = false; break; }      // does not fit the record: the general decoder takes the item
-                outp[t++] = zs_fastseq(ll, ml, offset);
+                outp[t++] = zs_fastseq((uint32_t)b.bitPos, cLL >> 25, cML >> 25, cOF >> 25);
+                const uint32_t xbits = ((cLL >> 20) & 31u) + ((cML >> 20) & 31u) + ((cOF >> 20) & 31u);   // skipped here, read by the execute kernel
+                const uint32_t nL = (cLL >> 16) & 15u, nM = (cML >> 16) & 15u, nO = (cOF >> 16) & 15u, sbits = nL + nM + nO;
+                if (xbits + sbits <= 57u) { FSEQ_NEED(xbits + sbits); b.c <<= xbits; b.avail -= xbits; b.bitPos -= (int32_t)xbits; }
+                else { b.bitPos -= (int32_t)xbits; b.avail = 0; FSEQ_NEED(sbits); }
+                const uint32_t x = bc_take(b, sbits);                    // LL bits on top, then ML, then OF (:1547-1550)
+                sLL = (cLL & 0xFFFFu) + __builtin_amdgcn_ubfe(x, nM + nO, nL);
+                sML = (cML & 0xFFFFu) + __builtin_amdgcn_ubfe(x, nO, nM);
+                sOF = (cOF & 0xFFFFu) + __builtin_amdgcn_ubfe(x, 0u, nO);
             }
             if (t == nbSeq || !ok) done = true;
         }
@@ -390,8 +374,12 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
               const ZsFastSeq *__restrict__ seqAll, uint8_t *__restrict__ litScratchAll, uint8_t *dstAll, uint32_t *__restrict__ dstSizes)
 {
     __shared__ uint32_t tiles[F][3][64];
+    __shared__ uint32_t codeTabs[36 + 53];                                      // base | extra bits << 24 of the LL / ML codes
     const uint32_t w = threadIdx.x >> 6, lane = (uint32_t)zs_lane();
     const uint32_t item = blockIdx.x * F + w;
+    if (threadIdx.x < 36) codeTabs[threadIdx.x] = d_LL_base[threadIdx.x] | ((uint32_t)d_LL_bits[threadIdx.x] << 24);
+    else if (threadIdx.x >= 64 && threadIdx.x < 64 + 53) codeTabs[36 + threadIdx.x - 64] = d_ML_base[threadIdx.x - 64] | ((uint32_t)d_ML_bits[threadIdx.x - 64] << 24);
+    __syncthreads();                                                            // the only workgroup barrier: before any wavefront leaves
     if (item >= nItems) return;
     const ZsFastDesc d = descs[item];
     if (!d.fast) return;
@@ -403,10 +391,99 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     if (d.litType == 0) litPtr = srcAll + it.srcOff + d.litSrc;
     else if (d.litType == 1) { for (uint32_t j = lane; j < d.litSize; j += 64) litBuf[j] = (uint8_t)d.litSrc; wave_mem_sync(); }
     const ZsFastSeq *seqs = seqAll + (size_t)item * ZS_FAST_MAXSEQ;
+    const uint8_t *bits = srcAll + it.srcOff + d.seqOff;                        // the sequence bitstream, d.seqSize bytes
+    // the 64 stream bits below bit position p, top aligned (bit p - 1 at bit 63); bits below the stream start read as 0
+    auto bitsBelow = [&](int32_t p) -> uint64_t {
+        if (p <= 0) return 0ull;
+        const int32_t bh = (p - 1) >> 3;
+        uint64_t wv;
+        if (bh >= 7) wv = zs_load64(bits + bh - 7);
+        else { wv = 0; for (int32_t k = 0; k <= bh; k++) wv |= (uint64_t)bits[k] << (8 * (k + 7 - bh)); }
+        return wv << (7u - (uint32_t)((p - 1) & 7));
+    };
     uint64_t op = 0; uint32_t litPos = 0; bool bad = false;
+    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                                      // the list carried from tile to tile (lane 0 holds it)
     for (uint32_t t0 = 0; t0 < d.nbSeq; t0 += 64) {
         const uint32_t T = min(64u, d.nbSeq - t0);
-        if (lane < T) { const ZsFastSeq r = seqs[t0 + lane]; tiles[w][0][lane] = (uint32_t)r & 0x3FFFFu; tiles[w][1][lane] = (uint32_t)(r >> 18) & 0x3FFFFu; tiles[w][2][lane] = (uint32_t)(r >> 36); }
+        // lane t: the extra bits of sequence t0 + t (:1487-1545) -> lengths, offset value and its recent-offset class
+        if (lane < T) {
+            const ZsFastSeq r = seqs[t0 + lane];
+            const int32_t bp = (int32_t)((uint32_t)r & 0xFFFFFu);
+            const uint32_t tLL = codeTabs[((uint32_t)r >> 20) & 63u], tML = codeTabs[36 + (((uint32_t)r >> 26) & 63u)], ofAdd = (uint32_t)(r >> 32) & 31u;
+            const uint32_t llBase = tLL & 0xFFFFFFu, llAdd = tLL >> 24, mlBase = tML & 0xFFFFFFu, mlAdd = tML >> 24;
+            uint32_t ofBits, mlBits, llBits;
+            if (ofAdd + mlAdd + llAdd <= 57u) {
+                const uint64_t c = bitsBelow(bp);
+                ofBits = ofAdd ? (uint32_t)(c >> (64 - ofAdd)) : 0u;
+                const uint64_t c2 = c << ofAdd;
+                mlBits = mlAdd ? (uint32_t)(c2 >> (64 - mlAdd)) : 0u;
+                const uint64_t c3 = c2 << mlAdd;
+                llBits = llAdd ? (uint32_t)(c3 >> (64 - llAdd)) : 0u;
+            } else {
+                ofBits = (uint32_t)(bitsBelow(bp) >> (64 - ofAdd));
+                const uint64_t c2 = bitsBelow(bp - (int32_t)ofAdd);
+                mlBits = mlAdd ? (uint32_t)(c2 >> (64 - mlAdd)) : 0u;
+                const uint64_t c3 = c2 << mlAdd;
+                llBits = llAdd ? (uint32_t)(c3 >> (64 - llAdd)) : 0u;
+            }
+            const uint32_t ofVal = ofBaseOf(ofAdd) + ofBits;
+            tiles[w][0][lane] = llBase + llBits;
+            tiles[w][1][lane] = mlBase + mlBits;
+            // class in the top bits: 0..3 = recent-offset code (with the "literal length 0" shift applied), 4 = a new offset
+            tiles[w][2][lane] = (ofAdd <= 1) ? ((ofVal + (llBase == 0)) << 29) : ((4u << 29) | ofVal);
+            if (ofAdd > 28) bad = true;                                         // an offset that does not fit beside the class: general decoder
+        }
+        if (__ballot(bad)) { bad = true; break; }
+        wave_sync();
+        // recent offsets (:1509-1530).  A sequence maps the list (r0, r1, r2) to a new list whose entries are each a constant
+        // (a new offset) or one of the old entries: code 0 keeps it, 1 -> (r1, r0, r2), 2 -> (r2, r0, r1), new v -> (v, r0, r1).
+        // Such maps compose, so the list in front of every sequence comes from one wavefront scan.  (Code 3, "r0 - 1", is not
+        // of that form: a tile that has one takes the serial loop.)
+        {
+            const uint32_t v = (lane < T) ? tiles[w][2][lane] : 0u, cls = v >> 29, val = v & 0x1FFFFFFFu;
+            constexpr uint32_t R0 = 0xFFFFFFF0u, R1 = 0xFFFFFFF1u, R2 = 0xFFFFFFF2u;          // "old entry k"
+            if (!__ballot(lane < T && cls == 3u)) {
+                uint32_t m0 = (cls == 4u) ? val : ((cls == 1u) ? R1 : ((cls == 2u) ? R2 : R0));
+                uint32_t m1 = (cls == 0u) ? R1 : R0;
+                uint32_t m2 = (cls == 0u || cls == 1u) ? R2 : R1;
+                if (lane >= T) { m0 = R0; m1 = R1; m2 = R2; }
+                // inclusive scan of "mine after the other": the other covers earlier sequences
+                #define REP_STEP(ctrl, rowMask) { \
+                    const uint32_t o0 = (uint32_t)__builtin_amdgcn_update_dpp((int)R0, (int)m0, ctrl, rowMask, 0xF, false); \
+                    const uint32_t o1 = (uint32_t)__builtin_amdgcn_update_dpp((int)R1, (int)m1, ctrl, rowMask, 0xF, false); \
+                    const uint32_t o2 = (uint32_t)__builtin_amdgcn_update_dpp((int)R2, (int)m2, ctrl, rowMask, 0xF, false); \
+                    if (m0 >= R0) m0 = (m0 == R0) ? o0 : ((m0 == R1) ? o1 : o2); \
+                    if (m1 >= R0) m1 = (m1 == R0) ? o0 : ((m1 == R1) ? o1 : o2); \
+                    if (m2 >= R0) m2 = (m2 == R0) ? o0 : ((m2 == R1) ? o1 : o2); }
+                REP_STEP(0x111, 0xF) REP_STEP(0x112, 0xF) REP_STEP(0x114, 0xF) REP_STEP(0x118, 0xF) REP_STEP(0x142, 0xA) REP_STEP(0x143, 0xC)
+                #undef REP_STEP
+                // the map in front of me = the inclusive result of the lane below (identity for lane 0), applied to the carried list
+                const uint32_t e0 = (uint32_t)__builtin_amdgcn_update_dpp((int)R0, (int)m0, 0x138, 0xF, 0xF, false);
+                const uint32_t e1 = (uint32_t)__builtin_amdgcn_update_dpp((int)R1, (int)m1, 0x138, 0xF, 0xF, false);
+                const uint32_t e2 = (uint32_t)__builtin_amdgcn_update_dpp((int)R2, (int)m2, 0x138, 0xF, 0xF, false);
+                const uint32_t c0 = wave_get(rep0, 0), c1 = wave_get(rep1, 0), c2 = wave_get(rep2, 0);
+                #define REP_APPLY(x) (((x) >= R0) ? (((x) == R0) ? c0 : (((x) == R1) ? c1 : c2)) : (x))
+                const uint32_t b0 = REP_APPLY(e0), b1 = REP_APPLY(e1), b2 = REP_APPLY(e2);
+                if (lane < T) tiles[w][2][lane] = (cls == 4u) ? val : ((cls == 0u) ? b0 : ((cls == 1u) ? b1 : b2));
+                // carried list after the tile: the last sequence's inclusive map applied to the carry
+                const uint32_t l0 = wave_get(m0, (int)T - 1), l1 = wave_get(m1, (int)T - 1), l2 = wave_get(m2, (int)T - 1);
+                rep0 = REP_APPLY(l0); rep1 = REP_APPLY(l1); rep2 = REP_APPLY(l2);
+                #undef REP_APPLY
+            } else if (lane == 0) {
+                for (uint32_t t = 0; t < T; t++) {
+                    const uint32_t vv = tiles[w][2][t], cc = vv >> 29;
+                    uint32_t offset = vv & 0x1FFFFFFFu;
+                    if (cc == 4u) { rep2 = rep1; rep1 = rep0; rep0 = offset; }
+                    else if (cc) {
+                        uint32_t temp = (cc == 3) ? rep0 - 1 : (cc == 1 ? rep1 : rep2);
+                        temp += !temp;
+                        if (cc != 1) rep2 = rep1;
+                        rep1 = rep0; rep0 = offset = temp;
+                    } else offset = rep0;
+                    tiles[w][2][t] = offset;
+                }
+            }
+        }
         wave_sync();
         if (execTile(tiles[w][0], tiles[w][1], tiles[w][2], T, dstBase, 0, oend, litPtr, d.litSize, op, litPos)) { bad = true; break; }
         wave_sync();
