@@ -81,6 +81,7 @@ struct DLds {
     union {                             // one phase at a time
         struct { uint8_t weights[256]; uint16_t symStart[256]; uint32_t rank[16]; int16_t norm[64]; uint16_t symbolNext[64];
                  struct { uint16_t newState; uint8_t symbol; uint8_t nbBits; } wfse[64];   // weight FSE table (tableLog <= 6)
+                 uint32_t hdrWin[66];                                                        // the header being parsed: 256 bytes + zero pad
                } tb;                                                                        // a table is being parsed / built
         uint32_t litWin[4][(ZS_LITWIN + 8) / 4 + 2];                                        // the Huffman streams run
         struct { uint32_t tileLL[64], tileML[64], tileOff[64]; uint32_t win[(ZS_SEQWIN + 8) / 4 + 2]; } sq;   // sequences run
@@ -133,13 +134,35 @@ __device__ __forceinline__ uint32_t br_look(BitR &b, uint32_t n)
 }
 __device__ __forceinline__ uint32_t br_read(BitR &b, uint32_t n) { const uint32_t v = br_look(b, n); b.bitPos -= n; return v; }
 
-// ---- ReadNCount (EntropyCommon.cs:79-188), lane 0 ----
-__device__ __forceinline__ uint32_t readNCount(int16_t *norm, uint32_t *maxSVPtr, uint32_t *tableLogPtr, const uint8_t *hdr, uint32_t hbSize)
+// ---- a header region staged in LDS (all lanes load 4 bytes each: 256 bytes, zero beyond the region), read by the serial
+//      parsers below, which run on one lane: a global load inside them is a memory round trip per few bits.
+//      (Keeping the window in registers and reading it with v_readlane inside the one-lane branch is NOT safe: register
+//      copies made under the one-lane exec mask drop the other lanes' values.) ----
+__device__ __forceinline__ void hw_stage(uint32_t *win, const uint8_t *p, uint32_t size)
 {
-    const uint8_t *const istart = hdr; const uint8_t *const iend = istart + hbSize; const uint8_t *ip = istart;
+    const uint32_t lane = (uint32_t)zs_lane(), o = 4u * lane;
+    uint32_t v = 0;
+    if (o + 4 <= size) v = zs_load32(p + o);
+    else for (uint32_t k = 0; k < 4; k++) if (o + k < size) v |= (uint32_t)p[o + k] << (8 * k);
+    win[lane] = v;
+    if (lane < 2) win[64 + lane] = 0;
+    wave_sync();
+}
+// unaligned dword at byte offset off of the staged region (off <= 256)
+__device__ __forceinline__ uint32_t rw_rd32(const uint32_t *win, uint32_t off)
+{
+    const uint32_t i = min(off >> 2, 64u);
+    return __builtin_amdgcn_alignbyte(win[i + 1], win[i], off & 3u);
+}
+
+// ---- ReadNCount (EntropyCommon.cs:79-188), one lane; the header sits in the staged window w (a description of <= 53
+//      symbols is < 100 bytes).  Offsets instead of pointers; hbSize may exceed the window (the rest of the block). ----
+__device__ __forceinline__ uint32_t readNCount(int16_t *norm, uint32_t *maxSVPtr, uint32_t *tableLogPtr, const uint32_t *w, uint32_t hbSize, uint32_t wOff)
+{
+    const int32_t iend = (int32_t)hbSize; int32_t ip = 0;
     int nbBits, remaining, threshold, bitCount; uint32_t bitStream, charnum = 0; int previous0 = 0;
     if (hbSize < 4) return ZE(E_srcSize_wrong);
-    bitStream = rd32(ip);
+    bitStream = rw_rd32(w, wOff + (uint32_t)ip);
     nbBits = (int)(bitStream & 0xF) + 5;
     if (nbBits > 15) return ZE(E_tableLog_tooLarge);
     bitStream >>= 4; bitCount = 4;
@@ -150,14 +173,14 @@ __device__ __forceinline__ uint32_t readNCount(int16_t *norm, uint32_t *maxSVPtr
             uint32_t n0 = charnum;
             while ((bitStream & 0xFFFF) == 0xFFFF) {
                 n0 += 24;
-                if (ip < iend - 5) { ip += 2; bitStream = rd32(ip) >> bitCount; }
+                if (ip < iend - 5) { ip += 2; bitStream = rw_rd32(w, wOff + (uint32_t)ip) >> bitCount; }
                 else { bitStream >>= 16; bitCount += 16; }
             }
             while ((bitStream & 3) == 3) { n0 += 3; bitStream >>= 2; bitCount += 2; }
             n0 += bitStream & 3; bitCount += 2;
             if (n0 > *maxSVPtr) return ZE(48);
             while (charnum < n0) norm[charnum++] = 0;
-            if ((ip <= iend - 7) || (ip + (bitCount >> 3) <= iend - 4)) { ip += bitCount >> 3; bitCount &= 7; bitStream = rd32(ip) >> bitCount; }
+            if ((ip <= iend - 7) || (ip + (bitCount >> 3) <= iend - 4)) { ip += bitCount >> 3; bitCount &= 7; bitStream = rw_rd32(w, wOff + (uint32_t)ip) >> bitCount; }
             else bitStream >>= 2;
         }
         {
@@ -172,14 +195,14 @@ __device__ __forceinline__ uint32_t readNCount(int16_t *norm, uint32_t *maxSVPtr
             while (remaining < threshold) { nbBits--; threshold >>= 1; }
             if ((ip <= iend - 7) || (ip + (bitCount >> 3) <= iend - 4)) { ip += bitCount >> 3; bitCount &= 7; }
             else { bitCount -= (int)(8 * (iend - 4 - ip)); ip = iend - 4; }
-            bitStream = rd32(ip) >> (bitCount & 31);
+            bitStream = rw_rd32(w, wOff + (uint32_t)ip) >> (bitCount & 31);
         }
     }
     if (remaining != 1) return ZE(E_corruption_detected);
     if (bitCount > 32) return ZE(E_corruption_detected);
     *maxSVPtr = charnum - 1;
     ip += (bitCount + 7) >> 3;
-    return (uint32_t)(ip - istart);
+    return (uint32_t)ip;
 }
 
 // ---- BuildFSETable (ZStdDecompress.cs:958-1034) by all 64 lanes; lane s owns symbol s (maxSym <= 52).
@@ -243,35 +266,40 @@ __device__ __forceinline__ void buildSeqTableWave(DLds &L, SeqSym *cells, uint32
 }
 
 // ---- ReadStats + table fill (EntropyCommon.cs:198-269, HufDecompress.cs:117-180) ----
-// lane 0 parses the weights; all lanes fill the table.  returns header size or error.
+// The weight description (<= 128 bytes) is held in a register window.  One lane parses FSE-compressed weights (serial by
+// nature: two interleaved FSE states); everything after the weights -- checks, rank counts, cell ranges, table fill -- runs
+// on all lanes, lane s of chunk c owning symbol 64c + s.  returns header size or error.
 __device__ __forceinline__ uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t srcSize)
 {
     const uint32_t lane = (uint32_t)zs_lane();
-    if (lane == 0) {
-        uint32_t result = 0, oSize = 0, iSize;
-        do {
-            if (!srcSize) { result = ZE(E_srcSize_wrong); break; }
-            iSize = src[0];
-            if (iSize >= 128) {
-                oSize = iSize - 127; iSize = (oSize + 1) / 2;
-                if (iSize + 1 > srcSize) { result = ZE(E_srcSize_wrong); break; }
-                if (oSize >= 256) { result = ZE(E_corruption_detected); break; }
-                for (uint32_t n = 0; n < oSize; n += 2) { L.u.tb.weights[n] = src[1 + n / 2] >> 4; L.u.tb.weights[n + 1] = src[1 + n / 2] & 15; }
-            } else {
-                // FSE-compressed weights (FseDecompress.cs:233-332), table log <= 6
-                if (iSize + 1 > srcSize) { result = ZE(E_srcSize_wrong); break; }
+    if (!srcSize) return ZE(E_srcSize_wrong);
+    hw_stage(L.u.tb.hdrWin, src, min(srcSize, 256u));
+    const uint32_t *hw = L.u.tb.hdrWin;
+    uint32_t iSize = src[0], oSize = 0;
+    if (iSize >= 128) {                                                     // direct: 4 bits per weight (EntropyCommon.cs:215-225)
+        oSize = iSize - 127; iSize = (oSize + 1) / 2;
+        if (iSize + 1 > srcSize) return ZE(E_srcSize_wrong);
+        if (oSize >= 256) return ZE(E_corruption_detected);
+        for (uint32_t n = lane; n < 2 * iSize; n += 64) { const uint32_t byte = src[1 + n / 2]; L.u.tb.weights[n] = (uint8_t)((n & 1) ? (byte & 15) : (byte >> 4)); }
+        wave_sync();
+    } else {
+        if (iSize + 1 > srcSize) return ZE(E_srcSize_wrong);
+        if (lane == 0) {
+            // FSE-compressed weights (FseDecompress.cs:233-332), table log <= 6, read from the register window (offset 1)
+            uint32_t result = 0;
+            do {
                 uint32_t tableLog, maxSV = 63;
-                const uint32_t nc = readNCount(L.u.tb.norm, &maxSV, &tableLog, src + 1, iSize);
+                const uint32_t nc = readNCount(L.u.tb.norm, &maxSV, &tableLog, hw, iSize, 1);       // the description starts at byte 1
                 if (isErr(nc)) { result = nc; break; }
                 if (tableLog > 6 || maxSV > 63) { result = ZE(E_tableLog_tooLarge); break; }
                 {   // FseDecompress.cs:111-181
                     const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
                     uint32_t highThreshold = tableSize - 1, position = 0;
-                    for (uint32_t s = 0; s <= maxSV; s++) {
-                        if (L.u.tb.norm[s] == -1) { L.u.tb.wfse[highThreshold--].symbol = (uint8_t)s; L.u.tb.symbolNext[s] = 1; } else L.u.tb.symbolNext[s] = (uint16_t)L.u.tb.norm[s];
+                    for (uint32_t sy = 0; sy <= maxSV; sy++) {
+                        if (L.u.tb.norm[sy] == -1) { L.u.tb.wfse[highThreshold--].symbol = (uint8_t)sy; L.u.tb.symbolNext[sy] = 1; } else L.u.tb.symbolNext[sy] = (uint16_t)L.u.tb.norm[sy];
                     }
-                    for (uint32_t s = 0; s <= maxSV; s++)
-                        for (int i = 0; i < L.u.tb.norm[s]; i++) { L.u.tb.wfse[position].symbol = (uint8_t)s; position = (position + step) & tableMask; while (position > highThreshold) position = (position + step) & tableMask; }
+                    for (uint32_t sy = 0; sy <= maxSV; sy++)
+                        for (int i = 0; i < L.u.tb.norm[sy]; i++) { L.u.tb.wfse[position].symbol = (uint8_t)sy; position = (position + step) & tableMask; while (position > highThreshold) position = (position + step) & tableMask; }
                     if (position != 0) { result = ZE(E_GENERIC); break; }
                     for (uint32_t u = 0; u < tableSize; u++) {
                         const uint32_t sy = L.u.tb.wfse[u].symbol; const uint32_t ns = L.u.tb.symbolNext[sy]++;
@@ -279,49 +307,118 @@ __device__ __forceinline__ uint32_t readHufTable(DLds &L, const uint8_t *src, ui
                         L.u.tb.wfse[u].newState = (uint16_t)((ns << L.u.tb.wfse[u].nbBits) - tableSize);
                     }
                 }
-                {   // two interleaved states, FseDecompress.cs:233-295
-                    BitR b; br_init(b, src + 1 + nc, iSize - nc);
-                    if (b.err || iSize <= nc) { result = ZE(E_corruption_detected); break; }
-                    uint32_t s1 = br_read(b, tableLog), s2 = br_read(b, tableLog);
+                {   // two interleaved states, FseDecompress.cs:233-295; the stream is bytes [1 + nc, 1 + iSize) of the window
+                    if (iSize <= nc) { result = ZE(E_corruption_detected); break; }
+                    const uint32_t s0 = 1 + nc, ssz = iSize - nc;
+                    const uint32_t lastByte = rw_rd32(hw, s0 + ssz - 1) & 0xFFu;
+                    if (lastByte == 0) { result = ZE(E_corruption_detected); break; }
+                    int32_t bitPos = (int32_t)(ssz * 8 - (8 - zs_highbit(lastByte)));
+                    // n <= 6 bits below the cursor (bits below the stream start read as 0, BitStream.cs:412)
+                    auto readBits = [&](uint32_t n) -> uint32_t {
+                        uint32_t v = 0;
+                        if (n && bitPos > 0) {
+                            const int32_t bh = (bitPos - 1) >> 3;
+                            const uint32_t raw = (bh >= 3) ? rw_rd32(hw, s0 + (uint32_t)bh - 3) : (rw_rd32(hw, s0) << (8 * (3 - bh)));
+                            v = (raw << (7u - (uint32_t)((bitPos - 1) & 7))) >> (32 - n);
+                        }
+                        bitPos -= (int32_t)n;
+                        return v;
+                    };
+                    uint32_t s1 = readBits(tableLog), s2 = readBits(tableLog);
                     uint32_t op = 0; bool bad = false;
                     for (;;) {
                         if (op > 253) { bad = true; break; }
-                        L.u.tb.weights[op++] = L.u.tb.wfse[s1].symbol; { const uint32_t nb = L.u.tb.wfse[s1].nbBits; s1 = L.u.tb.wfse[s1].newState + br_read(b, nb); }
-                        if (b.bitPos < 0) { L.u.tb.weights[op++] = L.u.tb.wfse[s2].symbol; break; }
+                        L.u.tb.weights[op++] = L.u.tb.wfse[s1].symbol; { const uint32_t nb = L.u.tb.wfse[s1].nbBits; s1 = L.u.tb.wfse[s1].newState + readBits(nb); }
+                        if (bitPos < 0) { L.u.tb.weights[op++] = L.u.tb.wfse[s2].symbol; break; }
                         if (op > 253) { bad = true; break; }
-                        L.u.tb.weights[op++] = L.u.tb.wfse[s2].symbol; { const uint32_t nb = L.u.tb.wfse[s2].nbBits; s2 = L.u.tb.wfse[s2].newState + br_read(b, nb); }
-                        if (b.bitPos < 0) { L.u.tb.weights[op++] = L.u.tb.wfse[s1].symbol; break; }
+                        L.u.tb.weights[op++] = L.u.tb.wfse[s2].symbol; { const uint32_t nb = L.u.tb.wfse[s2].nbBits; s2 = L.u.tb.wfse[s2].newState + readBits(nb); }
+                        if (bitPos < 0) { L.u.tb.weights[op++] = L.u.tb.wfse[s1].symbol; break; }
                     }
                     if (bad) { result = ZE(E_corruption_detected); break; }
-                    oSize = op;
+                    result = op;                                             // number of weights
                 }
-            }
-            for (int i = 0; i < 13; i++) L.u.tb.rank[i] = 0;
-            uint32_t weightTotal = 0; bool bad = false;
-            for (uint32_t n = 0; n < oSize; n++) { if (L.u.tb.weights[n] >= 12) { bad = true; break; } L.u.tb.rank[L.u.tb.weights[n]]++; weightTotal += (1u << L.u.tb.weights[n]) >> 1; }
-            if (bad || weightTotal == 0) { result = ZE(E_corruption_detected); break; }
-            const uint32_t tableLog = zs_highbit(weightTotal) + 1;
-            if (tableLog > 12) { result = ZE(E_corruption_detected); break; }
-            {
-                const uint32_t total = 1u << tableLog, rest = total - weightTotal;
-                const uint32_t verif = 1u << zs_highbit(rest), lastWeight = zs_highbit(rest) + 1;
-                if (verif != rest) { result = ZE(E_corruption_detected); break; }
-                L.u.tb.weights[oSize] = (uint8_t)lastWeight; L.u.tb.rank[lastWeight]++;
-            }
-            if ((L.u.tb.rank[1] < 2) || (L.u.tb.rank[1] & 1)) { result = ZE(E_corruption_detected); break; }
-            L.hufLog = tableLog;
-            { uint32_t next = 0; for (uint32_t n = 1; n < tableLog + 1; n++) { const uint32_t cur = next; next += L.u.tb.rank[n] << (n - 1); L.u.tb.rank[n] = cur; } }
-            L.misc[1] = oSize + 1;
-            result = iSize + 1;
-        } while (0);
-        L.misc[0] = result;
+            } while (0);
+            L.misc[0] = result;
+        }
+        wave_sync();
+        const uint32_t r = L.misc[0];
+        if (isErr(r)) return r;
+        oSize = r;
+    }
+    // ---- from here on all lanes.  weights[0 .. oSize) are known; the last symbol's weight is implied ----
+    uint32_t wgt[4]; uint32_t weightTotal = 0; bool bad = false;
+    #pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {
+        const uint32_t n = 64 * c + lane;
+        wgt[c] = (n < oSize) ? (uint32_t)L.u.tb.weights[n] : 0u;
+        bad |= wgt[c] >= 12;
+        weightTotal += (1u << min(wgt[c], 12u)) >> 1;
+    }
+    if (__ballot(bad)) return ZE(E_corruption_detected);
+    weightTotal = wave_sum(weightTotal);
+    if (weightTotal == 0) return ZE(E_corruption_detected);
+    const uint32_t tableLog = zs_highbit(weightTotal) + 1;
+    if (tableLog > 12) return ZE(E_corruption_detected);
+    const uint32_t rest = (1u << tableLog) - weightTotal, lastWeight = zs_highbit(rest) + 1;
+    if ((1u << zs_highbit(rest)) != rest) return ZE(E_corruption_detected);
+    #pragma unroll
+    for (uint32_t c = 0; c < 4; c++) if (64 * c + lane == oSize) wgt[c] = lastWeight;
+    const uint32_t nbSymbols = oSize + 1;
+    // symbols per weight, then the first cell of each weight (cells sorted by weight, then by symbol: HufDecompress.cs:148-176)
+    uint32_t rankStart[13];                                                  // uniform values
+    {
+        uint32_t next = 0;
+        #pragma unroll
+        for (uint32_t wv = 1; wv <= 12; wv++) {
+            uint32_t cnt = 0;
+            #pragma unroll
+            for (uint32_t c = 0; c < 4; c++) cnt += (uint32_t)__popcll(__ballot(wgt[c] == wv));
+            if (wv == 1 && ((cnt < 2) || (cnt & 1))) bad = true;             // EntropyCommon.cs:262
+            rankStart[wv] = next; next += cnt << (wv - 1);
+        }
+        rankStart[0] = 0;
+    }
+    if (bad) return ZE(E_corruption_detected);
+    if (lane == 0) L.hufLog = tableLog;
+    // every symbol with a weight fills its cells: start = first cell of its weight + (lower symbols of that weight) * cells per symbol
+    const uint64_t below = (1ull << lane) - 1ull;
+    uint32_t before[13];
+    #pragma unroll
+    for (uint32_t wv = 0; wv <= 12; wv++) before[wv] = 0;
+    #pragma unroll
+    for (uint32_t c = 0; c < 4; c++) {
+        uint32_t myStart = 0;
+        #pragma unroll
+        for (uint32_t wv = 1; wv <= 12; wv++) {
+            const uint64_t m = __ballot(wgt[c] == wv);
+            if (wgt[c] == wv) myStart = rankStart[wv] + ((before[wv] + (uint32_t)__popcll(m & below)) << (wv - 1));
+            before[wv] += (uint32_t)__popcll(m);
+        }
+        if (wgt[c]) L.u.tb.symStart[64 * c + lane] = (uint16_t)myStart;
+        L.u.tb.weights[64 * c + lane] = (uint8_t)wgt[c];
     }
     wave_sync();
-    const uint32_t res = L.misc[0];
-    if (isErr(res)) return res;
-    const uint32_t nbSymbols = L.misc[1], tableLog = L.hufLog;
-    if (lane == 0) for (uint32_t n = 0; n < nbSymbols; n++) { const uint32_t w = L.u.tb.weights[n]; L.u.tb.symStart[n] = (uint16_t)L.u.tb.rank[w]; if (w) L.u.tb.rank[w] += (1u << w) >> 1; }
-    wave_sync();
+#ifdef ZS_DEC_ERRLINE
+    {   // debugging aid: the serial statement (old code) must agree on every derived value
+        uint32_t mism = 0;
+        if (lane == 0) {
+            uint32_t rk[16]; for (int i = 0; i < 16; i++) rk[i] = 0;
+            uint32_t wt = 0;
+            for (uint32_t n = 0; n < oSize; n++) { rk[L.u.tb.weights[n]]++; wt += (1u << L.u.tb.weights[n]) >> 1; }
+            const uint32_t tl = zs_highbit(wt) + 1;
+            const uint32_t rs = (1u << tl) - wt, lw = zs_highbit(rs) + 1;
+            if (tl != tableLog) mism = 0x810000u | tl;
+            else if (lw != lastWeight || L.u.tb.weights[oSize] != lw) mism = 0x820000u | (lastWeight << 12) | ((uint32_t)L.u.tb.weights[oSize] << 8) | (oSize & 0xFFu);
+            else {
+                rk[lw]++;
+                uint32_t next = 0; for (uint32_t n = 1; n < tl + 1; n++) { const uint32_t cur = next; next += rk[n] << (n - 1); rk[n] = cur; }
+                for (uint32_t n = 0; n < nbSymbols && !mism; n++) { const uint32_t w = L.u.tb.weights[n]; if (w) { if (rk[w] != L.u.tb.symStart[n]) mism = 0x830000u | n; rk[w] += (1u << w) >> 1; } }
+            }
+        }
+        mism = wave_get(mism, 0);
+        if (mism) return 0xFF000000u | mism;
+    }
+#endif
     for (uint32_t n = 0; n < nbSymbols; n++) {            // uniform loop; lanes fill one symbol's cells together
         const uint32_t w = L.u.tb.weights[n];
         if (!w) continue;
@@ -330,7 +427,7 @@ __device__ __forceinline__ uint32_t readHufTable(DLds &L, const uint8_t *src, ui
         for (uint32_t u = lane; u < length; u += 64) L.huf[startAt + u] = e;
     }
     wave_sync();
-    return res;
+    return iSize + 1;
 }
 
 // ---- stream windows in LDS.  The serial decoders (Huffman: one lane per stream; sequences: lane 0) read their backward
@@ -572,6 +669,7 @@ __device__ __forceinline__ uint32_t seqHeaders(DLds &L, const DState &st, const 
                 uint32_t *tl = t == 0 ? &L.LL.tableLog : (t == 1 ? &L.OF.tableLog : &L.ML.tableLog);
                 const int16_t *dn = t == 0 ? d_LL_defaultNorm : (t == 1 ? d_OF_defaultNorm : d_ML_defaultNorm);
                 const uint32_t dmax = t == 0 ? 35 : (t == 1 ? 28 : 52);
+                hw_stage(L.u.tb.hdrWin, ip + consumed, (uint32_t)(iend - (ip + consumed)));           // this table's description, staged
                 if (lane == 0) {                                   // parse (serial, small): what to build and how many bytes it took
                     uint32_t err = 0, adv = 0, bmax = 0, blog = 0;
                     const uint8_t *p = ip + consumed;
@@ -587,7 +685,7 @@ __device__ __forceinline__ uint32_t seqHeaders(DLds &L, const DState &st, const 
                     else if (type == 3) { if (!st.fseEntropy) err = ZE(E_corruption_detected); }
                     else {
                         uint32_t tableLog = 0, max = maxS;
-                        const uint32_t h = readNCount(L.u.tb.norm, &max, &tableLog, p, left);
+                        const uint32_t h = readNCount(L.u.tb.norm, &max, &tableLog, L.u.tb.hdrWin, left, 0);
                         if (isErr(h) || tableLog > maxLog) err = ZE(E_corruption_detected);
                         else { bmax = max; blog = tableLog; adv = h; }
                     }
@@ -638,6 +736,9 @@ __device__ __forceinline__ uint32_t decodeBlock(DLds &L, DState &st, uint8_t *ds
                 const uint32_t h = readHufTable(L, cs, csz);
 #ifdef ZS_DEC_PROFILE
                 { const uint64_t now_ = __builtin_readcyclecounter(); if (g_prof) g_prof[6] += now_ - prof_t_; }
+#endif
+#ifdef ZS_DEC_ERRLINE
+                if (isErr(h)) return h;
 #endif
                 if (isErr(h)) return ZE(E_corruption_detected);
                 if (h >= csz) return ZE(E_corruption_detected);
