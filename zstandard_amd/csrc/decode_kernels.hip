@@ -605,7 +605,10 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
         if (ll && ll <= 16) {
             if (litStart + 16 <= litSize) {
                 const uint64_t a = zs_load64(litPtr + litStart), c = zs_load64(litPtr + litStart + 8);
-                for (uint32_t j = 0; j < ll; j++) dstBase[outStart + j] = (uint8_t)(j < 8 ? a >> (8 * j) : c >> (8 * (j - 8)));
+                if (ll + ml >= 16 && outStart + 16 <= oend) {
+                    // 16 bytes at once: what runs past the literals lands in this sequence's own match bytes, written later
+                    __builtin_memcpy(dstBase + outStart, &a, 8); __builtin_memcpy(dstBase + outStart + 8, &c, 8);
+                } else for (uint32_t j = 0; j < ll; j++) dstBase[outStart + j] = (uint8_t)(j < 8 ? a >> (8 * j) : c >> (8 * (j - 8)));
             } else for (uint32_t j = 0; j < ll; j++) dstBase[outStart + j] = litPtr[litStart + j];
         }
         for (uint64_t lm = __ballot(ll > 16); lm; lm &= lm - 1) {
@@ -619,9 +622,14 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
         const uint64_t msrc = mdst - off;
         const bool indep = ml && (msrc + ml <= tileStart);
         if (indep && ml <= 32) {
-            uint32_t j = 0;
-            for (; j + 8 <= ml; j += 8) { const uint64_t v = zs_load64(dstBase + msrc + j); __builtin_memcpy(dstBase + mdst + j, &v, 8); }
-            for (; j < ml; j++) dstBase[mdst + j] = dstBase[msrc + j];
+            if (ml >= 8) {
+                // whole 8-byte pieces, the last one moved back so that it ends with the match (source and destination do not overlap)
+                uint64_t v[4]; const uint32_t lastAt = ml - 8;
+                #pragma unroll
+                for (uint32_t k = 0; k < 4; k++) v[k] = zs_load64(dstBase + msrc + min(8 * k, lastAt));
+                #pragma unroll
+                for (uint32_t k = 0; k < 4; k++) if (8 * k < ml) __builtin_memcpy(dstBase + mdst + min(8 * k, lastAt), &v[k], 8);
+            } else for (uint32_t j = 0; j < ml; j++) dstBase[mdst + j] = dstBase[msrc + j];
         }
         for (uint64_t lm = __ballot(indep && ml > 32); lm; lm &= lm - 1) {
             const int t = __builtin_ctzll(lm);

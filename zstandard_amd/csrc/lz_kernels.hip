@@ -231,15 +231,33 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
 
     // ---- stage the unit ----
     if (tid < ZS_WALK_FRONT / 4) reinterpret_cast<uint32_t *>(walkLds)[tid] = 0;
-    for (uint32_t i = tid * 16; i < n + ZS_WALK_TAIL; i += NW * 8 * 16) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (i + 16 <= n) __builtin_memcpy(&v, s + i, 16);
-        else if (i < n) {
-            uint64_t lo = 0, hi = 0;
-            for (uint32_t k = 0; k < 16 && i + k < n; k++) { const uint64_t c = s[i + k]; if (k < 8) lo |= c << (8 * k); else hi |= c << (8 * (k - 8)); }
-            v = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+    {
+        // whole 16-byte pieces: the (up to 8) loads of a thread are issued together (a load behind a branch, followed by its LDS
+        // store, would wait out one memory round trip per piece); then the partial piece and the zero tail
+        constexpr uint32_t T = NW * 8, PER = CAP / 16 / T;                       // threads, pieces per thread (8)
+        const uint32_t nFull = n & ~15u;
+        uint4 v[PER];
+        #pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t i = (tid + k * T) * 16;
+            const uint32_t ii = (i + 16 <= nFull) ? i : 0u;                      // clamped: always a valid address when nFull >= 16
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (nFull >= 16) __builtin_memcpy(&v[k], s + ii, 16);
         }
-        if (i + 16 <= CAP + ZS_WALK_TAIL) *reinterpret_cast<uint4 *>(ls + i) = v;
+        #pragma unroll
+        for (uint32_t k = 0; k < PER; k++) {
+            const uint32_t i = (tid + k * T) * 16;
+            if (i + 16 <= nFull) *reinterpret_cast<uint4 *>(ls + i) = v[k];
+        }
+        for (uint32_t i = nFull + tid * 16; i < n + ZS_WALK_TAIL; i += T * 16) {
+            uint4 w = make_uint4(0, 0, 0, 0);
+            if (i < n) {
+                uint64_t lo = 0, hi = 0;
+                for (uint32_t k = 0; k < 16 && i + k < n; k++) { const uint64_t c = s[i + k]; if (k < 8) lo |= c << (8 * k); else hi |= c << (8 * (k - 8)); }
+                w = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
+            }
+            if (i + 16 <= CAP + ZS_WALK_TAIL) *reinterpret_cast<uint4 *>(ls + i) = w;
+        }
     }
     // candidate bits of the positions that can start a match; the word behind them reads as zero
     {
