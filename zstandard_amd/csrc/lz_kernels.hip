@@ -5,18 +5,23 @@
 // There is no reference code for this stage (the reference has no encoder);
 // what it emits is consumed by entropy_kernels.hip, whose output the reference decoder must accept.
 #include "zsmi_device.h"
+#include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
 // k_lz_candidates<NR, WPR> : one workgroup per LZ unit (<= NR ranges of 8 KiB), NR * WPR wavefronts.
-//   <8, *>  units of <= 64 KiB (one block),  LDS  64 KiB at 2^12 slots
+//   <8, 2>  units of <= 64 KiB (one block),  LDS  64 KiB at 2^12 slots, two workgroups per CU
 //   <16, 1> units of <= 128 KiB (two blocks), LDS 128 KiB
 // LDS: NR hash tables of 2^hashLog 16-bit slots: tag (3 hash bits) << 13 | position in the range; 0xFFFF = empty.
 // Positions are taken 64 at a time: all lanes read the table, then all lanes write it (same-slot writes of one
 // instruction: the highest lane stays -- probed on MI355X by tools/probe/lds_order.hip).
 // Phase A (one wavefront per range: table order matters) fills the tables and leaves each position's distance to its
-// own-range predecessor (same slot, same tag) in dist[]; phase B (after a barrier: earlier ranges' tables are final;
-// WPR wavefronts per range, alternating trips) falls back to the nearest earlier range holding the slot with the
-// same tag, checks the 4 bytes and writes the match distance: low 16 bits to dist[], bit 16 to distHi (NR == 16 only).
+// own-range predecessor (same slot, same tag) in dist[].  Phase B (after a barrier: every table is final) takes the
+// positions without one, falls back to the nearest earlier range holding the slot with the same tag, checks the 4 bytes
+// of every candidate and writes the match distance: low 16 bits to dist[], bit 16 to distHi (NR == 16 only), and the
+// "has a candidate" bit plane.  Phase B work is dealt in trips of 64 * U positions from a queue in LDS, last trip first:
+// a trip of range r probes r tables, so fixed shares would leave the wavefronts of the low ranges waiting at the end.
+// Trips that lie wholly inside the hashable positions run without bound checks; the one trip that may not (the last
+// of the unit) has its own guarded code.
 // Scalar statement: findCandidates in oracle/zso_encoder.c.
 // HBM/L2 traffic per unit: reads n (twice, second time from cache) + n gathers; writes 2n (dist twice).
 // ---------------------------------------------------------------------------------------------
@@ -25,6 +30,7 @@
 #define ZS_CAND_WPR 2              // wavefronts per range of the small-unit candidates kernel (8 ranges): 1 -> 512 threads, 2 -> 1024
 #endif
 #define ZS_SLOT_EMPTY 0xFFFFu
+#define ZS_CAND_LDS(NR) (((size_t)(NR) << ZS_HASH_LOG) * 2 + 16)      // the tables + the trip queue
 __device__ __forceinline__ uint32_t zs_slot_entry(uint32_t hh, int hashLog, uint32_t p)
 { return (((hh >> (32 - hashLog - ZS_TAG_BITS)) & ((1u << ZS_TAG_BITS) - 1)) << ZS_RANGE_LOG) | (p & (ZS_RANGE_SIZE - 1)); }
 
@@ -42,9 +48,12 @@ __device__ __forceinline__ uint32_t zs_slot_entry(uint32_t hh, int hashLog, uint
 template <int NR, int WPR>
 __global__ void __launch_bounds__(NR * WPR * 64, (NR == 8 ? ZS_CAND_MINWG : 1))
 k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units, uint32_t block0,
-                uint16_t *__restrict__ distAll, uint8_t *__restrict__ distHiAll, uint8_t *__restrict__ distMaskAll, int hashLog)
+                uint16_t *__restrict__ distAll, uint8_t *__restrict__ distHiAll, uint8_t *__restrict__ distMaskAll, int hashLogArg)
 {
     extern __shared__ __attribute__((aligned(16))) uint16_t tables[];
+    constexpr int hashLog = ZS_HASH_LOG;                              // fixed: table strides become instruction immediates
+    if (hashLogArg != hashLog) return;                                // the host passes ZS_HASH_LOG (zsmi_api.hip)
+    uint32_t *queue = reinterpret_cast<uint32_t *>(tables + ((size_t)NR << hashLog));      // next phase-B trip
     const ZsUnitDesc ud = units[blockIdx.x];
     const uint8_t *s = src + ud.srcOff;
     const uint32_t n = ud.size;
@@ -52,64 +61,151 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     uint8_t *distHi = distHiAll + (size_t)(ud.firstBlock - block0) * (ZS_BLOCK_MAX / 8);
     uint8_t *distMask = distMaskAll + (size_t)(ud.firstBlock - block0) * (ZS_BLOCK_MAX / 8);     // bit p: position p has a candidate
 
+#ifdef ZS_K1_PROFILE          // development aid (tools/k1_profile.py): s_memtime at the phase boundaries, left in the unit's distHi plane
+    uint64_t profT[4]; profT[0] = __builtin_amdgcn_s_memtime();
+#endif
     {   // clear the tables
         const uint32_t words = ((uint32_t)NR << hashLog) >> 1;      // 32-bit words
         uint32_t *t32 = reinterpret_cast<uint32_t *>(tables);
         for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) t32[i] = 0xFFFFFFFFu;
+        if (threadIdx.x == 0) *queue = 0;
     }
     __syncthreads();
 
-    const uint32_t waveAll = threadIdx.x >> 6, lane = threadIdx.x & 63u;
-    const uint32_t wave = waveAll % NR, half = waveAll / NR;          // range, and which of the range's WPR wavefronts
-    const uint32_t start = wave << ZS_RANGE_LOG;
+    // wavefront-uniform values are made scalars (readfirstlane): range bounds, trip bases and the loop control live in SGPRs
+    const uint32_t waveAll = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t hashable = (n >= 4) ? n - 3 : 0;                   // positions [0, hashable) have 4 bytes
-    const uint32_t end = min(start + ZS_RANGE_SIZE, hashable);
-    uint16_t *T = tables + ((size_t)wave << hashLog);
-
-    // U steps per trip.  The loads of trip t+1 are issued before trip t is worked on (registers double-buffered),
-    // so the table walk of a trip runs under the memory latency of the next one.
+    // U steps of 64 positions per trip.  The loads of trip t+1 are issued before trip t is worked on (registers
+    // double-buffered), so the table work of a trip runs under the memory latency of the next one.
     constexpr uint32_t U = (NR > 8) ? ZS_CAND_U_BIG : ZS_CAND_U;      // the 128 KiB shape runs one workgroup per CU: more loads in flight per wavefront
-    if (half == 0) {
-        uint32_t v[U], vn[U];
-        #pragma unroll
-        for (uint32_t u = 0; u < U; u++) { const uint32_t p = start + u * 64 + lane; v[u] = (p < end) ? zs_load32(s + p) : 0u; }
-        for (uint32_t base = start; base < end; base += 64 * U) {
-            const uint32_t nbase = base + 64 * U;
+    constexpr uint32_t TRIP = 64 * U;
+    using Whole = std::true_type; using Guarded = std::false_type;
+
+#ifdef ZS_K1_PROFILE
+    profT[1] = __builtin_amdgcn_s_memtime();
+#endif
+    // ---- phase A: wavefront r fills table r in position order
+    if (waveAll < NR) {
+        const uint32_t start = waveAll << ZS_RANGE_LOG, end = min(start + ZS_RANGE_SIZE, hashable);
+        uint16_t *T = tables + ((size_t)waveAll << hashLog);
+        auto load = [&](auto tag, uint32_t base, uint32_t (&v)[U]) {
+            constexpr bool WHOLE = decltype(tag)::value;
             #pragma unroll
-            for (uint32_t u = 0; u < U; u++) { const uint32_t p = nbase + u * 64 + lane; vn[u] = (p < end) ? zs_load32(s + p) : 0u; }
+            for (uint32_t u = 0; u < U; u++) { const uint32_t p = base + u * 64 + lane; v[u] = (WHOLE || p < end) ? zs_load32(s + p) : 0u; }
+        };
+        auto insert = [&](auto tag, uint32_t base, const uint32_t (&v)[U]) {
+            constexpr bool WHOLE = decltype(tag)::value;
+            // all U reads and writes of the trip go to the LDS back to back (it keeps their order); the distances are worked
+            // out afterwards, so the trip pays the LDS latency once
+            uint32_t own[U], mine[U];
             #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
                 const uint32_t p = base + u * 64 + lane;
-                if (p < end) {
+                if (WHOLE || p < end) {
                     const uint32_t hh = v[u] * 2654435761u;
-                    const uint32_t h = hh >> (32 - hashLog);
-                    const uint32_t mine = zs_slot_entry(hh, hashLog, p);
-                    const uint32_t own = T[h];
-                    T[h] = (uint16_t)mine;
-                    // same tag, filled: the predecessor is earlier in this range, so the distance is 1..8191
-                    dist[p] = (own != ZS_SLOT_EMPTY && ((own ^ mine) >> ZS_RANGE_LOG) == 0) ? (uint16_t)(mine - own) : (uint16_t)0;
+                    const uint32_t h = __builtin_amdgcn_ubfe(hh, 32 - hashLog, hashLog);
+                    mine[u] = zs_slot_entry(hh, hashLog, p);
+                    own[u] = T[h];
+                    T[h] = (uint16_t)mine[u];
                 }
             }
             #pragma unroll
-            for (uint32_t u = 0; u < U; u++) v[u] = vn[u];
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t p = base + u * 64 + lane;
+                if (WHOLE || p < end) {
+                    // same tag: the distance to the slot's position; an empty slot reads as (tag 7, position 8191), which no
+                    // position of the range lies behind: its "distance" is <= 0 and becomes 0 = no predecessor
+                    const int d = (int)mine[u] - (int)own[u];
+                    dist[p] = (uint16_t)(((own[u] ^ mine[u]) < ZS_RANGE_SIZE) ? max(d, 0) : 0);
+                }
+            }
+        };
+        if (start < end) {
+            uint32_t v[U], vn[U];
+            if (start + TRIP <= end) load(Whole{}, start, v); else load(Guarded{}, start, v);
+            // the first trip's values are waited for here, in front of the loop: left to the loop body, the wait lands behind the
+            // next trip's loads and takes them along (every trip would then sit out a full memory round trip)
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) asm volatile("" : "+v"(v[u]));
+            uint32_t base = start;
+            for (; base + TRIP <= end; base += TRIP) {
+                const uint32_t nbase = base + TRIP;
+                if (nbase + TRIP <= end) load(Whole{}, nbase, vn); else if (nbase < end) load(Guarded{}, nbase, vn);
+                insert(Whole{}, base, v);
+                #pragma unroll
+                for (uint32_t u = 0; u < U; u++) v[u] = vn[u];
+            }
+            if (base < end) insert(Guarded{}, base, v);
         }
     }
+#ifdef ZS_K1_PROFILE
+    profT[2] = __builtin_amdgcn_s_memtime();
+#endif
     __syncthreads();
+#ifdef ZS_K1_PROFILE
+    profT[3] = __builtin_amdgcn_s_memtime();
+#endif
 
+    // ---- phase B
     {
-        // trip t: (v, own candidate) loaded one trip ahead; its verification gathers are issued, then trip t-1's
-        // gathers (issued one trip earlier) are compared and stored.  cand = candidate position + 1, 0 = none.
-        uint32_t v[U], cand[U], vn[U], candn[U], pv[U], pcand[U], pcv[U];
-        uint32_t pbase = 0; bool havePrev = false;
-        const uint32_t first = start + half * 64 * U;
-        auto finish = [&](uint32_t fbase) {
+        // (v, own-range distance) of a trip are loaded one trip ahead; the trip's verification gathers are issued, then the
+        // previous trip's gathers are compared and stored.  cand = candidate position + 1, 0 = none.
+        auto load = [&](auto tag, uint32_t base, uint32_t (&v)[U], uint32_t (&d)[U]) {
+            constexpr bool WHOLE = decltype(tag)::value;
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t p = base + u * 64 + lane; const bool in = WHOLE || p < hashable;
+                v[u] = in ? zs_load32(s + p) : 0u; d[u] = in ? (uint32_t)dist[p] : 0u;
+            }
+        };
+        auto ownCandidates = [&](uint32_t base, const uint32_t (&d)[U], uint32_t (&cand)[U]) {
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) cand[u] = d[u] ? base + u * 64 + lane - d[u] + 1 : 0u;
+        };
+        auto probe = [&](auto tag, uint32_t base, const uint32_t (&v)[U], uint32_t (&cand)[U]) {
+            constexpr bool WHOLE = decltype(tag)::value;
+            uint32_t rangeV;                                          // the trip's range, as a per-lane value: the table reads below
+            asm volatile("v_mov_b32 %0, %1" : "=v"(rangeV) : "s"(base >> ZS_RANGE_LOG));      // are masked, not branched around
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) {
+                const uint32_t p = base + u * 64 + lane;
+                if ((WHOLE || p < hashable) && !cand[u]) {
+                    // the earlier ranges are read at once (independent LDS reads, range q at byte offset q << (hashLog + 1): an
+                    // immediate of the instruction); the nearest one holding the slot with this tag wins
+                    const uint32_t hh = v[u] * 2654435761u;
+                    const uint32_t h = __builtin_amdgcn_ubfe(hh, 32 - hashLog, hashLog);
+                    const uint32_t tagv = zs_slot_entry(hh, hashLog, 0);
+                    // slot ^ tagv < 8192 <=> same tag, and then it is the position in the range.  The empty slot 0xFFFF would pass
+                    // as (tag 7, position 8191): with tag 7 the limit drops to 8191.  Ascending ranges, each hit replacing the last.
+                    // (Leaving the chain at the trip's own range count through scalar branches: no gain at 8 ranges, a loss at 16.)
+                    const uint32_t limit = ZS_RANGE_SIZE - (tagv == (7u << ZS_RANGE_LOG) ? 1u : 0u);
+                    const uint16_t *Th = tables + h;
+                    uint32_t c[NR - 1];
+                    #pragma unroll
+                    for (uint32_t q = 0; q < NR - 1; q++) c[q] = (q < rangeV) ? (uint32_t)Th[(size_t)q << hashLog] : ZS_SLOT_EMPTY;
+                    uint32_t best = 0;
+                    #pragma unroll
+                    for (uint32_t q = 0; q < NR - 1; q++) {
+                        const uint32_t x = c[q] ^ tagv;
+                        best = (x < limit) ? x + ((q << ZS_RANGE_LOG) + 1u) : best;
+                    }
+                    cand[u] = best;
+                }
+            }
+        };
+        auto gather = [&](const uint32_t (&cand)[U], uint32_t (&cv)[U]) {
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) cv[u] = cand[u] ? zs_load32(s + cand[u] - 1) : 0u;
+        };
+        auto finish = [&](auto tag, uint32_t fbase, const uint32_t (&pv)[U], const uint32_t (&pcand)[U], const uint32_t (&pcv)[U]) {
+            constexpr bool WHOLE = decltype(tag)::value;
             // candidate bits (and bit 16 of the distances) of the trip's U groups of 64 positions: lane u keeps group u's word,
             // so each plane takes one store of U * 8 contiguous bytes
             uint64_t pmMine = 0, hiMine = 0;
             #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
                 const uint32_t p = fbase + u * 64 + lane;
-                uint32_t d = (p < end && pcand[u] && pcv[u] == pv[u]) ? p - (pcand[u] - 1) : 0u;
+                uint32_t d = ((WHOLE || p < hashable) && pcand[u] && pcv[u] == pv[u]) ? p - (pcand[u] - 1) : 0u;
                 if (NR > 8) {
                     if (d == 65536u) d = 0;
                     const uint64_t hi = __ballot((d >> 16) != 0);
@@ -117,63 +213,61 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
                 }
                 const uint64_t pm = __ballot(d != 0);
                 if (lane == u) pmMine = pm;
-                if (p < end) dist[p] = (uint16_t)d;
+                if (WHOLE || p < hashable) dist[p] = (uint16_t)d;
             }
-            if (lane < U && fbase + lane * 64 < end) {
+            if (lane < U && (WHOLE || fbase + lane * 64 < hashable)) {
                 *reinterpret_cast<uint64_t *>(distMask + ((fbase + lane * 64) >> 3)) = pmMine;
                 if (NR > 8) *reinterpret_cast<uint64_t *>(distHi + ((fbase + lane * 64) >> 3)) = hiMine;
             }
         };
-        #pragma unroll
-        for (uint32_t u = 0; u < U; u++) {
-            const uint32_t p = first + u * 64 + lane; const bool in = p < end;
-            v[u] = in ? zs_load32(s + p) : 0u; const uint32_t d = in ? (uint32_t)dist[p] : 0u; cand[u] = d ? p - d + 1 : 0u;
+        auto grab = [&]() -> uint32_t {
+            uint32_t i = 0;
+            if (lane == 0) i = atomicAdd(queue, 1u);
+            return __builtin_amdgcn_readfirstlane(i);
+        };
+
+        const uint32_t nWhole = hashable / TRIP;                      // trips [t * TRIP, (t + 1) * TRIP) wholly hashable
+        uint32_t v[U], cand[U], vn[U], dn[U], pv[U], pcand[U], pcv[U], cv[U];
+        if (waveAll == NR * WPR - 1 && nWhole * TRIP < hashable) {    // the unit's last, partial trip: on its own, not pipelined
+            const uint32_t base = nWhole * TRIP;
+            load(Guarded{}, base, v, dn);
+            ownCandidates(base, dn, cand);
+            probe(Guarded{}, base, v, cand);
+            gather(cand, cv);
+            finish(Guarded{}, base, v, cand, cv);
         }
-        for (uint32_t base = first; base < end; base += WPR * 64 * U) {
-            const uint32_t nbase = base + WPR * 64 * U;
+        uint32_t cur = grab(), pbase = 0; bool havePrev = false;
+        if (cur < nWhole) {
+            load(Whole{}, (nWhole - 1 - cur) * TRIP, v, dn);
+            ownCandidates((nWhole - 1 - cur) * TRIP, dn, cand);
             #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t p = nbase + u * 64 + lane; const bool in = p < end;
-                vn[u] = in ? zs_load32(s + p) : 0u; const uint32_t d = in ? (uint32_t)dist[p] : 0u; candn[u] = d ? p - d + 1 : 0u;
-            }
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t p = base + u * 64 + lane;
-                if (p < end && !cand[u]) {
-                    // all earlier ranges are read at once (independent LDS reads); the nearest one holding the slot with this tag wins
-                    const uint32_t hh = v[u] * 2654435761u;
-                    const uint32_t h = hh >> (32 - hashLog);
-                    const uint32_t tagv = zs_slot_entry(hh, hashLog, 0);
-                    // slot ^ tagv < 8192 <=> same tag, and then it is the position in the range.  The empty slot 0xFFFF would pass
-                    // as (tag 7, position 8191): with tag 7 the limit drops to 8191.  The nearest range = the largest key.
-                    const uint32_t limit = ZS_RANGE_SIZE - (tagv == (7u << ZS_RANGE_LOG) ? 1u : 0u);
-                    uint32_t c[NR - 1];
-                    #pragma unroll
-                    for (uint32_t q = 0; q < NR - 1; q++) c[q] = (q < wave) ? (uint32_t)tables[((size_t)q << hashLog) + h] : ZS_SLOT_EMPTY;
-                    uint32_t best = 0;
-                    #pragma unroll
-                    for (uint32_t q = 0; q < NR - 1; q++) {
-                        const uint32_t x = c[q] ^ tagv;
-                        best = max(best, (x < limit) ? x + (q << ZS_RANGE_LOG) + 1u : 0u);
-                    }
-                    cand[u] = best;
-                }
-            }
-            uint32_t cv[U];
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) cv[u] = cand[u] ? zs_load32(s + cand[u] - 1) : 0u;
-            if (havePrev) finish(pbase);
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) { pv[u] = v[u]; pcand[u] = cand[u]; pcv[u] = cv[u]; v[u] = vn[u]; cand[u] = candn[u]; }
-            pbase = base; havePrev = true;
+            for (uint32_t u = 0; u < U; u++) asm volatile("" : "+v"(v[u]), "+v"(cand[u]));      // as in phase A: wait in front of the loop
         }
-        if (havePrev) finish(pbase);
+        while (cur < nWhole) {
+            const uint32_t base = (nWhole - 1 - cur) * TRIP;
+            const uint32_t nxt = grab();
+            const uint32_t nbase = (nWhole - 1 - nxt) * TRIP;
+            if (nxt < nWhole) load(Whole{}, nbase, vn, dn);
+            probe(Whole{}, base, v, cand);
+            gather(cand, cv);
+            if (havePrev) finish(Whole{}, pbase, pv, pcand, pcv);
+            #pragma unroll
+            for (uint32_t u = 0; u < U; u++) { pv[u] = v[u]; pcand[u] = cand[u]; pcv[u] = cv[u]; v[u] = vn[u]; }
+            // the own-range distances become positions only here, at the end of the trip: worked out next to their loads they
+            // would stall the trip on the memory round trip the prefetch is there to hide
+            ownCandidates(nbase, dn, cand);
+            pbase = base; havePrev = true; cur = nxt;
+        }
+        if (havePrev) finish(Whole{}, pbase, pv, pcand, pcv);
     }
+#ifdef ZS_K1_PROFILE
+    if (NR == 8 && lane == 0) {           // per wavefront: start, phase A begin / end, phase B begin / end
+        uint64_t *o = reinterpret_cast<uint64_t *>(distHi) + waveAll * 8;
+        o[0] = profT[0]; o[1] = profT[1]; o[2] = profT[2]; o[3] = profT[3]; o[4] = __builtin_amdgcn_s_memtime();
+    }
+#endif
     // positions without 4 bytes left: no candidate
-    {
-        const uint32_t rend = min(start + ZS_RANGE_SIZE, n);
-        if (half == 0) for (uint32_t p = max(end, start) + lane; p < rend; p += 64) dist[p] = 0;
-    }
+    if (waveAll == 0) for (uint32_t p = hashable + lane; p < n; p += 64) dist[p] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -165,8 +165,8 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     if (hipStream) { c->stream = (hipStream_t)hipStream; c->ownStream = false; }
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; } c->ownStream = true; }
     // dynamic LDS beyond the 64 KiB default
-    (void)hipFuncSetAttribute((const void *)k_lz_candidates<8, ZS_CAND_WPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (8 << ZS_HASH_LOG) * 2);
-    (void)hipFuncSetAttribute((const void *)k_lz_candidates<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (16 << ZS_HASH_LOG) * 2);
+    (void)hipFuncSetAttribute((const void *)k_lz_candidates<8, ZS_CAND_WPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZS_CAND_LDS(8));
+    (void)hipFuncSetAttribute((const void *)k_lz_candidates<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZS_CAND_LDS(16));
     (void)hipFuncSetAttribute((const void *)k_lz_walk<64, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_BLOCK_MAX));
     (void)hipFuncSetAttribute((const void *)k_lz_walk<128, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_BLOCK_MAX));
     (void)hipFuncSetAttribute((const void *)k_lz_walk<128, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_UNIT_MAX));
@@ -325,9 +325,9 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         // match search per LZ unit: small units (one block) and big units (two blocks) have their own kernel shapes
         const uint32_t s0 = c->smallBefore[chunk0], ns = c->smallBefore[chunk1] - s0, b0 = c->bigBefore[chunk0], nbig = c->bigBefore[chunk1] - b0;
         const ZsUnitDesc *dUS = (const ZsUnitDesc *)c->dUnits.p + s0, *dUB = (const ZsUnitDesc *)c->dUnits.p + c->planSmall + b0;
-        if (ns) LAUNCH_ON(c, st, "k_lz_candidates", (k_lz_candidates<8, ZS_CAND_WPR>), dim3(ns), dim3(8 * ZS_CAND_WPR * 64), (size_t)(8 << hashLog) * 2, (const uint8_t *)dSrc, dUS, block0,
+        if (ns) LAUNCH_ON(c, st, "k_lz_candidates", (k_lz_candidates<8, ZS_CAND_WPR>), dim3(ns), dim3(8 * ZS_CAND_WPR * 64), ZS_CAND_LDS(8), (const uint8_t *)dSrc, dUS, block0,
                           (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, (uint8_t *)L.dDistMask.p, hashLog);
-        if (nbig) LAUNCH_ON(c, st, "k_lz_candidates_big", (k_lz_candidates<16, 1>), dim3(nbig), dim3(1024), (size_t)(16 << hashLog) * 2, (const uint8_t *)dSrc, dUB, block0,
+        if (nbig) LAUNCH_ON(c, st, "k_lz_candidates_big", (k_lz_candidates<16, 1>), dim3(nbig), dim3(1024), ZS_CAND_LDS(16), (const uint8_t *)dSrc, dUB, block0,
                             (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, (uint8_t *)L.dDistMask.p, hashLog);
         if (ns && getenv("ZSMI_EXP_WALK")) LAUNCH_ON(c, st, "k_lz_walk_exp", (k_lz_walk<128, 9>), dim3(ns), dim3(1024), ZS_WALK_LDS(ZS_BLOCK_MAX), (const uint8_t *)dSrc, dUS, block0, (const uint16_t *)L.dDist.p,
                           (const uint8_t *)L.dDistHi.p, (const uint8_t *)L.dDistMask.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dLits.p, look);
