@@ -24,6 +24,8 @@
 // of the unit) has its own guarded code.
 // Scalar statement: findCandidates in oracle/zso_encoder.c.
 // HBM/L2 traffic per unit: reads n (twice, second time from cache) + n gathers; writes 2n (dist twice).
+// What bounds it on MI355X (profiles/r1_h_*): the vector-memory path.  TA_TA_BUSY 95 % of the kernel's cycles, three
+// quarters of it the verification gathers (64 lanes = 64 cache lines an instruction); vector ALU issue 82 %.
 // ---------------------------------------------------------------------------------------------
 #define ZS_TAG_BITS 3
 #ifndef ZS_CAND_WPR
@@ -149,7 +151,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     // ---- phase B
     {
         // (v, own-range distance) of a trip are loaded one trip ahead; the trip's verification gathers are issued, then the
-        // previous trip's gathers are compared and stored.  cand = candidate position + 1, 0 = none.
+        // previous trip's gathers are compared and stored.  d = distance to the candidate, 0 = none.
         auto load = [&](auto tag, uint32_t base, uint32_t (&v)[U], uint32_t (&d)[U]) {
             constexpr bool WHOLE = decltype(tag)::value;
             #pragma unroll
@@ -158,54 +160,51 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
                 v[u] = in ? zs_load32(s + p) : 0u; d[u] = in ? (uint32_t)dist[p] : 0u;
             }
         };
-        auto ownCandidates = [&](uint32_t base, const uint32_t (&d)[U], uint32_t (&cand)[U]) {
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) cand[u] = d[u] ? base + u * 64 + lane - d[u] + 1 : 0u;
-        };
-        auto probe = [&](auto tag, uint32_t base, const uint32_t (&v)[U], uint32_t (&cand)[U]) {
+        auto probe = [&](auto tag, uint32_t base, const uint32_t (&v)[U], uint32_t (&d)[U]) {
             constexpr bool WHOLE = decltype(tag)::value;
             uint32_t rangeV;                                          // the trip's range, as a per-lane value: the table reads below
             asm volatile("v_mov_b32 %0, %1" : "=v"(rangeV) : "s"(base >> ZS_RANGE_LOG));      // are masked, not branched around
             #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
                 const uint32_t p = base + u * 64 + lane;
-                if ((WHOLE || p < hashable) && !cand[u]) {
+                if ((WHOLE || p < hashable) && !d[u]) {
                     // the earlier ranges are read at once (independent LDS reads, range q at byte offset q << (hashLog + 1): an
                     // immediate of the instruction); the nearest one holding the slot with this tag wins
                     const uint32_t hh = v[u] * 2654435761u;
                     const uint32_t h = __builtin_amdgcn_ubfe(hh, 32 - hashLog, hashLog);
                     const uint32_t tagv = zs_slot_entry(hh, hashLog, 0);
                     // slot ^ tagv < 8192 <=> same tag, and then it is the position in the range.  The empty slot 0xFFFF would pass
-                    // as (tag 7, position 8191): with tag 7 the limit drops to 8191.  Ascending ranges, each hit replacing the last.
-                    // (Leaving the chain at the trip's own range count through scalar branches: no gain at 8 ranges, a loss at 16.)
+                    // as (tag 7, position 8191): with tag 7 the limit drops to 8191.  Ascending ranges, each hit replacing the last;
+                    // "none" is the position itself (distance 0).  (Ending the chain at the trip's own range count through scalar
+                    // branches halves its instructions and buys nothing: the kernel is bound by the vector-memory path, TA busy 95 %.)
                     const uint32_t limit = ZS_RANGE_SIZE - (tagv == (7u << ZS_RANGE_LOG) ? 1u : 0u);
                     const uint16_t *Th = tables + h;
                     uint32_t c[NR - 1];
                     #pragma unroll
                     for (uint32_t q = 0; q < NR - 1; q++) c[q] = (q < rangeV) ? (uint32_t)Th[(size_t)q << hashLog] : ZS_SLOT_EMPTY;
-                    uint32_t best = 0;
+                    uint32_t best = p;
                     #pragma unroll
                     for (uint32_t q = 0; q < NR - 1; q++) {
                         const uint32_t x = c[q] ^ tagv;
-                        best = (x < limit) ? x + ((q << ZS_RANGE_LOG) + 1u) : best;
+                        best = (x < limit) ? x + (q << ZS_RANGE_LOG) : best;
                     }
-                    cand[u] = best;
+                    d[u] = p - best;
                 }
             }
         };
-        auto gather = [&](const uint32_t (&cand)[U], uint32_t (&cv)[U]) {
+        auto gather = [&](uint32_t base, const uint32_t (&d)[U], uint32_t (&cv)[U]) {
             #pragma unroll
-            for (uint32_t u = 0; u < U; u++) cv[u] = cand[u] ? zs_load32(s + cand[u] - 1) : 0u;
+            for (uint32_t u = 0; u < U; u++) cv[u] = d[u] ? zs_load32(s + (base + u * 64 + lane - d[u])) : 0u;
         };
-        auto finish = [&](auto tag, uint32_t fbase, const uint32_t (&pv)[U], const uint32_t (&pcand)[U], const uint32_t (&pcv)[U]) {
+        auto finish = [&](auto tag, uint32_t fbase, const uint32_t (&pv)[U], const uint32_t (&pd)[U], const uint32_t (&pcv)[U]) {
             constexpr bool WHOLE = decltype(tag)::value;
             // candidate bits (and bit 16 of the distances) of the trip's U groups of 64 positions: lane u keeps group u's word,
-            // so each plane takes one store of U * 8 contiguous bytes
+            // so each plane takes one store of U * 8 contiguous bytes.  Without a candidate the gathered word is 0 and so is d.
             uint64_t pmMine = 0, hiMine = 0;
             #pragma unroll
             for (uint32_t u = 0; u < U; u++) {
                 const uint32_t p = fbase + u * 64 + lane;
-                uint32_t d = ((WHOLE || p < hashable) && pcand[u] && pcv[u] == pv[u]) ? p - (pcand[u] - 1) : 0u;
+                uint32_t d = (pcv[u] == pv[u]) ? pd[u] : 0u;
                 if (NR > 8) {
                     if (d == 65536u) d = 0;
                     const uint64_t hi = __ballot((d >> 16) != 0);
@@ -227,38 +226,32 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
         };
 
         const uint32_t nWhole = hashable / TRIP;                      // trips [t * TRIP, (t + 1) * TRIP) wholly hashable
-        uint32_t v[U], cand[U], vn[U], dn[U], pv[U], pcand[U], pcv[U], cv[U];
+        uint32_t v[U], d[U], vn[U], dn[U], pv[U], pd[U], pcv[U], cv[U];
         if (waveAll == NR * WPR - 1 && nWhole * TRIP < hashable) {    // the unit's last, partial trip: on its own, not pipelined
             const uint32_t base = nWhole * TRIP;
-            load(Guarded{}, base, v, dn);
-            ownCandidates(base, dn, cand);
-            probe(Guarded{}, base, v, cand);
-            gather(cand, cv);
-            finish(Guarded{}, base, v, cand, cv);
+            load(Guarded{}, base, v, d);
+            probe(Guarded{}, base, v, d);
+            gather(base, d, cv);
+            finish(Guarded{}, base, v, d, cv);
         }
         uint32_t cur = grab(), pbase = 0; bool havePrev = false;
         if (cur < nWhole) {
-            load(Whole{}, (nWhole - 1 - cur) * TRIP, v, dn);
-            ownCandidates((nWhole - 1 - cur) * TRIP, dn, cand);
+            load(Whole{}, (nWhole - 1 - cur) * TRIP, v, d);
             #pragma unroll
-            for (uint32_t u = 0; u < U; u++) asm volatile("" : "+v"(v[u]), "+v"(cand[u]));      // as in phase A: wait in front of the loop
+            for (uint32_t u = 0; u < U; u++) asm volatile("" : "+v"(v[u]), "+v"(d[u]));      // as in phase A: wait in front of the loop
         }
         while (cur < nWhole) {
             const uint32_t base = (nWhole - 1 - cur) * TRIP;
             const uint32_t nxt = grab();
-            const uint32_t nbase = (nWhole - 1 - nxt) * TRIP;
-            if (nxt < nWhole) load(Whole{}, nbase, vn, dn);
-            probe(Whole{}, base, v, cand);
-            gather(cand, cv);
-            if (havePrev) finish(Whole{}, pbase, pv, pcand, pcv);
+            if (nxt < nWhole) load(Whole{}, (nWhole - 1 - nxt) * TRIP, vn, dn);
+            probe(Whole{}, base, v, d);
+            gather(base, d, cv);
+            if (havePrev) finish(Whole{}, pbase, pv, pd, pcv);
             #pragma unroll
-            for (uint32_t u = 0; u < U; u++) { pv[u] = v[u]; pcand[u] = cand[u]; pcv[u] = cv[u]; v[u] = vn[u]; }
-            // the own-range distances become positions only here, at the end of the trip: worked out next to their loads they
-            // would stall the trip on the memory round trip the prefetch is there to hide
-            ownCandidates(nbase, dn, cand);
+            for (uint32_t u = 0; u < U; u++) { pv[u] = v[u]; pd[u] = d[u]; pcv[u] = cv[u]; v[u] = vn[u]; d[u] = dn[u]; }
             pbase = base; havePrev = true; cur = nxt;
         }
-        if (havePrev) finish(Whole{}, pbase, pv, pcand, pcv);
+        if (havePrev) finish(Whole{}, pbase, pv, pd, pcv);
     }
 #ifdef ZS_K1_PROFILE
     if (NR == 8 && lane == 0) {           // per wavefront: start, phase A begin / end, phase B begin / end
