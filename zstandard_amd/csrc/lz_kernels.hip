@@ -411,16 +411,29 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
                 key = ((gain + 2048) << 3) | (int)(7u - sub);
             }
         }
-        // best key of the walker's 8 lanes: data-parallel-primitive moves (xor 1, xor 2 inside a quad, then the mirrored
-        // lane of the other quad) -- no LDS round trips
-        int best = key;
-        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
-        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
-        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x141, 0xF, 0xF, false));    // row_half_mirror: lane i <- lane 7 - i
-        const uint32_t bl = (lane & ~7u) + (7u - (uint32_t)(best & 7));      // lane holding the best candidate
-        // its (q - ip, fwd, back) travel in one word, the distance in another
-        const uint32_t packed = (uint32_t)__shfl((int)(idx | (fwd << 8) | (back << 16)), (int)bl);
-        const uint32_t boff = (uint32_t)__shfl((int)off, (int)bl);
+        // best candidate of the walker's 8 lanes, by data-parallel-primitive moves (xor 1, xor 2 inside a quad, then the mirrored
+        // lane of the other quad).  64 KiB units: a max over 64-bit words -- high word key << 17 | distance (keys differ between
+        // lanes, so the key decides), low word (q - ip, fwd, back) -- leaves every lane with the winner's words and no LDS
+        // round trip (walk 0.857 -> 0.833 ms).  128 KiB units (one workgroup per CU, issue-bound): a max over the keys and two
+        // ds_bpermute reads of the winner's words is the shorter instruction sequence (1.00 vs 1.04 ms).
+        uint32_t whi = ((uint32_t)key << 17) | off, wlo = idx | (fwd << 8) | (back << 16);
+        int best; uint32_t packed, boff;
+        if (BIG) {
+            best = key;
+            best = max(best, __builtin_amdgcn_update_dpp(0, best, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+            best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+            best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x141, 0xF, 0xF, false));    // row_half_mirror: lane i <- lane 7 - i
+            const uint32_t bl = (lane & ~7u) + (7u - (uint32_t)(best & 7));      // lane holding the best candidate
+            packed = (uint32_t)__shfl((int)wlo, (int)bl);
+            boff = (uint32_t)__shfl((int)off, (int)bl);
+        } else {
+            #define ZS_WMAX(ctrl) { const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)whi, ctrl, 0xF, 0xF, false), \
+                                                   olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wlo, ctrl, 0xF, 0xF, false); \
+                                    const bool t_ = ohi > whi; whi = t_ ? ohi : whi; wlo = t_ ? olo : wlo; }
+            ZS_WMAX(0xB1) ZS_WMAX(0x4E) ZS_WMAX(0x141)
+            #undef ZS_WMAX
+            best = (int)(whi >> 17); packed = wlo; boff = whi & 0x1FFFFu;
+        }
         const uint32_t bq = ip + (packed & 0xFFu);
         uint32_t bfwd = (packed >> 8) & 0xFFu;
         const uint32_t bback = packed >> 16;
