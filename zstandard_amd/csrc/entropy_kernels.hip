@@ -50,6 +50,9 @@ struct FseCT {                       // encoding table of one symbol type
 #ifndef ZS_LIT_MINWG
 #define ZS_LIT_MINWG 8
 #endif
+#ifndef ZS_LIT_TILES
+#define ZS_LIT_TILES 2               // tiles of 64 sequences the literal gather keeps in flight per wavefront
+#endif
 struct K3Lds {                       // literals kernel
     uint32_t count[256];             // literal histogram
     uint8_t  nbBits[256];
@@ -62,6 +65,7 @@ struct K3Lds {                       // literals kernel
         struct { uint32_t pkg[10][256]; uint32_t S[512]; uint32_t npk[12]; } pm;      // package-merge (levels 2..11)
         struct { FseCT ct[1]; int16_t norm[64]; uint8_t tableSymbol[512]; uint32_t cumul[66]; } fse;   // weights table
         uint32_t tile[4][208];       // bit-packing tiles, one per wavefront (streams are written after the tables are done)
+        uint32_t hist[8][257];       // literal gather: eight private histograms (lane & 7), rows one word apart in the banks
     } u;
     uint32_t misc[16];
     uint32_t rngN[ZS_WALK_RANGES], rngCarry[ZS_WALK_RANGES], litBase[ZS_WALK_RANGES];
@@ -554,47 +558,104 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     if (n < 16) FINISH(0, 0, 0);
 
     if (wave == 0) loadRangesWave(hdr, L.rngN, L.rngCarry, nullptr, L.litBase, &L.misc[1], &L.misc[2]);
-    L.count[tid] = 0;
+    #pragma unroll
+    for (uint32_t k = 0; k < 8; k++) L.u.hist[k][tid] = 0;
     __syncthreads();
     const uint32_t lastLits = L.misc[1];
     const uint32_t nlit = L.misc[2];
 
     // ---- literals: gather into lits[], histogram.  Range r's own literals start at litBase[r]; the first sequence of a
     //      range also takes the literals carried over from the ranges before it (they sit right in front). ----
-    for (uint32_t r = wave; r < ZS_WALK_RANGES; r += 4) {
-        const uint32_t ns = L.rngN[r];
-        const ZsSeqRec *sq = seqBase + (size_t)r * ZS_SEQ_PER_RANGE;
-        uint32_t done = L.litBase[r] - L.rngCarry[r];
-        for (uint32_t base = 0; base < ns; base += 64) {
-            const uint32_t k = base + lane;
-            uint32_t ll = 0, mpos = 0;
-            if (k < ns) { const ZsSeqRec rec = sq[k]; ll = rec.ll; if (k == 0) ll += L.rngCarry[r]; mpos = rec.flags; }
-            const uint32_t incl = wave_incl_scan(ll);
-            const uint32_t dstOff = done + incl - ll;
-            const uint32_t srcPos = mpos - ll;
-            // short runs by their own lane (one round of loads), long runs by the whole wavefront
-            if (ll && ll <= 16) {
-                const uint32_t endPos = srcPos + ll;
-                const uint32_t skip = 16 - ll;
-                uint64_t w0 = 0, w1 = 0;
-                if (endPos >= 16) { w0 = zs_load64(s + endPos - 16); w1 = zs_load64(s + endPos - 8); }
-                else for (uint32_t j = 0; j < ll; j++) { const uint64_t c = s[srcPos + j]; const uint32_t bi = skip + j; if (bi < 8) w0 |= c << (8 * bi); else w1 |= c << (8 * (bi - 8)); }
-                for (uint32_t j = 0; j < ll; j++) {
-                    const uint32_t bi = skip + j;
-                    const uint8_t c = (uint8_t)((bi < 8 ? w0 >> (8 * bi) : w1 >> (8 * (bi - 8))));
-                    lits[dstOff + j] = c; atomicAdd(&L.count[c], 1u);
+    // The wavefront's tiles (64 sequences of one of its ranges) are taken ZS_LIT_TILES at a time: the record loads of all of
+    // them are issued together, then their source loads, then the stores.  A tile alone is two dependent memory round
+    // trips, and the loop was bound by exactly that latency.
+    uint32_t *hist = L.u.hist[lane & 7u];                                  // this lane's private histogram
+    {
+        constexpr uint32_t GT = ZS_LIT_TILES;
+        auto rangeN = [&](uint32_t r) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)L.rngN[r]); };
+        uint32_t r = wave, base = 0, done = 0;                               // next tile: range, first sequence (wavefront-uniform)
+        while (r < ZS_WALK_RANGES && rangeN(r) == 0) r += 4;
+        while (r < ZS_WALK_RANGES) {
+            uint32_t tr[GT], tb[GT];                                          // the tiles of this round; tr == ZS_WALK_RANGES: none
+            ZsSeqRec rec[GT];
+            #pragma unroll
+            for (uint32_t g = 0; g < GT; g++) {                               // stage 1: the records
+                tr[g] = r; tb[g] = base;
+                rec[g].ll = 0; rec[g].ml = 0; rec[g].off = 0; rec[g].flags = 0;
+                if (r < ZS_WALK_RANGES) {
+                    const uint32_t ns = rangeN(r), k = base + lane;
+                    if (k < ns) rec[g] = seqBase[(size_t)r * ZS_SEQ_PER_RANGE + k];
+                    base += 64;
+                    if (base >= ns) { base = 0; r += 4; while (r < ZS_WALK_RANGES && rangeN(r) == 0) r += 4; }
                 }
             }
-            uint64_t longm = __ballot(ll > 16);
-            while (longm) {
-                const int t = __builtin_ctzll(longm); longm &= longm - 1;
-                const uint32_t l2 = wave_get(ll, t), d2 = wave_get(dstOff, t), s2 = wave_get(srcPos, t);
-                for (uint32_t j = lane; j < l2; j += 64) { const uint8_t c = s[s2 + j]; lits[d2 + j] = c; atomicAdd(&L.count[c], 1u); }
+            uint32_t ll[GT], dstOff[GT], srcPos[GT];
+            uint64_t w0[GT], w1[GT];
+            #pragma unroll
+            for (uint32_t g = 0; g < GT; g++) {                               // stage 2: places in the literal buffer, source loads
+                ll[g] = 0; dstOff[g] = 0; srcPos[g] = 0; w0[g] = 0; w1[g] = 0;
+                if (tr[g] < ZS_WALK_RANGES) {
+                    const uint32_t k = tb[g] + lane;
+                    uint32_t l = (k < rangeN(tr[g])) ? (uint32_t)rec[g].ll : 0u;
+                    if (k == 0) l += L.rngCarry[tr[g]];
+                    if (tb[g] == 0) done = L.litBase[tr[g]] - L.rngCarry[tr[g]];
+                    const uint32_t incl = wave_incl_scan(l);
+                    ll[g] = l; dstOff[g] = done + incl - l; srcPos[g] = (uint32_t)rec[g].flags - l;
+                    done += wave_last(incl);
+                    // short runs by their own lane (one round of loads), long runs by the whole wavefront
+                    if (l && l <= 16) {
+                        const uint32_t endPos = srcPos[g] + l, skip = 16 - l;
+                        if (endPos >= 16) { w0[g] = zs_load64(s + endPos - 16); w1[g] = zs_load64(s + endPos - 8); }
+                        else for (uint32_t j = 0; j < l; j++) { const uint64_t c = s[srcPos[g] + j]; const uint32_t bi = skip + j; if (bi < 8) w0[g] |= c << (8 * bi); else w1[g] |= c << (8 * (bi - 8)); }
+                    }
+                }
             }
-            done += wave_last(incl);
+            #pragma unroll
+            for (uint32_t g = 0; g < GT; g++) {                               // stage 3: the stores and the histogram
+                if (tr[g] >= ZS_WALK_RANGES) continue;
+                const uint32_t l = ll[g];
+                if (l && l <= 16) {
+                    // the run sits right-aligned in the 16-byte window (w0, w1): it leaves in at most five unaligned stores, biggest
+                    // piece first from its end, and is counted a window word at a time (a loop over its bytes cost the vector ALU
+                    // ~200 instructions a tile at a third of the lanes).  Counting in a pass of its own over the gathered buffer
+                    // (every lane busy) was slower: 0.50 vs 0.48 ms for the kernel
+                    uint8_t *dp = lits + dstOff[g];
+                    uint64_t t1 = w1[g];
+                    if (l == 16) { zs_store64(dp, w0[g]); zs_store64(dp + 8, t1); }
+                    else {
+                        if (l & 8) { zs_store64(dp + l - 8, t1); t1 = w0[g]; }                   // what is left ends at the top of t1
+                        if (l & 4) { zs_store32(dp + (l & 7) - 4, (uint32_t)(t1 >> 32)); t1 <<= 32; }
+                        if (l & 2) { zs_store16(dp + (l & 3) - 2, (uint16_t)(t1 >> 48)); t1 <<= 16; }
+                        if (l & 1) dp[0] = (uint8_t)(t1 >> 56);
+                    }
+                }
+                {
+                    const uint32_t first = (l && l <= 16) ? 16 - l : 16;        // window bytes [first, 16) are literals
+                    const uint32_t wd[4] = { (uint32_t)w0[g], (uint32_t)(w0[g] >> 32), (uint32_t)w1[g], (uint32_t)(w1[g] >> 32) };
+                    #pragma unroll
+                    for (uint32_t i = 0; i < 4; i++) {
+                        if (!__any(first < 4 * i + 4)) continue;
+                        #pragma unroll
+                        for (uint32_t bb = 0; bb < 4; bb++) if (4 * i + bb >= first) atomicAdd(&hist[(wd[i] >> (8 * bb)) & 0xFFu], 1u);
+                    }
+                }
+                uint64_t longm = __ballot(l > 16);
+                while (longm) {
+                    const int t = __builtin_ctzll(longm); longm &= longm - 1;
+                    const uint32_t l2 = wave_get(l, t), d2 = wave_get(dstOff[g], t), s2 = wave_get(srcPos[g], t);
+                    for (uint32_t j = lane; j < l2; j += 64) { const uint8_t c = s[s2 + j]; lits[d2 + j] = c; atomicAdd(&hist[c], 1u); }
+                }
+            }
         }
     }
-    for (uint32_t j = tid; j < lastLits; j += 256) { const uint8_t c = s[n - lastLits + j]; lits[nlit - lastLits + j] = c; atomicAdd(&L.count[c], 1u); }
+    for (uint32_t j = tid; j < lastLits; j += 256) { const uint8_t c = s[n - lastLits + j]; lits[nlit - lastLits + j] = c; atomicAdd(&hist[c], 1u); }
+    __syncthreads();
+    {
+        uint32_t c = 0;
+        #pragma unroll
+        for (uint32_t k = 0; k < 8; k++) c += L.u.hist[k][tid];
+        L.count[tid] = c;
+    }
     __syncthreads();
     if (stopAt == 1) FINISH(0, 0, 0);            // timing aid (ZSMI_STOP_LIT): stop after the literal gather
 

@@ -48,6 +48,10 @@ struct ZsBlockResult { uint32_t payloadSize; uint32_t type; /* 0 raw, 1 rle, 2 c
 // pointer lets it turn a wave-uniform address into a scalar load, which drops the low address bits.
 __device__ __forceinline__ uint32_t zs_load32(const uint8_t *p) { uint32_t v; __builtin_memcpy(&v, p, 4); return v; }
 __device__ __forceinline__ uint64_t zs_load64(const uint8_t *p) { uint64_t v; __builtin_memcpy(&v, p, 8); return v; }
+// unaligned stores (global memory takes them at any byte address)
+__device__ __forceinline__ void zs_store16(uint8_t *p, uint16_t v) { __builtin_memcpy(p, &v, 2); }
+__device__ __forceinline__ void zs_store32(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+__device__ __forceinline__ void zs_store64(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 __device__ __forceinline__ uint32_t zs_hash4(uint32_t v, int hashLog) { return (v * 2654435761u) >> (32 - hashLog); }
 __device__ __forceinline__ uint32_t zs_highbit(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
 __device__ __forceinline__ int zs_lane() { return (int)(threadIdx.x & 63u); }
