@@ -32,8 +32,52 @@ __constant__ uint8_t c_ML_Code[128] = { 0,1,2,3,4,5,6,7, 8,9,10,11,12,13,14,15, 
                                        40,40,40,40,40,40,40,40, 40,40,40,40,40,40,40,40, 41,41,41,41,41,41,41,41, 41,41,41,41,41,41,41,41,
                                        42,42,42,42,42,42,42,42, 42,42,42,42,42,42,42,42, 42,42,42,42,42,42,42,42, 42,42,42,42,42,42,42,42 };
 
-__device__ __forceinline__ uint32_t llCodeOf(uint32_t ll) { return (ll > 63) ? zs_highbit(ll) + 19 : c_LL_Code[ll]; }
-__device__ __forceinline__ uint32_t mlCodeOf(uint32_t mlBase) { return (mlBase > 127) ? zs_highbit(mlBase) + 36 : c_ML_Code[mlBase]; }
+// Codes and extra bits by arithmetic: the same values as the tables above (LL_Code / ML_Code, LL_base / LL_bits, ML_base /
+// ML_bits; checked value by value for every length up to 2^17), without a gather from constant memory in the middle of a
+// tile (a memory round trip each, and its wait takes the loop's prefetch along).
+__device__ __forceinline__ uint32_t llCodeOf(uint32_t ll)
+{
+    uint32_t c = zs_highbit(ll | 1u) + 19;                        // ll >= 64
+    c = (ll < 64) ? 24u : c;
+    c = (ll < 48) ? 22u + ((ll - 32) >> 3) : c;
+    c = (ll < 32) ? 20u + ((ll - 24) >> 2) : c;
+    c = (ll < 24) ? 16u + ((ll - 16) >> 1) : c;
+    return (ll < 16) ? ll : c;
+}
+__device__ __forceinline__ uint32_t mlCodeOf(uint32_t x)         // x = match length - 3
+{
+    uint32_t c = zs_highbit(x | 1u) + 36;                         // x >= 128
+    c = (x < 128) ? 42u : c;
+    c = (x < 96) ? 40u + ((x - 64) >> 4) : c;
+    c = (x < 64) ? 38u + ((x - 48) >> 3) : c;
+    c = (x < 48) ? 36u + ((x - 40) >> 2) : c;
+    c = (x < 40) ? 32u + ((x - 32) >> 1) : c;
+    return (x < 32) ? x : c;
+}
+// extra bits of a literal length / of a match length (x = length - 3): value and count
+__device__ __forceinline__ uint32_t llExtraOf(uint32_t ll, uint32_t &bits)
+{
+    const uint32_t h = zs_highbit(ll | 1u);
+    uint32_t v = ll - (1u << h), b = h;                            // ll >= 64
+    if (ll < 64) { v = ll - 48; b = 4; }
+    if (ll < 48) { v = ll & 7u; b = 3; }
+    if (ll < 32) { v = ll & 3u; b = 2; }
+    if (ll < 24) { v = ll & 1u; b = 1; }
+    if (ll < 16) { v = 0; b = 0; }
+    bits = b; return v;
+}
+__device__ __forceinline__ uint32_t mlExtraOf(uint32_t x, uint32_t &bits)
+{
+    const uint32_t h = zs_highbit(x | 1u);
+    uint32_t v = x - (1u << h), b = h;                             // x >= 128
+    if (x < 128) { v = x - 96; b = 5; }
+    if (x < 96) { v = x & 15u; b = 4; }
+    if (x < 64) { v = x & 7u; b = 3; }
+    if (x < 48) { v = x & 3u; b = 2; }
+    if (x < 40) { v = x & 1u; b = 1; }
+    if (x < 32) { v = 0; b = 0; }
+    bits = b; return v;
+}
 
 // ---------------------------------------------------------------------------------------------
 // per-wavefront LDS workspace
@@ -875,19 +919,29 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
         {
             uint32_t cPrev, cA, cB;                       // carried: previous offset (= rep0), rep1, rep2
             if (bd.firstInChunk) { cPrev = 1; cA = 4; cB = 8; } else { cPrev = 0xFFFFFFF1u; cA = 0xFFFFFFF2u; cB = 0xFFFFFFF3u; }
-            // sequences are taken 64 at a time in block order, whatever walk range they belong to
+            // sequences are taken 64 at a time in block order, whatever walk range they belong to; the records of the next 64 are
+            // loaded while these are worked on (their addresses depend on nothing that is carried)
+            auto locate = [&](uint32_t g, uint32_t &kOut, uint32_t &rrOut) -> ZsSeqRec * {
+                uint32_t rr = 0;
+                #pragma unroll
+                for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
+                kOut = g - L.rngStart[rr]; rrOut = rr;
+                return seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + kOut;
+            };
+            // (a record travels as its two raw words and is taken apart only where it is used: unpacked next to the load, the
+            // compiler waits for the load on the spot)
+            uint2 rawN = make_uint2(0, 0); ZsSeqRec *rpN = seqBase; uint32_t kN = 1, rrN = 0;
+            if (lane < nseq) { rpN = locate(lane, kN, rrN); rawN = *reinterpret_cast<const uint2 *>(rpN); }
+            asm volatile("" : "+v"(rawN.x), "+v"(rawN.y));                  // the first records are waited for here, not inside the loop
             for (uint32_t base = 0; base < nseq; base += 64) {
                 const uint32_t g = base + lane;
                 const bool in = g < nseq;
+                const uint2 raw = rawN; ZsSeqRec *rp = rpN; const uint32_t k = kN, rr = rrN;
+                if (g + 64 < nseq) { rpN = locate(g + 64, kN, rrN); rawN = *reinterpret_cast<const uint2 *>(rpN); }
                 uint32_t off = 0, ll = 0, ml = 0;
-                ZsSeqRec *rp = seqBase;
-                if (in) {
-                    uint32_t rr = 0;
-                    #pragma unroll
-                    for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
-                    const uint32_t k = g - L.rngStart[rr];
-                    rp = seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + k;
-                    const ZsSeqRec rec = *rp; off = (uint32_t)rec.off | (((uint32_t)rec.ml >> 13) & 1u) << 16; ll = rec.ll; ml = rec.ml & 0x1FFFu; if (k == 0) ll += rngCarry[rr];
+                if (in) {                                                    // ZsSeqRec: ll, ml (low word), off, flags (high word)
+                    const uint32_t recMl = raw.x >> 16;
+                    off = (raw.y & 0xFFFFu) | ((recMl >> 13) & 1u) << 16; ll = raw.x & 0xFFFFu; ml = recMl & 0x1FFFu; if (k == 0) ll += rngCarry[rr];
                 }
                 uint32_t prev = ZS_DPP(0, off, 0x138, 0xF, true); if (lane == 0) prev = cPrev;      // wave_shr:1        // rep0 before me
                 const bool change = in && !(ll > 0 && off == prev);
@@ -1038,37 +1092,42 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
             SeqLds &B = LS[g];
             const uint32_t Tg = chainLane ? B.misc[3] : 0u;
             const uint32_t Tmax = wave_max(Tg);
-            if (chainLane && Tg && stopAt != 3) {              // stopAt 3: timing aid, no chains
+            if (chainLane && stopAt != 3) {                    // stopAt 3: timing aid, no chains
                 const FseCT &ct = B.ct[c];
                 const uint2 *op = B.u.tile.op[c];
                 uint32_t *outp = B.u.tile.tileState[c];
-                if (!ct.rle) {
-                    uint32_t t = 0;
-                    if (i == 0) {                      // first step of the block: the state is chosen from the symbol alone
+                // One loop without branches for all chain lanes: a lane whose block has no tile this round, whose tile is shorter, or
+                // whose table is RLE (one state, no bits) runs along on zero operands and keeps its state.  The chain is the
+                // critical path of the workgroup -- per step an add, two shifts, an add and the dependent table read -- so
+                // nothing else (branches, exec-mask updates) may sit between two steps.
+                const bool moves = Tg && !ct.rle;
+                const uint32_t Tact = moves ? Tg : 0u;
+                uint32_t t0 = 0;
+                if (i == 0) {                          // first step of the block: the state is chosen from the symbol alone
+                    if (moves) {
                         const uint32_t dnb = op[0].x;
                         const uint32_t nbo = (dnb + (1u << 15)) >> 16;
                         const uint32_t v = (nbo << 16) - dnb;
                         chainState = ct.stateTable[(v >> nbo) + (int)op[0].y];
-                        outp[0] = 0;
-                        t = 1;
                     }
-                    // operands of step t+1 are read before the dependent table lookup of step t; lanes whose tile is shorter idle.
-                    // The chain is the critical path of the workgroup: its wavefront issues ahead of the others on its SIMD.
-                    __builtin_amdgcn_s_setprio(3);
-                    uint2 cur = op[t];
-                    for (; t < Tmax; t++) {
-                        const uint2 nxt = op[t + 1];
-                        if (t < Tg) {
-                            const uint32_t nbo = (chainState + cur.x) >> 16;
-                            outp[t] = (chainState & ((1u << nbo) - 1)) | (nbo << 16);
-                            chainState = ct.stateTable[(chainState >> nbo) + (int)cur.y];
-                        }
-                        cur = nxt;
-                    }
-                    __builtin_amdgcn_s_setprio(0);
-                } else {
-                    for (uint32_t t = 0; t < Tg; t++) outp[t] = 0;
+                    if (Tg) outp[0] = 0;
+                    t0 = 1;
                 }
+                // its wavefront issues ahead of the others on its SIMD
+                __builtin_amdgcn_s_setprio(3);
+                uint2 cur = moves ? op[t0] : make_uint2(0, 0);
+                #pragma unroll 4
+                for (uint32_t t = t0; t < Tmax; t++) {
+                    uint2 nxt = op[t + 1];                                         // operands of step t+1: read before the dependent lookup of step t
+                    if (!moves) nxt = make_uint2(0, 0);
+                    const uint32_t nbo = (chainState + cur.x) >> 16;
+                    const uint32_t ns = ct.stateTable[(chainState >> nbo) + (int)cur.y];
+                    const uint32_t o = (chainState & ((1u << nbo) - 1)) | (nbo << 16);
+                    if (t < Tg) outp[t] = moves ? o : 0u;
+                    chainState = (t < Tact) ? ns : chainState;
+                    cur = nxt;
+                }
+                __builtin_amdgcn_s_setprio(0);
             }
         }
         __syncthreads();
@@ -1080,8 +1139,8 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                 PUTB(sOF & 0xFFFFu, sOF >> 16);
                 PUTB(sML & 0xFFFFu, sML >> 16);
                 PUTB(sLL & 0xFFFFu, sLL >> 16);
-                PUTB(ll - c_LL_base[llc], c_LL_bits[llc]);
-                PUTB(ml - c_ML_base[mlc], c_ML_bits[mlc]);
+                { uint32_t xb; const uint32_t xv = llExtraOf(ll, xb); PUTB(xv, xb); }
+                { uint32_t xb; const uint32_t xv = mlExtraOf(ml - 3, xb); PUTB(xv, xb); }
                 PUTB(val - (1u << ofc), ofc);
                 #undef PUTB
             }
