@@ -621,14 +621,14 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
         while (r < ZS_WALK_RANGES && rangeN(r) == 0) r += 4;
         while (r < ZS_WALK_RANGES) {
             uint32_t tr[GT], tb[GT];                                          // the tiles of this round; tr == ZS_WALK_RANGES: none
-            ZsSeqRec rec[GT];
+            uint2 rec[GT];                                                    // records as raw words: ll, ml | off, flags
             #pragma unroll
             for (uint32_t g = 0; g < GT; g++) {                               // stage 1: the records
                 tr[g] = r; tb[g] = base;
-                rec[g].ll = 0; rec[g].ml = 0; rec[g].off = 0; rec[g].flags = 0;
+                rec[g] = make_uint2(0, 0);
                 if (r < ZS_WALK_RANGES) {
                     const uint32_t ns = rangeN(r), k = base + lane;
-                    if (k < ns) rec[g] = seqBase[(size_t)r * ZS_SEQ_PER_RANGE + k];
+                    if (k < ns) rec[g] = *reinterpret_cast<const uint2 *>(seqBase + (size_t)r * ZS_SEQ_PER_RANGE + k);
                     base += 64;
                     if (base >= ns) { base = 0; r += 4; while (r < ZS_WALK_RANGES && rangeN(r) == 0) r += 4; }
                 }
@@ -640,11 +640,11 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
                 ll[g] = 0; dstOff[g] = 0; srcPos[g] = 0; w0[g] = 0; w1[g] = 0;
                 if (tr[g] < ZS_WALK_RANGES) {
                     const uint32_t k = tb[g] + lane;
-                    uint32_t l = (k < rangeN(tr[g])) ? (uint32_t)rec[g].ll : 0u;
+                    uint32_t l = (k < rangeN(tr[g])) ? (rec[g].x & 0xFFFFu) : 0u;
                     if (k == 0) l += L.rngCarry[tr[g]];
                     if (tb[g] == 0) done = L.litBase[tr[g]] - L.rngCarry[tr[g]];
                     const uint32_t incl = wave_incl_scan(l);
-                    ll[g] = l; dstOff[g] = done + incl - l; srcPos[g] = (uint32_t)rec[g].flags - l;
+                    ll[g] = l; dstOff[g] = done + incl - l; srcPos[g] = (rec[g].y >> 16) - l;
                     done += wave_last(incl);
                     // short runs by their own lane (one round of loads), long runs by the whole wavefront
                     if (l && l <= 16) {
@@ -1047,10 +1047,10 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
     bool overflow = false;
     uint32_t remaining = live ? nseq : 0u;
     // sequence records are fetched one tile ahead: the loads of tile i+1 fly while the state chains of tile i run
-    ZsSeqRec recN; uint32_t carryN = 0; bool validN = false;
-    recN.ll = recN.ml = recN.off = recN.flags = 0;
+    // (as raw words, taken apart where they are used: see pass 1)
+    uint2 recN = make_uint2(0, 0); uint32_t carryN = 0; bool validN = false;
     auto fetch = [&](uint32_t rem) {
-        validN = false; carryN = 0; recN.ll = recN.ml = recN.off = recN.flags = 0;
+        validN = false; carryN = 0; recN = make_uint2(0, 0);
         const uint32_t T2 = min(64u, rem);
         if (lane < T2) {
             const uint32_t g = rem - 1 - lane;
@@ -1058,24 +1058,26 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
             #pragma unroll
             for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
             const uint32_t k = g - L.rngStart[rr];
-            recN = seqBase[(size_t)rr * ZS_SEQ_PER_RANGE + k];
+            recN = *reinterpret_cast<const uint2 *>(seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + k);
             carryN = (k == 0) ? L.rngCarry[rr] : 0u;
             validN = true;
         }
     };
     if (remaining) fetch(remaining);
+    asm volatile("" : "+v"(recN.x), "+v"(recN.y));                     // the first tile's records are waited for here, not inside the loop
     for (uint32_t i = 0; i < maxT; i++) {
         const bool mine = (i < nT) && !overflow;
         uint32_t T = 0, ll = 0, ml = 0, val = 0, llc = 0, mlc = 0, ofc = 0;
         if (mine) {
             T = min(64u, remaining);
-            const ZsSeqRec rec = recN; const uint32_t carry = carryN; const bool valid = validN;
+            const uint2 raw = recN; const uint32_t carry = carryN; const bool valid = validN;
             if (remaining > T) fetch(remaining - T);
             uint2 o0 = make_uint2(0, 0), o1 = o0, o2 = o0;
-            if (valid) {
-                ll = (uint32_t)rec.ll + carry;
-                ml = rec.ml & 0x1FFFu; const uint32_t rep = rec.ml >> 14;
-                val = rep ? rep : ((uint32_t)rec.off | (((uint32_t)rec.ml >> 13) & 1u) << 16) + 3;
+            if (valid) {                                                     // ZsSeqRec: ll, ml (low word), off, flags (high word)
+                const uint32_t recMl = raw.x >> 16;
+                ll = (raw.x & 0xFFFFu) + carry;
+                ml = recMl & 0x1FFFu; const uint32_t rep = recMl >> 14;
+                val = rep ? rep : ((raw.y & 0xFFFFu) | ((recMl >> 13) & 1u) << 16) + 3;
                 llc = llCodeOf(ll); mlc = mlCodeOf(ml - 3); ofc = zs_highbit(val);
                 o0 = make_uint2(L.ct[0].deltaNbBits[llc], (uint32_t)L.ct[0].deltaFindState[llc]);
                 o1 = make_uint2(L.ct[1].deltaNbBits[ofc], (uint32_t)L.ct[1].deltaFindState[ofc]);
