@@ -18,10 +18,12 @@
 #define ZS_FAST_HUFLOG   11u                      // Huffman tables the fast kernel holds: 2^11 entries per item
 #define ZS_FAST_MAXSEQ   16384u                   // sequences per block the fast path buffers (8 bytes each)
 #define ZS_FAST_HUFWIN   128u                     // bytes of each Huffman stream staged in LDS at a time
-#define ZS_FAST_SEQWIN   256u                     // bytes of each sequence bitstream staged in LDS at a time
+#ifndef ZS_FAST_SEQWIN
+#define ZS_FAST_SEQWIN   256u
+#endif                     // bytes of each sequence bitstream staged in LDS at a time
 #define ZS_FAST_GROUP    16u                      // items per wavefront of the Huffman kernel (4 lanes each)
 #ifndef ZS_FAST_SEQGROUP
-#define ZS_FAST_SEQGROUP 4u                       // items per wavefront of the sequences kernel (5 KiB of tables each); measured 4: 4.7 ms, 8: 5.2, 16: 5.1
+#define ZS_FAST_SEQGROUP 4u                       // items per wavefront of the sequences kernel (2.5 KiB of tables each); measured 2: 3.06 ms, 4: 2.32, 8: 3.28, 16: 2.51
 #endif
 
 struct ZsFastDesc {                               // per item, global memory, written by k_dec_prep
@@ -37,14 +39,25 @@ struct ZsFastDesc {                               // per item, global memory, wr
     uint32_t pad[2];
 };
 #define ZS_FAST_HUFTAB_BYTES (2u << ZS_FAST_HUFLOG)                       // uint16 entries
-#define ZS_FAST_SEQTAB_BYTES ((512u + 256u + 512u) * 4u)                  // LL, OF, ML cells
+#define ZS_FAST_SEQTAB_BYTES ((512u + 256u + 512u) * 2u)                  // LL, OF, ML cells, 2 bytes each
 // what the sequences kernel leaves per sequence, 8 bytes: where its extra bits start in the bitstream (bit position, 20 bits)
 // and its three codes (LL 6 bits at 20, ML 6 bits at 26, OF 5 bits at 32).  The execute kernel turns that into lengths and
 // offsets, 64 sequences at a time on 64 lanes; only the FSE state chain stays serial.
 typedef uint64_t ZsFastSeq;
 __device__ __forceinline__ ZsFastSeq zs_fastseq(uint32_t bitPos, uint32_t symLL, uint32_t symML, uint32_t symOF)
 { return (uint64_t)(bitPos | (symLL << 20) | (symML << 26)) | ((uint64_t)symOF << 32); }
-__device__ __forceinline__ uint32_t zs_fastcell(uint32_t next, uint32_t nb, uint32_t add, uint32_t sym) { return next | (nb << 16) | (add << 20) | (sym << 25); }
+// A fast-path table cell in 16 bits (half the LDS of a 4-byte cell = twice the items a CU decodes at once): the symbol in
+// bits 0-5; above it 1 << (9 - nbBits) | (nextState >> nbBits).  nextState is a multiple of 2^nbBits, one of 2^(tableLog -
+// nbBits) (FseDecompress.cs:111-181), and tableLog <= 9: the marker is the highest bit set and gives nbBits back.
+// The extra bits of a code come from the code by arithmetic (LL_bits / ML_bits, ZStdInternal.cs:158,173).
+__device__ __forceinline__ uint32_t zs_fastcell(uint32_t next, uint32_t nb, uint32_t sym) { return ((((1u << (9u - nb)) | (next >> nb)) << 6) | sym); }
+__device__ __forceinline__ void zs_fastcell_open(uint32_t c, uint32_t &next, uint32_t &nb, uint32_t &sym)
+{
+    const uint32_t p = c >> 6, hb = 31u - (uint32_t)__builtin_clz(p | 1u);
+    nb = 9u - hb; next = (p ^ (1u << hb)) << nb; sym = c & 63u;
+}
+__device__ __forceinline__ uint32_t zs_llExtraBits(uint32_t s) { return s < 16 ? 0u : (s <= 19 ? 1u : (s <= 21 ? 2u : (s <= 23 ? 3u : (s == 24 ? 4u : s - 19)))); }
+__device__ __forceinline__ uint32_t zs_mlExtraBits(uint32_t s) { return s < 32 ? 0u : (s <= 35 ? 1u : (s <= 37 ? 2u : (s <= 39 ? 3u : (s <= 41 ? 4u : (s == 42 ? 5u : s - 36))))); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_dec_prep
@@ -146,11 +159,10 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
         d.nbSeq = nbSeq; d.seqOff = (uint32_t)(ip - src); d.seqSize = remaining;
         if (nbSeq) {
             d.llLog = L.LL.tableLog; d.ofLog = L.OF.tableLog; d.mlLog = L.ML.tableLog;
-            uint32_t *stab = reinterpret_cast<uint32_t *>(seqTabs + (size_t)item * ZS_FAST_SEQTAB_BYTES);
-            // fast-path cell: nextState bits 0-15, nbBits 16-19, extra bits of the code 20-24, symbol 25-31
-            for (uint32_t i = lane; i < (1u << d.llLog); i += 64) { const SeqSym c = L.LL.cells[i]; stab[i] = zs_fastcell(c.nextState, c.nbBits, L.llTab[c.sym] >> 24, c.sym); }
-            for (uint32_t i = lane; i < (1u << d.ofLog); i += 64) { const SeqSym c = L.OF.cells[i]; stab[512 + i] = zs_fastcell(c.nextState, c.nbBits, c.sym, c.sym); }
-            for (uint32_t i = lane; i < (1u << d.mlLog); i += 64) { const SeqSym c = L.ML.cells[i]; stab[768 + i] = zs_fastcell(c.nextState, c.nbBits, L.mlTab[c.sym] >> 24, c.sym); }
+            uint16_t *stab = reinterpret_cast<uint16_t *>(seqTabs + (size_t)item * ZS_FAST_SEQTAB_BYTES);
+            for (uint32_t i = lane; i < (1u << d.llLog); i += 64) { const SeqSym c = L.LL.cells[i]; stab[i] = (uint16_t)zs_fastcell(c.nextState, c.nbBits, c.sym); }
+            for (uint32_t i = lane; i < (1u << d.ofLog); i += 64) { const SeqSym c = L.OF.cells[i]; stab[512 + i] = (uint16_t)zs_fastcell(c.nextState, c.nbBits, c.sym); }
+            for (uint32_t i = lane; i < (1u << d.mlLog); i += 64) { const SeqSym c = L.ML.cells[i]; stab[768 + i] = (uint16_t)zs_fastcell(c.nextState, c.nbBits, c.sym); }
         }
         d.fast = 1;
     } while (0);
@@ -288,10 +300,10 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_dec_sequences : lane g = item g of the group.  Tables in LDS (16 x 5 KiB), bitstream windows in LDS.
+// k_dec_sequences : lane g = item g of the group.  Tables in LDS (2.5 KiB an item: 16-bit cells), bitstream windows in LDS.
 // The per-sequence code is decodeBlock's (:1473-1553); results go to global memory, 12 bytes a sequence.
 // ---------------------------------------------------------------------------------------------------------------------
-struct SeqDecLds { uint32_t cells[ZS_FAST_SEQGROUP][1280]; uint32_t win[ZS_FAST_SEQGROUP][(ZS_FAST_SEQWIN + 8) / 4 + 2]; };
+struct SeqDecLds { uint16_t cells[ZS_FAST_SEQGROUP][1280]; uint32_t win[ZS_FAST_SEQGROUP][(ZS_FAST_SEQWIN + 8) / 4 + 2]; };
 
 __global__ void __launch_bounds__(64)
 k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
@@ -311,25 +323,26 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
         if (!wave_get(mine ? 1u : 0u, (int)gg)) continue;
         const uint32_t *st = reinterpret_cast<const uint32_t *>(seqTabs + (size_t)(blockIdx.x * ZS_FAST_SEQGROUP + gg) * ZS_FAST_SEQTAB_BYTES);
         const uint32_t a = 1u << wave_get(llLog, (int)gg), o = 1u << wave_get(ofLog, (int)gg), m = 1u << wave_get(mlLog, (int)gg);
-        {   // the three tables: every load issued before the first LDS store (up to 8 + 4 + 8 dwords per lane)
-            uint32_t va[8], vo[4], vm[8];
+        {   // the three tables, two cells a dword: every load issued before the first LDS store (up to 4 + 2 + 4 dwords per lane)
+            uint32_t va[4], vo[2], vm[4];
+            uint32_t *cw = reinterpret_cast<uint32_t *>(S.cells[gg]);
             #pragma unroll
-            for (uint32_t u = 0; u < 8; u++) va[u] = (lane + 64 * u < a) ? st[lane + 64 * u] : 0u;
+            for (uint32_t u = 0; u < 4; u++) va[u] = (2 * (lane + 64 * u) < a) ? st[lane + 64 * u] : 0u;
             #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) vo[u] = (lane + 64 * u < o) ? st[512 + lane + 64 * u] : 0u;
+            for (uint32_t u = 0; u < 2; u++) vo[u] = (2 * (lane + 64 * u) < o) ? st[256 + lane + 64 * u] : 0u;
             #pragma unroll
-            for (uint32_t u = 0; u < 8; u++) vm[u] = (lane + 64 * u < m) ? st[768 + lane + 64 * u] : 0u;
+            for (uint32_t u = 0; u < 4; u++) vm[u] = (2 * (lane + 64 * u) < m) ? st[384 + lane + 64 * u] : 0u;
             #pragma unroll
-            for (uint32_t u = 0; u < 8; u++) if (lane + 64 * u < a) S.cells[gg][lane + 64 * u] = va[u];
+            for (uint32_t u = 0; u < 4; u++) if (2 * (lane + 64 * u) < a) cw[lane + 64 * u] = va[u];
             #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) if (lane + 64 * u < o) S.cells[gg][512 + lane + 64 * u] = vo[u];
+            for (uint32_t u = 0; u < 2; u++) if (2 * (lane + 64 * u) < o) cw[256 + lane + 64 * u] = vo[u];
             #pragma unroll
-            for (uint32_t u = 0; u < 8; u++) if (lane + 64 * u < m) S.cells[gg][768 + lane + 64 * u] = vm[u];
+            for (uint32_t u = 0; u < 4; u++) if (2 * (lane + 64 * u) < m) cw[384 + lane + 64 * u] = vm[u];
         }
     }
     BitC b; b.c = 0; b.avail = 0; b.bitPos = 0;
     bool ok = !mine || bc_init(b, src, size);
-    const uint32_t *cells = S.cells[lane & (ZS_FAST_SEQGROUP - 1)];
+    const uint16_t *cells = S.cells[lane & (ZS_FAST_SEQGROUP - 1)];
     const uint32_t *win = S.win[lane & (ZS_FAST_SEQGROUP - 1)];
     ZsFastSeq *outp = seqOutAll + (size_t)item * ZS_FAST_MAXSEQ;
     uint32_t sLL = 0, sOF = 0, sML = 0, t = 0;
@@ -347,15 +360,17 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
                 if (b.bitPos > 0 && base > 0 && ((b.bitPos - 1) >> 3) < base + 24) break;
                 if (b.bitPos < 0) { ok = false; break; }                 // stream exhausted before all sequences (:1582, :1594)
                 const uint32_t cLL = cells[sLL], cOF = cells[512 + sOF], cML = cells[768 + sML];
-                outp[t++] = zs_fastseq((uint32_t)b.bitPos, cLL >> 25, cML >> 25, cOF >> 25);
-                const uint32_t xbits = ((cLL >> 20) & 31u) + ((cML >> 20) & 31u) + ((cOF >> 20) & 31u);   // skipped here, read by the execute kernel
-                const uint32_t nL = (cLL >> 16) & 15u, nM = (cML >> 16) & 15u, nO = (cOF >> 16) & 15u, sbits = nL + nM + nO;
+                uint32_t bLL, bML, bOF, nL, nM, nO, yLL, yML, yOF;
+                zs_fastcell_open(cLL, bLL, nL, yLL); zs_fastcell_open(cML, bML, nM, yML); zs_fastcell_open(cOF, bOF, nO, yOF);
+                outp[t++] = zs_fastseq((uint32_t)b.bitPos, yLL, yML, yOF);
+                const uint32_t xbits = zs_llExtraBits(yLL) + zs_mlExtraBits(yML) + yOF;                     // skipped here, read by the execute kernel
+                const uint32_t sbits = nL + nM + nO;
                 if (xbits + sbits <= 57u) { FSEQ_NEED(xbits + sbits); b.c <<= xbits; b.avail -= xbits; b.bitPos -= (int32_t)xbits; }
                 else { b.bitPos -= (int32_t)xbits; b.avail = 0; FSEQ_NEED(sbits); }
                 const uint32_t x = bc_take(b, sbits);                    // LL bits on top, then ML, then OF (:1547-1550)
-                sLL = (cLL & 0xFFFFu) + __builtin_amdgcn_ubfe(x, nM + nO, nL);
-                sML = (cML & 0xFFFFu) + __builtin_amdgcn_ubfe(x, nO, nM);
-                sOF = (cOF & 0xFFFFu) + __builtin_amdgcn_ubfe(x, 0u, nO);
+                sLL = bLL + __builtin_amdgcn_ubfe(x, nM + nO, nL);
+                sML = bML + __builtin_amdgcn_ubfe(x, nO, nM);
+                sOF = bOF + __builtin_amdgcn_ubfe(x, 0u, nO);
             }
             if (t == nbSeq || !ok) done = true;
         }
