@@ -418,6 +418,9 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     };
     uint64_t op = 0; uint32_t litPos = 0; bool bad = false;
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                                      // the list carried from tile to tile (lane 0 holds it)
+#ifdef ZS_EXEC_PROFILE
+    uint64_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const uint64_t pfStart = __builtin_amdgcn_s_memtime(); uint64_t pfMark = pfStart;
+#endif
     for (uint32_t t0 = 0; t0 < d.nbSeq; t0 += 64) {
         const uint32_t T = min(64u, d.nbSeq - t0);
         // lane t: the extra bits of sequence t0 + t (:1487-1545) -> lengths, offset value and its recent-offset class
@@ -500,9 +503,18 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
             }
         }
         wave_sync();
+#ifdef ZS_EXEC_PROFILE
+        { const uint64_t now = __builtin_amdgcn_s_memtime(); pf[3] += now - pfMark; }          // records, bits, recent offsets
+        if (execTile(tiles[w][0], tiles[w][1], tiles[w][2], T, dstBase, 0, oend, litPtr, d.litSize, op, litPos, pf)) { bad = true; break; }
+        pfMark = __builtin_amdgcn_s_memtime();
+#else
         if (execTile(tiles[w][0], tiles[w][1], tiles[w][2], T, dstBase, 0, oend, litPtr, d.litSize, op, litPos)) { bad = true; break; }
+#endif
         wave_sync();
     }
+#ifdef ZS_EXEC_PROFILE
+    if (lane == 0) { uint64_t *o = reinterpret_cast<uint64_t *>(litBuf + (1u << 17)); pf[4] = __builtin_amdgcn_s_memtime() - pfStart; pf[5] = d.nbSeq; for (int k = 0; k < 8; k++) o[k] = pf[k]; }
+#endif
     if (!bad) {
         const uint32_t lastLL = d.litSize - litPos;
         if (lastLL > oend - op) bad = true;

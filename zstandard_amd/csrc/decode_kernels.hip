@@ -578,9 +578,21 @@ __device__ static uint64_t xxh64(const uint8_t *p, uint64_t len)
 struct DState { uint32_t rep[3]; uint32_t litEntropy, fseEntropy; uint32_t llRepeatOk; };
 
 // ---- one tile of <= 64 decoded sequences (L.u.sq.tile*) -> output bytes.  Returns 0 or an error; advances op / litPos. ----
+#ifdef ZS_EXEC_PROFILE          // development aid (tools/exec_profile.py): s_memtime per phase of execTile, summed per item
+#define ZS_PF_PARAM , uint64_t *pf
+#define ZS_PF_STAMP(k) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); pf[k] += now_ - pfT; pfT = now_; }
+#define ZS_PF_DUMMY , pfDummy
+#else
+#define ZS_PF_PARAM
+#define ZS_PF_STAMP(k)
+#define ZS_PF_DUMMY
+#endif
 __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint32_t *tileML, const uint32_t *tileOff, uint32_t T, uint8_t *dstBase,
-                                             uint64_t frameStart, uint64_t oend, const uint8_t *litPtr, uint32_t litSize, uint64_t &op, uint32_t &litPos)
+                                             uint64_t frameStart, uint64_t oend, const uint8_t *litPtr, uint32_t litSize, uint64_t &op, uint32_t &litPos ZS_PF_PARAM)
 {
+#ifdef ZS_EXEC_PROFILE
+    uint64_t pfT = __builtin_amdgcn_s_memtime();
+#endif
     const uint32_t lane = (uint32_t)zs_lane();
     // execute the tile (ExecSequence :1265-1352).  Lane t owns sequence t: output positions by prefix sums, the checks
     // of the reference in its order (the first failing sequence decides), then all literal runs at once, then all
@@ -601,23 +613,55 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
         const uint64_t em = __ballot(err != 0);
         if (em) return ZE(wave_get(err, __builtin_ctzll(em)));
         const uint64_t tileStart = op;
-        // literals
-        if (ll && ll <= 16) {
-            if (litStart + 16 <= litSize) {
-                const uint64_t a = zs_load64(litPtr + litStart), c = zs_load64(litPtr + litStart + 8);
-                if (ll + ml >= 16 && outStart + 16 <= oend) {
-                    // 16 bytes at once: what runs past the literals lands in this sequence's own match bytes, written later
-                    __builtin_memcpy(dstBase + outStart, &a, 8); __builtin_memcpy(dstBase + outStart + 8, &c, 8);
-                } else for (uint32_t j = 0; j < ll; j++) dstBase[outStart + j] = (uint8_t)(j < 8 ? a >> (8 * j) : c >> (8 * (j - 8)));
-            } else for (uint32_t j = 0; j < ll; j++) dstBase[outStart + j] = litPtr[litStart + j];
+        // literals.  Runs of <= 16 bytes by their own lane (two 8-byte loads), longer runs by the whole wavefront, eight runs at a
+        // time; all the loads of a round are issued before its stores (a run at a time is a memory round trip per run; ~6 long
+        // runs a tile on the log data), and the first round of long runs shares its round trip with the short ones.
+        {
+            uint64_t lm = __ballot(ll > 16);
+            constexpr uint32_t LR = 8;
+            uint32_t l2[LR], s2[LR]; uint64_t d2[LR]; uint8_t v[LR];
+            auto take = [&]() {
+                #pragma unroll
+                for (uint32_t k = 0; k < LR; k++) {
+                    l2[k] = 0; s2[k] = 0; d2[k] = 0;
+                    if (lm) { const int t = __builtin_ctzll(lm); lm &= lm - 1; l2[k] = wave_get(ll, t); s2[k] = wave_get(litStart, t); d2[k] = wave_get64(outStart, t); }
+                }
+            };
+            auto loads = [&]() {
+                #pragma unroll
+                for (uint32_t k = 0; k < LR; k++) v[k] = (lane < l2[k]) ? litPtr[s2[k] + lane] : (uint8_t)0;
+            };
+            auto stores = [&]() {
+                #pragma unroll
+                for (uint32_t k = 0; k < LR; k++) if (lane < l2[k]) dstBase[d2[k] + lane] = v[k];
+                #pragma unroll
+                for (uint32_t k = 0; k < LR; k++) for (uint32_t j = 64 + lane; j < l2[k]; j += 64) dstBase[d2[k] + j] = litPtr[s2[k] + j];
+            };
+            take();
+            const bool shortRun = ll && ll <= 16, wide = shortRun && (litStart + 16 <= litSize);
+            uint64_t a = 0, c = 0;
+            if (wide) { a = zs_load64(litPtr + litStart); c = zs_load64(litPtr + litStart + 8); }
+            loads();
+            if (shortRun) {
+                uint8_t *dp = dstBase + outStart;
+                if (wide) {
+                    if ((ll + ml >= 16 && outStart + 16 <= oend) || ll == 16) {
+                        // 16 bytes at once: what runs past the literals lands in this sequence's own match bytes, written later
+                        __builtin_memcpy(dp, &a, 8); __builtin_memcpy(dp + 8, &c, 8);
+                    } else {
+                        // exactly ll bytes in at most four pieces (8, 4, 2, 1 by the bits of ll), not a store per byte
+                        uint64_t w = a; uint32_t at = 0;
+                        if (ll & 8) { __builtin_memcpy(dp, &w, 8); w = c; at = 8; }
+                        if (ll & 4) { const uint32_t x = (uint32_t)w; __builtin_memcpy(dp + at, &x, 4); w >>= 32; at += 4; }
+                        if (ll & 2) { const uint16_t x = (uint16_t)w; __builtin_memcpy(dp + at, &x, 2); w >>= 16; at += 2; }
+                        if (ll & 1) dp[at] = (uint8_t)w;
+                    }
+                } else for (uint32_t j = 0; j < ll; j++) dp[j] = litPtr[litStart + j];
+            }
+            stores();
+            while (lm) { take(); loads(); stores(); }
         }
-        for (uint64_t lm = __ballot(ll > 16); lm; lm &= lm - 1) {
-            const int t = __builtin_ctzll(lm);
-            const uint32_t l2 = wave_get(ll, t), s2 = wave_get(litStart, t);
-            const uint64_t d2 = wave_get64(outStart, t);
-            for (uint32_t j = lane; j < l2; j += 64) dstBase[d2 + j] = litPtr[s2 + j];
-        }
-        wave_mem_sync();
+        ZS_PF_STAMP(0)                                                        // scans, checks, literals (no wait: the next matches read older output)
         // matches reading only output that existed before this tile
         const uint64_t msrc = mdst - off;
         const bool indep = ml && (msrc + ml <= tileStart);
@@ -629,6 +673,10 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
                 for (uint32_t k = 0; k < 4; k++) v[k] = zs_load64(dstBase + msrc + min(8 * k, lastAt));
                 #pragma unroll
                 for (uint32_t k = 0; k < 4; k++) if (8 * k < ml) __builtin_memcpy(dstBase + mdst + min(8 * k, lastAt), &v[k], 8);
+            } else if (ml >= 4) {
+                // 4 .. 7 bytes: two 4-byte pieces, the second ending with the match (a byte loop is a memory round trip per byte)
+                const uint32_t x0 = zs_load32(dstBase + msrc), x1 = zs_load32(dstBase + msrc + ml - 4);
+                __builtin_memcpy(dstBase + mdst, &x0, 4); __builtin_memcpy(dstBase + mdst + ml - 4, &x1, 4);
             } else for (uint32_t j = 0; j < ml; j++) dstBase[mdst + j] = dstBase[msrc + j];
         }
         for (uint64_t lm = __ballot(indep && ml > 32); lm; lm &= lm - 1) {
@@ -638,15 +686,42 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
             for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j];
         }
         wave_mem_sync();
-        // matches reading this tile's own output (earlier sequences are complete by then), in order
-        for (uint64_t dm = __ballot(ml && !indep); dm; dm &= dm - 1) {
-            const int t = __builtin_ctzll(dm);
-            const uint32_t m2 = wave_get(ml, t), o2 = wave_get(off, t);
-            const uint64_t s2 = wave_get64(msrc, t), d2 = wave_get64(mdst, t);
-            if (o2 >= m2) { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j]; }
-            else { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + (j % o2)]; }      // period = offset
+        ZS_PF_STAMP(1)                                                        // matches from before the tile
+        // matches reading this tile's own output (earlier sequences are complete by then): in order, a group at a time.  A group
+        // is a run of such matches none of which reads what the group writes -- destinations ascend, so that is: every source ends
+        // at or before the FIRST member's destination.  Its members copy side by side (a lane each, like the matches above); only
+        // the first member may overlap its own destination (offset < length: the periodic copy).  One memory round trip a group
+        // instead of one a match (26 such matches in ~8 groups per tile on the log data).
+        for (uint64_t rem = __ballot(ml && !indep); rem; ) {
+            const int g0 = __builtin_ctzll(rem);
+            const uint64_t lo = wave_get64(mdst, g0);
+            const uint64_t viol = __ballot(((rem >> lane) & 1ull) && (int)lane > g0 && msrc + ml > lo);
+            const uint64_t grp = viol ? (rem & ((1ull << __builtin_ctzll(viol)) - 1ull)) : rem;
+            const bool in = (grp >> lane) & 1ull;
+            const bool self = in && off < ml;                        // only lane g0 can be
+            if (in && !self && ml <= 32) {
+                if (ml >= 8) {
+                    uint64_t v[4]; const uint32_t lastAt = ml - 8;
+                    #pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) v[k] = zs_load64(dstBase + msrc + min(8 * k, lastAt));
+                    #pragma unroll
+                    for (uint32_t k = 0; k < 4; k++) if (8 * k < ml) __builtin_memcpy(dstBase + mdst + min(8 * k, lastAt), &v[k], 8);
+                } else if (ml >= 4) {
+                    const uint32_t x0 = zs_load32(dstBase + msrc), x1 = zs_load32(dstBase + msrc + ml - 4);
+                    __builtin_memcpy(dstBase + mdst, &x0, 4); __builtin_memcpy(dstBase + mdst + ml - 4, &x1, 4);
+                } else for (uint32_t j = 0; j < ml; j++) dstBase[mdst + j] = dstBase[msrc + j];
+            }
+            for (uint64_t lm = __ballot(in && (self || ml > 32)); lm; lm &= lm - 1) {
+                const int t = __builtin_ctzll(lm);
+                const uint32_t m2 = wave_get(ml, t), o2 = wave_get(off, t);
+                const uint64_t s2 = wave_get64(msrc, t), d2 = wave_get64(mdst, t);
+                if (o2 >= m2) { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j]; }
+                else { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + (j % o2)]; }      // period = offset
+            }
             wave_mem_sync();
+            rem &= ~grp;
         }
+        ZS_PF_STAMP(2)                                                        // matches inside the tile
         op += wave_last(incl);
         litPos += wave_last(inclL);
     }
@@ -863,7 +938,10 @@ __device__ __forceinline__ uint32_t decodeBlock(DLds &L, DState &st, uint8_t *ds
             wave_sync();
             PROF_ADD(2);
             if (L.misc[0]) return ZE(E_corruption_detected);
-            { const uint32_t e = execTile(L.u.sq.tileLL, L.u.sq.tileML, L.u.sq.tileOff, T, dstBase, frameStart, oend, litPtr, litSize, op, litPos); if (e) return e; }
+#ifdef ZS_EXEC_PROFILE
+            uint64_t pfDummy[8];
+#endif
+            { const uint32_t e = execTile(L.u.sq.tileLL, L.u.sq.tileML, L.u.sq.tileOff, T, dstBase, frameStart, oend, litPtr, litSize, op, litPos ZS_PF_DUMMY); if (e) return e; }
             PROF_ADD(3);
             left -= T;
         }
