@@ -383,8 +383,11 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 // k_dec_execute : one wavefront per item: the decoded sequences, 64 at a time, through execTile; last literals; size check.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef ZS_EXEC_MINWG
+#define ZS_EXEC_MINWG 1
+#endif
 template <int F>
-__global__ void __launch_bounds__(64 * F)
+__global__ void __launch_bounds__(64 * F, ZS_EXEC_MINWG)
 k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
               const ZsFastSeq *__restrict__ seqAll, uint8_t *__restrict__ litScratchAll, uint8_t *dstAll, uint32_t *__restrict__ dstSizes)
 {

@@ -618,7 +618,10 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
         // runs a tile on the log data), and the first round of long runs shares its round trip with the short ones.
         {
             uint64_t lm = __ballot(ll > 16);
-            constexpr uint32_t LR = 8;
+#ifndef ZS_EXEC_LR
+#define ZS_EXEC_LR 8
+#endif
+            constexpr uint32_t LR = ZS_EXEC_LR;
             uint32_t l2[LR], s2[LR]; uint64_t d2[LR]; uint8_t v[LR];
             auto take = [&]() {
                 #pragma unroll
