@@ -303,7 +303,10 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
 // k_dec_sequences : lane g = item g of the group.  Tables in LDS (2.5 KiB an item: 16-bit cells), bitstream windows in LDS.
 // The per-sequence code is decodeBlock's (:1473-1553); results go to global memory, 12 bytes a sequence.
 // ---------------------------------------------------------------------------------------------------------------------
-struct SeqDecLds { uint16_t cells[ZS_FAST_SEQGROUP][1280]; uint32_t win[ZS_FAST_SEQGROUP][(ZS_FAST_SEQWIN + 8) / 4 + 2]; };
+#ifndef ZS_FAST_CELLPAD
+#define ZS_FAST_CELLPAD 0
+#endif
+struct SeqDecLds { uint16_t cells[ZS_FAST_SEQGROUP][1280 + ZS_FAST_CELLPAD]; uint32_t win[ZS_FAST_SEQGROUP][(ZS_FAST_SEQWIN + 8) / 4 + 2]; };
 
 __global__ void __launch_bounds__(64)
 k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
