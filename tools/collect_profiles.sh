@@ -31,3 +31,10 @@ for r in rows:
 json.dump(out, open(f"gpurun_out/{tag}_traffic.json", "w"), indent=1)
 print(json.dumps(out["kernels"], indent=1))
 PY
+# decode side: kernel stats of tools/bench_decode.py (16384 frames of 32 KiB) and its JSON line
+timeout -k 5 240 python tools/bench_decode.py > gpurun_out/${tag}_decode_bench.json 2> gpurun_out/${tag}_decode_bench.err || true
+timeout -k 5 240 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_dec -- python tools/bench_decode.py > gpurun_out/${tag}_decode_under_rocprof.json 2> gpurun_out/${tag}_decode_rocprof.err || true
+cp $(ls gpurun_out/prof_${tag}_dec/*/*_kernel_stats.csv | head -1) gpurun_out/${tag}_decode_kernel_stats.csv
+# 128 KiB chunks and level 1 (BASELINE configs 3 and 5 shapes)
+timeout -k 5 240 python bench.py --chunks 2048 --chunk-size 131072 --no-cpu-baseline > gpurun_out/${tag}_bench_128k.json 2>/dev/null || true
+timeout -k 5 240 python bench.py --chunks 2048 --chunk-size 131072 --level 1 --no-cpu-baseline > gpurun_out/${tag}_bench_128k_l1.json 2>/dev/null || true
