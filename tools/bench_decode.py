@@ -9,7 +9,7 @@ import torch
 from zstandard_amd import BatchCodec
 import _data as D, _oracle as O
 
-ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=16384); ap.add_argument("--chunk", type=int, default=32768)
+ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=57344); ap.add_argument("--chunk", type=int, default=32768)
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2); a = ap.parse_args()
 n, cs = a.frames, a.chunk
 host = D.zipf_log(n * cs, threads=32)

@@ -133,6 +133,9 @@ struct zsmi_ctx {
     // decompress workspace
     DevBuf dItems, dLitScratch, dFastDesc, dHufTabs, dSeqTabs, dSeqOut;     // decode: items, literal scratch, fast-path tables and sequences
     bool decodeFast = true;              // ZSMI_DEC_FAST=0: general kernel only
+    uint32_t maxItemsInFlight = 65536;   // ZSMI_ITEMS_IN_FLIGHT: items per decode launch (scratch: 263 KiB an item, reserved for what a call needs).
+                                         // Every decode kernel is a long dependent chain per item: a launch is one to three rounds of workgroups and its
+                                         // last round is mostly tail, so big launches pay (16384 frames of 32 KiB: 82 GiB/s, 57344: 104 GiB/s)
     PinBuf hItems;
     // staging for host-buffer calls
     DevBuf sSrc, sDst, sSizes;
@@ -173,6 +176,7 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_OVERLAP")) c->overlapEntropy = atoi(e) != 0;
     if (const char *e = getenv("ZSMI_DEC_FAST")) c->decodeFast = atoi(e) != 0;
+    if (const char *e = getenv("ZSMI_ITEMS_IN_FLIGHT")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->maxItemsInFlight = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_STOP_LIT")) c->stopLit = atoi(e);
     if (const char *e = getenv("ZSMI_STOP_SEQ")) c->stopSeq = atoi(e);
     if (const char *e = getenv("ZSMI_LANES")) { long v = atol(e); if (v >= 1 && v <= zsmi_ctx::kMaxLanes) c->nLanes = (int)v; }
@@ -369,7 +373,7 @@ extern "C" int zsmi_decompressBatchDevice(zsmi_ctx *c, const void *dSrc, const u
     ZsDecItem *hi = (ZsDecItem *)c->hItems.p;
     for (uint32_t i = 0; i < n; i++) { hi[i].srcOff = srcOffsets[i]; hi[i].dstOff = dstOffsets[i]; hi[i].srcSize = srcSizes[i]; hi[i].dstCap = dstCaps[i]; }
     if (hipMemcpyAsync(c->dItems.p, hi, sizeof(ZsDecItem) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
-    const uint32_t cap = std::min<uint32_t>(n, 8192);
+    const uint32_t cap = std::min<uint32_t>(n, c->maxItemsInFlight);
     if (!c->dLitScratch.reserve((size_t)cap * ((1u << 17) + 64))) return ZSMI_error_memory_allocation;
     const bool fast = c->decodeFast;
     if (fast && (!c->dFastDesc.reserve((size_t)cap * sizeof(ZsFastDesc)) || !c->dHufTabs.reserve((size_t)cap * ZS_FAST_HUFTAB_BYTES) ||
