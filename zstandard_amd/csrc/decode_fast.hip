@@ -387,7 +387,7 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
 // k_dec_execute : one wavefront per item: the decoded sequences, 64 at a time, through execTile; last literals; size check.
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef ZS_EXEC_MINWG
-#define ZS_EXEC_MINWG 1
+#define ZS_EXEC_MINWG 6                 // 6 workgroups = 6 wavefronts per SIMD at <= 80 VGPRs (24 bytes of spill); measured 1: 5.86 ms, 6: 5.42, 7: 5.43, 8: 6.46
 #endif
 template <int F>
 __global__ void __launch_bounds__(64 * F, ZS_EXEC_MINWG)

@@ -601,18 +601,19 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
     {
         const uint32_t ll = (lane < T) ? tileLL[lane] : 0u, ml = (lane < T) ? tileML[lane] : 0u, off = (lane < T) ? tileOff[lane] : 0u;
         const uint32_t incl = wave_incl_scan(ll + ml), inclL = wave_incl_scan(ll);
-        const uint64_t outStart = op + (incl - ll - ml);              // where my literals go
+        const uint64_t outStart64 = op + (incl - ll - ml);            // where my literals go
         const uint32_t litStart = litPos + (inclL - ll);
-        const uint64_t mdst = outStart + ll;                          // where my match goes
         uint32_t err = 0;
         if (lane < T) {
-            if ((uint64_t)ll + ml > oend - outStart || outStart > oend) err = E_dstSize_tooSmall;
+            if ((uint64_t)ll + ml > oend - outStart64 || outStart64 > oend) err = E_dstSize_tooSmall;
             else if (ll > litSize - litStart || litStart > litSize) err = E_corruption_detected;
-            else if (off > mdst - frameStart) err = E_corruption_detected;
+            else if (off > outStart64 + ll - frameStart) err = E_corruption_detected;
         }
         const uint64_t em = __ballot(err != 0);
         if (em) return ZE(wave_get(err, __builtin_ctzll(em)));
-        const uint64_t tileStart = op;
+        // past the checks every position of the tile lies inside the item's output, whose capacity is a 32-bit count
+        // (ZStdDecompress.cs:2182, size_t = UInt32): positions are 32-bit offsets from dstBase from here on
+        const uint32_t outStart = (uint32_t)outStart64, mdst = outStart + ll, tileStart = (uint32_t)op, oend32 = (uint32_t)oend;
         // literals.  Runs of <= 16 bytes by their own lane (two 8-byte loads), longer runs by the whole wavefront, eight runs at a
         // time; all the loads of a round are issued before its stores (a run at a time is a memory round trip per run; ~6 long
         // runs a tile on the log data), and the first round of long runs shares its round trip with the short ones.
@@ -622,12 +623,12 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
 #define ZS_EXEC_LR 8
 #endif
             constexpr uint32_t LR = ZS_EXEC_LR;
-            uint32_t l2[LR], s2[LR]; uint64_t d2[LR]; uint8_t v[LR];
+            uint32_t l2[LR], s2[LR], d2[LR]; uint8_t v[LR];
             auto take = [&]() {
                 #pragma unroll
                 for (uint32_t k = 0; k < LR; k++) {
                     l2[k] = 0; s2[k] = 0; d2[k] = 0;
-                    if (lm) { const int t = __builtin_ctzll(lm); lm &= lm - 1; l2[k] = wave_get(ll, t); s2[k] = wave_get(litStart, t); d2[k] = wave_get64(outStart, t); }
+                    if (lm) { const int t = __builtin_ctzll(lm); lm &= lm - 1; l2[k] = wave_get(ll, t); s2[k] = wave_get(litStart, t); d2[k] = wave_get(outStart, t); }
                 }
             };
             auto loads = [&]() {
@@ -648,7 +649,7 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
             if (shortRun) {
                 uint8_t *dp = dstBase + outStart;
                 if (wide) {
-                    if ((ll + ml >= 16 && outStart + 16 <= oend) || ll == 16) {
+                    if ((ll + ml >= 16 && oend32 - outStart >= 16) || ll == 16) {
                         // 16 bytes at once: what runs past the literals lands in this sequence's own match bytes, written later
                         __builtin_memcpy(dp, &a, 8); __builtin_memcpy(dp + 8, &c, 8);
                     } else {
@@ -666,7 +667,7 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
         }
         ZS_PF_STAMP(0)                                                        // scans, checks, literals (no wait: the next matches read older output)
         // matches reading only output that existed before this tile
-        const uint64_t msrc = mdst - off;
+        const uint32_t msrc = mdst - off;
         const bool indep = ml && (msrc + ml <= tileStart);
         if (indep && ml <= 32) {
             if (ml >= 8) {
@@ -685,7 +686,7 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
         for (uint64_t lm = __ballot(indep && ml > 32); lm; lm &= lm - 1) {
             const int t = __builtin_ctzll(lm);
             const uint32_t m2 = wave_get(ml, t);
-            const uint64_t s2 = wave_get64(msrc, t), d2 = wave_get64(mdst, t);
+            const uint32_t s2 = wave_get(msrc, t), d2 = wave_get(mdst, t);
             for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j];
         }
         wave_mem_sync();
@@ -697,7 +698,7 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
         // instead of one a match (26 such matches in ~8 groups per tile on the log data).
         for (uint64_t rem = __ballot(ml && !indep); rem; ) {
             const int g0 = __builtin_ctzll(rem);
-            const uint64_t lo = wave_get64(mdst, g0);
+            const uint32_t lo = wave_get(mdst, g0);
             const uint64_t viol = __ballot(((rem >> lane) & 1ull) && (int)lane > g0 && msrc + ml > lo);
             const uint64_t grp = viol ? (rem & ((1ull << __builtin_ctzll(viol)) - 1ull)) : rem;
             const bool in = (grp >> lane) & 1ull;
@@ -717,7 +718,7 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
             for (uint64_t lm = __ballot(in && (self || ml > 32)); lm; lm &= lm - 1) {
                 const int t = __builtin_ctzll(lm);
                 const uint32_t m2 = wave_get(ml, t), o2 = wave_get(off, t);
-                const uint64_t s2 = wave_get64(msrc, t), d2 = wave_get64(mdst, t);
+                const uint32_t s2 = wave_get(msrc, t), d2 = wave_get(mdst, t);
                 if (o2 >= m2) { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j]; }
                 else { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + (j % o2)]; }      // period = offset
             }
