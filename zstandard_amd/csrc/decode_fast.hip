@@ -23,7 +23,10 @@
 #endif                     // bytes of each sequence bitstream staged in LDS at a time
 #define ZS_FAST_GROUP    16u                      // items per wavefront of the Huffman kernel (4 lanes each)
 #ifndef ZS_FAST_SEQGROUP
-#define ZS_FAST_SEQGROUP 4u                       // items per wavefront of the sequences kernel (2.5 KiB of tables each); measured 2: 3.06 ms, 4: 2.32, 8: 3.28, 16: 2.51
+#define ZS_FAST_SEQGROUP 4u                       // items per wavefront of the sequences kernel (2.5 KiB of tables each); measured 2: 3.06 ms, 4: 2.32, 8: 3.28, 16: 2.51 per 16384 items
+#endif
+#ifndef ZS_FAST_SEQGROUP_SMALL
+#define ZS_FAST_SEQGROUP_SMALL 16u                // the same for items with tables of <= 2^8 cells (1.5 KiB): measured 4: 4.36 ms, 8: 3.70, 16: 3.16 per 57344 items
 #endif
 
 struct ZsFastDesc {                               // per item, global memory, written by k_dec_prep
@@ -306,25 +309,32 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
 #ifndef ZS_FAST_CELLPAD
 #define ZS_FAST_CELLPAD 0
 #endif
-struct SeqDecLds { uint16_t cells[ZS_FAST_SEQGROUP][1280 + ZS_FAST_CELLPAD]; uint32_t win[ZS_FAST_SEQGROUP][(ZS_FAST_SEQWIN + 8) / 4 + 2]; };
+// The kernel comes in two table sizes: LOG9 = false holds items whose LL and ML tables have <= 2^8 cells (blocks of <= 2048
+// sequences get such tables: FSE_optimalTableLog) in 1.5 KiB, LOG9 = true the rest in 2.5 KiB.  How many items a CU decodes
+// at once is set by that LDS share, and the kernel's time by how many it decodes at once.  Both are launched over all
+// groups; a lane takes its item only in the kernel of the item's class.
+template <bool LOG9, uint32_t G>
+struct SeqDecLds { uint16_t cells[G][(LOG9 ? 1280 : 768) + ZS_FAST_CELLPAD]; uint32_t win[G][(ZS_FAST_SEQWIN + 8) / 4 + 2]; };
 
+template <bool LOG9, uint32_t G>
 __global__ void __launch_bounds__(64)
 k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
                 const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll)
 {
-    __shared__ SeqDecLds S;
+    __shared__ SeqDecLds<LOG9, G> S;
+    constexpr uint32_t LLC = LOG9 ? 512 : 256, OFB = LLC, MLB = LLC + 256;        // cells of the LL table; where OF and ML start
     const uint32_t lane = (uint32_t)zs_lane();
-    const uint32_t item = blockIdx.x * ZS_FAST_SEQGROUP + lane;
+    const uint32_t item = blockIdx.x * G + lane;
     bool mine = false; uint32_t nbSeq = 0, size = 0, llLog = 0, ofLog = 0, mlLog = 0;
     const uint8_t *src = srcAll;
-    if (lane < ZS_FAST_SEQGROUP && item < nItems) {
+    if (lane < G && item < nItems) {
         const ZsFastDesc *d = descs + item;
-        if (d->fast && d->nbSeq) { mine = true; nbSeq = d->nbSeq; size = d->seqSize; llLog = d->llLog; ofLog = d->ofLog; mlLog = d->mlLog; src = srcAll + items[item].srcOff + d->seqOff; }
+        if (d->fast && d->nbSeq && ((d->llLog > 8 || d->mlLog > 8) == LOG9)) { mine = true; nbSeq = d->nbSeq; size = d->seqSize; llLog = d->llLog; ofLog = d->ofLog; mlLog = d->mlLog; src = srcAll + items[item].srcOff + d->seqOff; }
     }
     if (!__ballot(mine)) return;
-    for (uint32_t gg = 0; gg < ZS_FAST_SEQGROUP; gg++) {
+    for (uint32_t gg = 0; gg < G; gg++) {
         if (!wave_get(mine ? 1u : 0u, (int)gg)) continue;
-        const uint32_t *st = reinterpret_cast<const uint32_t *>(seqTabs + (size_t)(blockIdx.x * ZS_FAST_SEQGROUP + gg) * ZS_FAST_SEQTAB_BYTES);
+        const uint32_t *st = reinterpret_cast<const uint32_t *>(seqTabs + (size_t)(blockIdx.x * G + gg) * ZS_FAST_SEQTAB_BYTES);
         const uint32_t a = 1u << wave_get(llLog, (int)gg), o = 1u << wave_get(ofLog, (int)gg), m = 1u << wave_get(mlLog, (int)gg);
         {   // the three tables, two cells a dword: every load issued before the first LDS store (up to 4 + 2 + 4 dwords per lane)
             uint32_t va[4], vo[2], vm[4];
@@ -338,15 +348,15 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
             #pragma unroll
             for (uint32_t u = 0; u < 4; u++) if (2 * (lane + 64 * u) < a) cw[lane + 64 * u] = va[u];
             #pragma unroll
-            for (uint32_t u = 0; u < 2; u++) if (2 * (lane + 64 * u) < o) cw[256 + lane + 64 * u] = vo[u];
+            for (uint32_t u = 0; u < 2; u++) if (2 * (lane + 64 * u) < o) cw[OFB / 2 + lane + 64 * u] = vo[u];
             #pragma unroll
-            for (uint32_t u = 0; u < 4; u++) if (2 * (lane + 64 * u) < m) cw[384 + lane + 64 * u] = vm[u];
+            for (uint32_t u = 0; u < 4; u++) if (2 * (lane + 64 * u) < m) cw[MLB / 2 + lane + 64 * u] = vm[u];
         }
     }
     BitC b; b.c = 0; b.avail = 0; b.bitPos = 0;
     bool ok = !mine || bc_init(b, src, size);
-    const uint16_t *cells = S.cells[lane & (ZS_FAST_SEQGROUP - 1)];
-    const uint32_t *win = S.win[lane & (ZS_FAST_SEQGROUP - 1)];
+    const uint16_t *cells = S.cells[lane & (G - 1)];
+    const uint32_t *win = S.win[lane & (G - 1)];
     ZsFastSeq *outp = seqOutAll + (size_t)item * ZS_FAST_MAXSEQ;
     uint32_t sLL = 0, sOF = 0, sML = 0, t = 0;
     bool started = false, done = !mine || !ok;
@@ -354,7 +364,7 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
     for (;;) {
         const int32_t base = bc_windowBase(b, ZS_FAST_SEQWIN);
         wave_sync();
-        if (!done) stageOwnWindow<ZS_FAST_SEQWIN>(S.win[lane & (ZS_FAST_SEQGROUP - 1)], src, size, base);
+        if (!done) stageOwnWindow<ZS_FAST_SEQWIN>(S.win[lane & (G - 1)], src, size, base);
         wave_sync();
         if (!done) {
             if (!started) { FSEQ_NEED(llLog + ofLog + mlLog); sLL = bc_take(b, llLog); sOF = bc_take(b, ofLog); sML = bc_take(b, mlLog); started = true; }
@@ -362,7 +372,7 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
                 // a sequence reads < 12 bytes of stream: stop for a refill while that much is still inside the window
                 if (b.bitPos > 0 && base > 0 && ((b.bitPos - 1) >> 3) < base + 24) break;
                 if (b.bitPos < 0) { ok = false; break; }                 // stream exhausted before all sequences (:1582, :1594)
-                const uint32_t cLL = cells[sLL], cOF = cells[512 + sOF], cML = cells[768 + sML];
+                const uint32_t cLL = cells[sLL], cOF = cells[OFB + sOF], cML = cells[MLB + sML];
                 uint32_t bLL, bML, bOF, nL, nM, nO, yLL, yML, yOF;
                 zs_fastcell_open(cLL, bLL, nL, yLL); zs_fastcell_open(cML, bML, nM, yML); zs_fastcell_open(cOF, bOF, nO, yOF);
                 outp[t++] = zs_fastseq((uint32_t)b.bitPos, yLL, yML, yOF);

@@ -390,7 +390,8 @@ extern "C" int zsmi_decompressBatchDevice(zsmi_ctx *c, const void *dSrc, const u
             LAUNCH(c, "k_dec_prep", (k_dec_prep<ZS_DEC_GROUP>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc, dI, cnt, dD,
                    (uint8_t *)c->dHufTabs.p, (uint8_t *)c->dSeqTabs.p);
             LAUNCH(c, "k_dec_huffman", k_dec_huffman, dim3(groups), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p);
-            LAUNCH(c, "k_dec_sequences", k_dec_sequences, dim3((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p);
+            LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p);
+            LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, ZS_FAST_SEQGROUP>), dim3((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p);
             LAUNCH(c, "k_dec_execute", (k_dec_execute<4>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const ZsFastSeq *)c->dSeqOut.p,
                    (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0);
             doneFlags = &dD->fast;
