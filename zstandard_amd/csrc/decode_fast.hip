@@ -49,11 +49,8 @@ struct ZsFastDesc {                               // per item, global memory, wr
 typedef uint64_t ZsFastSeq;
 __device__ __forceinline__ ZsFastSeq zs_fastseq(uint32_t bitPos, uint32_t symLL, uint32_t symML, uint32_t symOF)
 { return (uint64_t)(bitPos | (symLL << 20) | (symML << 26)) | ((uint64_t)symOF << 32); }
-// A fast-path table cell in 16 bits (half the LDS of a 4-byte cell = twice the items a CU decodes at once): the symbol in
-// bits 0-5; above it 1 << (9 - nbBits) | (nextState >> nbBits).  nextState is a multiple of 2^nbBits, one of 2^(tableLog -
-// nbBits) (FseDecompress.cs:111-181), and tableLog <= 9: the marker is the highest bit set and gives nbBits back.
-// The extra bits of a code come from the code by arithmetic (LL_bits / ML_bits, ZStdInternal.cs:158,173).
-__device__ __forceinline__ uint32_t zs_fastcell(uint32_t next, uint32_t nb, uint32_t sym) { return ((((1u << (9u - nb)) | (next >> nb)) << 6) | sym); }
+// (the 16-bit cell format: zs_fastcell in decode_kernels.hip.)  The extra bits of a code come from the code by arithmetic
+// (LL_bits / ML_bits, ZStdInternal.cs:158,173).
 __device__ __forceinline__ void zs_fastcell_open(uint32_t c, uint32_t &next, uint32_t &nb, uint32_t &sym)
 {
     const uint32_t p = c >> 6, hb = 31u - (uint32_t)__builtin_clz(p | 1u);
@@ -70,10 +67,11 @@ __global__ void __launch_bounds__(64 * F)
 k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems,
            ZsFastDesc *__restrict__ descs, uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ seqTabs)
 {
-    __shared__ DLds LS[F];
+    // the general decoder's LDS image without its Huffman table and with one sequence table instead of three (4.4 of 15.5 KiB)
+    __shared__ __attribute__((aligned(16))) unsigned char LSraw[F][(ZS_DLDS_PREP + 15) & ~15u];
     const uint32_t item = blockIdx.x * F + (threadIdx.x >> 6);
     if (item >= nItems) return;
-    DLds &L = LS[threadIdx.x >> 6];
+    DLds &L = *reinterpret_cast<DLds *>(LSraw[threadIdx.x >> 6]);
     const ZsDecItem it = items[item];
     const uint32_t lane = (uint32_t)zs_lane();
     const uint8_t *src = srcAll + it.srcOff;
@@ -121,7 +119,8 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                 else { lhSize = 5; litSize = (lhc >> 4) & 0x3FFFF; litCSize = (lhc >> 22) + ((uint32_t)bs[4] << 10); }
                 if (litSize > (1u << 17) || litCSize + lhSize > cSize) break;
                 if (!single && (litSize == 0 || litCSize == 0)) break;
-                const uint32_t h = readHufTable(L, bs + lhSize, litCSize);
+                uint16_t *ht = reinterpret_cast<uint16_t *>(hufTabs + (size_t)item * ZS_FAST_HUFTAB_BYTES);
+                const uint32_t h = readHufTableT<true>(L, bs + lhSize, litCSize, ht, ZS_FAST_HUFLOG);
                 if (isErr(h) || h >= litCSize || L.hufLog > ZS_FAST_HUFLOG) break;
                 const uint32_t cs0 = b0 + lhSize + h, csz = litCSize - h;
                 d.litType = 2; d.litSize = litSize; d.hufLog = L.hufLog;
@@ -139,9 +138,6 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                     for (uint32_t k = 0; k < 4; k++) { d.sCnt[k] = k < 3 ? seg : litSize - 3 * seg; d.sOut[k] = k * seg; }
                 }
                 litCSizeTot = litCSize + lhSize;
-                // the table leaves for the Huffman kernel
-                uint16_t *ht = reinterpret_cast<uint16_t *>(hufTabs + (size_t)item * ZS_FAST_HUFTAB_BYTES);
-                for (uint32_t i = lane; i < (1u << L.hufLog); i += 64) ht[i] = L.huf[i];
             } else {
                 uint32_t lhSize, litSize;
                 if (lhl == 1) { lhSize = 2; litSize = rd16(bs) >> 4; }
@@ -156,17 +152,13 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
         // ---- sequence headers + tables (:1110-1180), then the tables leave for the sequences kernel ----
         const uint8_t *ip = bs + litCSizeTot; uint32_t remaining = cSize - litCSizeTot, nbSeq = 0;
         DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = 0; st.llRepeatOk = 0;
-        if (seqHeaders(L, st, ip, remaining, nbSeq)) break;
+        uint16_t *stab = reinterpret_cast<uint16_t *>(seqTabs + (size_t)item * ZS_FAST_SEQTAB_BYTES);
+        if (lane < 3) L.misc[8 + lane] = 0;
+        if (seqHeadersT<true>(L, st, ip, remaining, nbSeq, stab, &L.misc[8])) break;
         if (nbSeq > ZS_FAST_MAXSEQ) break;
         if (nbSeq == 0 && remaining != 0) break;
         d.nbSeq = nbSeq; d.seqOff = (uint32_t)(ip - src); d.seqSize = remaining;
-        if (nbSeq) {
-            d.llLog = L.LL.tableLog; d.ofLog = L.OF.tableLog; d.mlLog = L.ML.tableLog;
-            uint16_t *stab = reinterpret_cast<uint16_t *>(seqTabs + (size_t)item * ZS_FAST_SEQTAB_BYTES);
-            for (uint32_t i = lane; i < (1u << d.llLog); i += 64) { const SeqSym c = L.LL.cells[i]; stab[i] = (uint16_t)zs_fastcell(c.nextState, c.nbBits, c.sym); }
-            for (uint32_t i = lane; i < (1u << d.ofLog); i += 64) { const SeqSym c = L.OF.cells[i]; stab[512 + i] = (uint16_t)zs_fastcell(c.nextState, c.nbBits, c.sym); }
-            for (uint32_t i = lane; i < (1u << d.mlLog); i += 64) { const SeqSym c = L.ML.cells[i]; stab[768 + i] = (uint16_t)zs_fastcell(c.nextState, c.nbBits, c.sym); }
-        }
+        if (nbSeq) { d.llLog = L.misc[8]; d.ofLog = L.misc[9]; d.mlLog = L.misc[10]; }
         d.fast = 1;
     } while (0);
     if (lane == 0) descs[item] = d;

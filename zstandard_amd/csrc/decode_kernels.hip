@@ -74,10 +74,8 @@ struct SeqTab { uint32_t tableLog; SeqSym cells[512]; };
 #define ZS_LITWIN 512u      // bytes of each Huffman stream staged in LDS at a time
 #define ZS_SEQWIN 1024u     // bytes of the sequence bitstream staged in LDS at a time (a tile of 64 sequences reads < 720)
 struct DLds {
-    uint16_t huf[4096];                 // byte | nbBits << 8   (HufDecompress.cs:109-113)
     uint32_t hufLog;
-    SeqTab LL, ML;
-    struct { uint32_t tableLog; SeqSym cells[256]; } OF;
+    SeqTab LL;
     union {                             // one phase at a time
         struct { uint8_t weights[256]; uint16_t symStart[256]; uint32_t rank[16]; int16_t norm[64]; uint16_t symbolNext[64];
                  struct { uint16_t newState; uint8_t symbol; uint8_t nbBits; } wfse[64];   // weight FSE table (tableLog <= 6)
@@ -88,7 +86,14 @@ struct DLds {
     } u;
     uint32_t misc[16];
     uint32_t llTab[36], mlTab[53];      // base | extra bits << 24 of each LL / ML code (LL_base, LL_bits, ML_base, ML_bits)
+    uint32_t pad16[1];
+    // k_dec_prep allocates the struct up to here (ZS_DLDS_PREP bytes): it builds its three sequence tables one after the other
+    // in LL and its Huffman table in global memory, and what it holds per item decides how many items a CU prepares at once
+    SeqTab ML;
+    struct { uint32_t tableLog; SeqSym cells[256]; } OF;
+    uint16_t huf[4096];                 // byte | nbBits << 8   (HufDecompress.cs:109-113)
 };
+#define ZS_DLDS_PREP (offsetof(DLds, ML))
 __device__ __forceinline__ uint32_t ofBaseOf(uint32_t sym) { return sym == 0 ? 0u : (sym == 1 ? 1u : ((1u << sym) - 3u)); }   // OF_base :1088
 
 __device__ __forceinline__ uint32_t rd16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
@@ -269,7 +274,10 @@ __device__ __forceinline__ void buildSeqTableWave(DLds &L, SeqSym *cells, uint32
 // The weight description (<= 128 bytes) is held in a register window.  One lane parses FSE-compressed weights (serial by
 // nature: two interleaved FSE states); everything after the weights -- checks, rank counts, cell ranges, table fill -- runs
 // on all lanes, lane s of chunk c owning symbol 64c + s.  returns header size or error.
-__device__ __forceinline__ uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t srcSize)
+// hufGlobal == nullptr: the table goes to L.huf (LDS); otherwise to that global table, which holds 2^maxLog cells: a table that
+// needs more is reported as E_tableLog_tooLarge before anything is written (k_dec_prep then leaves the item to the general kernel)
+template <bool TO_GLOBAL>
+__device__ __forceinline__ uint32_t readHufTableT(DLds &L, const uint8_t *src, uint32_t srcSize, uint16_t *hufGlobal, uint32_t maxLog)
 {
     const uint32_t lane = (uint32_t)zs_lane();
     if (!srcSize) return ZE(E_srcSize_wrong);
@@ -359,6 +367,7 @@ __device__ __forceinline__ uint32_t readHufTable(DLds &L, const uint8_t *src, ui
     if (weightTotal == 0) return ZE(E_corruption_detected);
     const uint32_t tableLog = zs_highbit(weightTotal) + 1;
     if (tableLog > 12) return ZE(E_corruption_detected);
+    if (TO_GLOBAL && tableLog > maxLog) return ZE(E_tableLog_tooLarge);
     const uint32_t rest = (1u << tableLog) - weightTotal, lastWeight = zs_highbit(rest) + 1;
     if ((1u << zs_highbit(rest)) != rest) return ZE(E_corruption_detected);
     #pragma unroll
@@ -424,11 +433,13 @@ __device__ __forceinline__ uint32_t readHufTable(DLds &L, const uint8_t *src, ui
         if (!w) continue;
         const uint32_t length = (1u << w) >> 1, startAt = L.u.tb.symStart[n];
         const uint16_t e = (uint16_t)(n | ((tableLog + 1 - w) << 8));
-        for (uint32_t u = lane; u < length; u += 64) L.huf[startAt + u] = e;
+        if (TO_GLOBAL) { for (uint32_t u = lane; u < length; u += 64) hufGlobal[startAt + u] = e; }
+        else { for (uint32_t u = lane; u < length; u += 64) L.huf[startAt + u] = e; }
     }
     wave_sync();
     return iSize + 1;
 }
+__device__ __forceinline__ uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t srcSize) { return readHufTableT<false>(L, src, srcSize, nullptr, 12); }
 
 // ---- stream windows in LDS.  The serial decoders (Huffman: one lane per stream; sequences: lane 0) read their backward
 //      bitstreams from LDS: a global load inside such a dependent chain costs a full memory round trip per ~64 bits
@@ -732,9 +743,17 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
     return 0;
 }
 
+// A fast-path table cell in 16 bits (half the LDS of a 4-byte cell = twice the items a CU decodes at once): the symbol in
+// bits 0-5; above it 1 << (9 - nbBits) | (nextState >> nbBits).  nextState is a multiple of 2^nbBits, one of 2^(tableLog -
+// nbBits) (FseDecompress.cs:111-181), and tableLog <= 9: the marker is the highest bit set and gives nbBits back.
+__device__ __forceinline__ uint32_t zs_fastcell(uint32_t next, uint32_t nb, uint32_t sym) { return ((((1u << (9u - nb)) | (next >> nb)) << 6) | sym); }
+
 // ---- sequence headers (DecodeSeqHeaders :1110-1180): number of sequences, the three tables.  ip / remaining move past them.
 //      Returns 0 or an error code. ----
-__device__ __forceinline__ uint32_t seqHeaders(DLds &L, const DState &st, const uint8_t *&ip, uint32_t &remaining, uint32_t &nbSeq)
+//      EMIT (k_dec_prep): each table is built in L.LL, turned into 16-bit fast-path cells and stored to stab (LL at cell 0, OF at
+//      512, ML at 768) before the next one takes its place; logsOut[t] = its tableLog.
+template <bool EMIT>
+__device__ __forceinline__ uint32_t seqHeadersT(DLds &L, const DState &st, const uint8_t *&ip, uint32_t &remaining, uint32_t &nbSeq, uint16_t *stab, uint32_t *logsOut)
 {
     const uint32_t lane = (uint32_t)zs_lane();
     {
@@ -752,8 +771,8 @@ __device__ __forceinline__ uint32_t seqHeaders(DLds &L, const DState &st, const 
             for (int t = 0; t < 3; t++) {
                 const uint32_t type = (modes >> (6 - 2 * t)) & 3;
                 const uint32_t maxS = t == 0 ? 35 : (t == 1 ? 31 : 52), maxLog = t == 1 ? 8 : 9;
-                SeqSym *cells = t == 0 ? L.LL.cells : (t == 1 ? L.OF.cells : L.ML.cells);
-                uint32_t *tl = t == 0 ? &L.LL.tableLog : (t == 1 ? &L.OF.tableLog : &L.ML.tableLog);
+                SeqSym *cells = (EMIT || t == 0) ? L.LL.cells : (t == 1 ? L.OF.cells : L.ML.cells);
+                uint32_t *tl = (EMIT || t == 0) ? &L.LL.tableLog : (t == 1 ? &L.OF.tableLog : &L.ML.tableLog);
                 const int16_t *dn = t == 0 ? d_LL_defaultNorm : (t == 1 ? d_OF_defaultNorm : d_ML_defaultNorm);
                 const uint32_t dmax = t == 0 ? 35 : (t == 1 ? 28 : 52);
                 hw_stage(L.u.tb.hdrWin, ip + consumed, (uint32_t)(iend - (ip + consumed)));           // this table's description, staged
@@ -785,6 +804,12 @@ __device__ __forceinline__ uint32_t seqHeaders(DLds &L, const DState &st, const 
                 if (type == 0) { if (lane <= dmax) L.u.tb.norm[lane] = dn[lane]; wave_sync(); }
                 if (type == 0 || type == 2) buildSeqTableWave(L, cells, tl, bmax, blog);
                 wave_sync();
+                if (EMIT) {
+                    const uint32_t log = *tl, at = t == 0 ? 0u : (t == 1 ? 512u : 768u);
+                    for (uint32_t i = lane; i < (1u << log); i += 64) { const SeqSym c = cells[i]; stab[at + i] = (uint16_t)zs_fastcell(c.nextState, c.nbBits, c.sym); }
+                    if (lane == 0) logsOut[t] = log;
+                    wave_sync();
+                }
             }
             ip += consumed;
             remaining = (uint32_t)(iend - ip);
@@ -792,6 +817,8 @@ __device__ __forceinline__ uint32_t seqHeaders(DLds &L, const DState &st, const 
     }
     return 0;
 }
+__device__ __forceinline__ uint32_t seqHeaders(DLds &L, const DState &st, const uint8_t *&ip, uint32_t &remaining, uint32_t &nbSeq)
+{ return seqHeadersT<false>(L, st, ip, remaining, nbSeq, nullptr, nullptr); }
 
 // ---- one compressed block (ZSTD_decompressBlock_internal :1868-1909). returns decoded size or error ----
 
