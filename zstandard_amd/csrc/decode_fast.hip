@@ -210,7 +210,7 @@ __device__ __forceinline__ void stageOwnWindow(uint32_t *win, const uint8_t *src
 // k_dec_huffman : lane 4g + k = stream k of item g.  Tables in LDS (16 x 4 KiB), stream windows in LDS, refilled in rounds
 // by all lanes; symbol loop of the general decoder (four symbols per refill, then the careful tail).
 // ---------------------------------------------------------------------------------------------------------------------
-struct HufLds { uint16_t huf[ZS_FAST_GROUP][1u << ZS_FAST_HUFLOG]; uint32_t win[64][(ZS_FAST_HUFWIN + 8) / 4 + 2]; };
+struct HufLds { uint16_t huf[ZS_FAST_GROUP][ZS_HUF2_ENTRIES]; uint32_t win[64][(ZS_FAST_HUFWIN + 8) / 4 + 2]; };     // two-level tables: 1.25 KiB an item
 
 __global__ void __launch_bounds__(64)
 k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
@@ -238,13 +238,13 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
         if (!log2) continue;
         const uint32_t *ht = reinterpret_cast<const uint32_t *>(hufTabs + (size_t)it2 * ZS_FAST_HUFTAB_BYTES);
         uint32_t *dstw = reinterpret_cast<uint32_t *>(H.huf[gg]);
-        {   // <= 16 dwords per lane, the loads issued together
-            const uint32_t words = (1u << log2) / 2;
-            uint32_t v[16];
+        {   // 5 dwords per lane, the loads issued together
+            constexpr uint32_t words = ZS_HUF2_ENTRIES / 2, per = (words + 63) / 64;
+            uint32_t v[per];
             #pragma unroll
-            for (uint32_t u = 0; u < 16; u++) v[u] = (lane + 64 * u < words) ? ht[lane + 64 * u] : 0u;
+            for (uint32_t u = 0; u < per; u++) v[u] = (lane + 64 * u < words) ? ht[lane + 64 * u] : 0u;
             #pragma unroll
-            for (uint32_t u = 0; u < 16; u++) if (lane + 64 * u < words) dstw[lane + 64 * u] = v[u];
+            for (uint32_t u = 0; u < per; u++) if (lane + 64 * u < words) dstw[lane + 64 * u] = v[u];
         }
     }
     BitC b; b.c = 0; b.avail = 0; b.bitPos = 0;
@@ -253,7 +253,6 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     bool done = !mine || !ok || n == 0;
     const uint16_t *huf = H.huf[g];
     const uint32_t *win = H.win[lane];
-    const uint32_t sh = 32u - dtLog;
     for (;;) {
         const int32_t base = bc_windowBase(b, ZS_FAST_HUFWIN);
         wave_sync();
@@ -267,7 +266,9 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
                 uint32_t used = 0, pack = 0;
                 #pragma unroll
                 for (int q = 0; q < 4; q++) {
-                    const uint32_t e = huf[(uint32_t)(c >> 32) >> sh];
+                    const uint32_t top = (uint32_t)(c >> 32);
+                    uint32_t e = huf[top >> 23];                                   // 9 bits; codes of 10 / 11 bits: 2 more in a sub-table
+                    if (e & 0x8000u) e = huf[512u + ((e & 0x7FFFu) << 2) + ((top >> 21) & 3u)];
                     const uint32_t nb = e >> 8;
                     c <<= nb; used += nb; pack |= (e & 0xFFu) << (8 * q);
                 }
@@ -281,7 +282,9 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
                     if (b.bitPos > 0 && base > 0 && ((b.bitPos - 1) >> 3) < base + 8) break;
                     bc_refill(b, win, base);
                 }
-                const uint32_t e = huf[(uint32_t)(b.c >> 32) >> sh];
+                const uint32_t top = (uint32_t)(b.c >> 32);
+                uint32_t e = huf[top >> 23];
+                if (e & 0x8000u) e = huf[512u + ((e & 0x7FFFu) << 2) + ((top >> 21) & 3u)];
                 const uint32_t nb = e >> 8;
                 b.c <<= nb; b.avail -= nb; b.bitPos -= (int32_t)nb;
                 out[i++] = (uint8_t)e;

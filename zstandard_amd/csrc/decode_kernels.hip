@@ -274,8 +274,11 @@ __device__ __forceinline__ void buildSeqTableWave(DLds &L, SeqSym *cells, uint32
 // The weight description (<= 128 bytes) is held in a register window.  One lane parses FSE-compressed weights (serial by
 // nature: two interleaved FSE states); everything after the weights -- checks, rank counts, cell ranges, table fill -- runs
 // on all lanes, lane s of chunk c owning symbol 64c + s.  returns header size or error.
-// hufGlobal == nullptr: the table goes to L.huf (LDS); otherwise to that global table, which holds 2^maxLog cells: a table that
-// needs more is reported as E_tableLog_tooLarge before anything is written (k_dec_prep then leaves the item to the general kernel)
+// TO_GLOBAL false: the flat table goes to L.huf (LDS).  TO_GLOBAL true (k_dec_prep): a two-level table goes to hufGlobal
+// (ZS_HUF2_ENTRIES 16-bit entries); a table of more than maxLog bits or one that does not fit is reported as
+// E_tableLog_tooLarge before anything the fast path would use is complete (the item is then left to the general kernel)
+#define ZS_HUF2_SUBS    32u                         // sub-tables (9-bit prefixes holding longer codes) the fast path has room for
+#define ZS_HUF2_ENTRIES (512u + 4u * ZS_HUF2_SUBS)
 template <bool TO_GLOBAL>
 __device__ __forceinline__ uint32_t readHufTableT(DLds &L, const uint8_t *src, uint32_t srcSize, uint16_t *hufGlobal, uint32_t maxLog)
 {
@@ -433,8 +436,49 @@ __device__ __forceinline__ uint32_t readHufTableT(DLds &L, const uint8_t *src, u
         if (!w) continue;
         const uint32_t length = (1u << w) >> 1, startAt = L.u.tb.symStart[n];
         const uint16_t e = (uint16_t)(n | ((tableLog + 1 - w) << 8));
-        if (TO_GLOBAL) { for (uint32_t u = lane; u < length; u += 64) hufGlobal[startAt + u] = e; }
-        else { for (uint32_t u = lane; u < length; u += 64) L.huf[startAt + u] = e; }
+        if (!TO_GLOBAL) { for (uint32_t u = lane; u < length; u += 64) L.huf[startAt + u] = e; }
+    }
+    if (TO_GLOBAL) {
+        // The fast path's two-level table (ZS_HUF2_*): P[512] is indexed by the next 9 stream bits; a code of <= 9 bits owns whole
+        // entries of P (tables of < 9 bits are spread out), a 9-bit prefix under which 10- and 11-bit codes sit points (bit 15)
+        // to a 4-entry sub-table indexed by the next 2 bits.  1.25 KiB an item instead of the 4 KiB of a flat 2^11 table; more
+        // than ZS_HUF2_SUBS such prefixes: the item is left to the general kernel.
+        const uint32_t extra = tableLog > 9 ? tableLog - 9 : 0u, rep = tableLog < 9 ? 9 - tableLog : 0u;
+        uint16_t *subOf = reinterpret_cast<uint16_t *>(L.LL.cells);                 // scratch: 512 entries, sub-table id + 1 of a prefix
+        for (uint32_t i = lane; i < 512; i += 64) subOf[i] = 0;
+        wave_sync();
+        for (uint32_t n = 0; n < nbSymbols; n++) {
+            const uint32_t w = L.u.tb.weights[n];
+            if (w && tableLog + 1 - w > 9 && lane == 0) subOf[L.u.tb.symStart[n] >> extra] = 1;
+        }
+        wave_sync();
+        {
+            uint32_t f[8], cnt = 0;
+            #pragma unroll
+            for (uint32_t q = 0; q < 8; q++) { f[q] = subOf[8 * lane + q]; cnt += f[q]; }
+            const uint32_t incl = wave_incl_scan(cnt);
+            if (wave_last(incl) > ZS_HUF2_SUBS) return ZE(E_tableLog_tooLarge);
+            uint32_t id = incl - cnt;
+            wave_sync();
+            #pragma unroll
+            for (uint32_t q = 0; q < 8; q++) { if (f[q]) { subOf[8 * lane + q] = (uint16_t)(id + 1); id++; } }
+        }
+        wave_sync();
+        for (uint32_t n = 0; n < nbSymbols; n++) {        // uniform loop; lanes fill one symbol's entries together
+            const uint32_t w = L.u.tb.weights[n];
+            if (!w) continue;
+            const uint32_t nb = tableLog + 1 - w, length = (1u << w) >> 1, startAt = L.u.tb.symStart[n];
+            const uint16_t e = (uint16_t)(n | (nb << 8));
+            if (nb <= 9) {
+                const uint32_t lo = tableLog >= 9 ? startAt >> extra : startAt << rep, hi = tableLog >= 9 ? (startAt + length) >> extra : (startAt + length) << rep;
+                for (uint32_t u = lo + lane; u < hi; u += 64) hufGlobal[u] = e;
+            } else if (lane < 4) {
+                const uint32_t prefix = startAt >> extra, sub = (uint32_t)subOf[prefix] - 1u;
+                const uint32_t j = (prefix << extra) + (lane >> (2 - extra));              // the cell of the flat table this sub-table slot stands for
+                if (j >= startAt && j < startAt + length) hufGlobal[512 + sub * 4 + lane] = e;
+            }
+        }
+        for (uint32_t i = lane; i < 512; i += 64) { const uint32_t sid = subOf[i]; if (sid) hufGlobal[i] = (uint16_t)(0x8000u | (sid - 1u)); }
     }
     wave_sync();
     return iSize + 1;
