@@ -17,6 +17,8 @@ def content(rng, total):
     parts.append(np.repeat(rng.integers(0, 256, total // 4096 + 1, dtype=np.uint8), 512)[: total // 8])   # runs
     parts.append(np.tile(np.frombuffer(D.alphabet_data(), dtype=np.uint8), total // 8 // 3409 + 1)[: total // 8])
     parts.append(rng.choice(np.array([65, 66, 67, 10], dtype=np.uint8), total // 8, p=[0.7, 0.2, 0.05, 0.05]))   # skewed
+    pz = 1.0 / np.arange(1, 257) ** 1.1
+    parts.append(rng.choice(256, total // 8, p=pz / pz.sum()).astype(np.uint8))          # long tail of rare symbols: 10- and 11-bit Huffman codes
     return np.concatenate(parts)
 
 def sizes_for(rng, n):

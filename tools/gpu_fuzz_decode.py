@@ -18,6 +18,10 @@ def pieces(rng, total):
     yield rng.choice(np.array([97, 98, 99, 32, 10], dtype=np.uint8), total, p=[0.5, 0.2, 0.1, 0.15, 0.05])
     per = rng.integers(0, 256, 37, dtype=np.uint8); yield np.tile(per, total // 37 + 1)[:total]          # short period: overlapping copies
     yield rng.integers(0, 256, total, dtype=np.uint8)
+    # 256 symbols with a long tail of rare ones: Huffman tables with many 10- and 11-bit codes (the fast path's two-level table
+    # and its fall-back when the long codes need more sub-tables than it holds)
+    pz = 1.0 / np.arange(1, 257) ** 1.1; yield rng.choice(256, total, p=pz / pz.sum()).astype(np.uint8)
+    pg = 0.97 ** np.arange(256); yield rng.choice(256, total, p=pg / pg.sum()).astype(np.uint8)
 
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
