@@ -523,7 +523,9 @@ __device__ __forceinline__ uint32_t huffEncodeStream(K3Lds &L, uint32_t *tile, u
 // per-block result of the two encode kernels, consumed by k_assemble_frames
 // ---------------------------------------------------------------------------------------------
 struct ZsBlockMeta { uint32_t type;       // 0 raw, 1 rle, 2 literal + sequence sections present
-                     uint32_t rleByte; uint32_t litSecSize; uint32_t seqSecSize; };   // seqSecSize 0xFFFFFFFF: section failed / overflowed
+                     uint32_t rleByte; uint32_t litSecSize; uint32_t seqSecSize;      // seqSecSize 0xFFFFFFFF: section failed / overflowed
+                     uint32_t seqHdrSize, seqGap;     // the sequence section lies in its buffer as seqHdrSize bytes, seqGap (0..3) unused bytes,
+                     uint32_t pad[2]; };              // then the bitstream (built 4-byte aligned); k_assemble_frames closes the gap as it copies
 #define ZS_LITSEC_STRIDE  (ZS_BLOCK_MAX + 1024u)
 #define ZS_SEQSEC_STRIDE  (ZS_BLOCK_MAX + 4096u)
 #define ZS_STREAM_STRIDE  (24u * 1024u)          // per Huffman stream scratch: 16384 symbols * 11 bits = 22528 B max
@@ -893,6 +895,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
     // ======== part 1, each wavefront on its own block (no workgroup barrier inside): header, recent-offset codes,
     //          histograms, tables.  result: section size so far / 0xFFFFFFFF = no compressed sequences section ========
     uint32_t result = 0xFFFFFFFFu, nseq = 0, bitstreamOff = 0;
+    uint32_t secHdr = 0xFFFFFFFFu, secGap = 0;        // where the bitstream lies behind the headers (0xFFFFFFFF: no bitstream, the section is all headers)
     bool live = false;                                  // this wavefront has a bitstream to write in part 2
     do {
         if (!exists || n < 16) break;
@@ -1170,21 +1173,14 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
             sink_put(sink, lo, 0u, nb);
         }
         const uint32_t bsSize = sink_close(sink);
-        // move the stream down to its unaligned place (gap <= 3 bytes; lanes move ascending chunks, reads of a round precede its writes)
+        // the stream stays where it was built (4-byte aligned, up to 3 bytes behind the headers): the frame assembly copies the two
+        // pieces next to each other (moving it down here was ~160 dependent load -> store rounds per block)
         const uint32_t gap = (uint32_t)(bsTmp - (out + bitstreamOff));
-        if (gap) {
-            for (uint32_t base = 0; base < bsSize; base += 64) {
-                const uint32_t j = base + lane;
-                const uint8_t v = (j < bsSize) ? bsTmp[j] : 0;
-                wave_sync();
-                if (j < bsSize) out[bitstreamOff + j] = v;
-                wave_sync();
-            }
-        }
+        secHdr = bitstreamOff; secGap = gap;
         const uint32_t total = bitstreamOff + bsSize;
         result = total > cap ? 0xFFFFFFFFu : total;
     }
-    if (lane == 0 && exists) metas[blk].seqSecSize = result;
+    if (lane == 0 && exists) { metas[blk].seqSecSize = result; metas[blk].seqHdrSize = (secHdr == 0xFFFFFFFFu) ? result : secHdr; metas[blk].seqGap = secGap; }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1193,6 +1189,21 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
 // iff both sections exist and literal section + sequence section < block size (else raw; RLE if flagged).
 // ---------------------------------------------------------------------------------------------
 struct ZsChunkDesc { uint64_t srcOff; uint64_t dstOff; uint32_t size; uint32_t firstBlock; uint32_t nBlocks; uint32_t pad; };
+
+// a workgroup copies n bytes: 16-byte pieces (two unaligned 8-byte accesses), four pieces a thread in flight, then the tail.
+// (A byte a thread and iteration was 100 dependent load -> store rounds per section.)
+__device__ __forceinline__ void zs_block_copy(uint8_t *__restrict__ d, const uint8_t *__restrict__ s, uint32_t n, uint32_t tid, uint32_t nthreads)
+{
+    const uint32_t n16 = n >> 4;
+    for (uint32_t i = tid; i < n16; i += 4 * nthreads) {
+        uint64_t a[4], b[4];
+        #pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { const uint32_t idx = min(i + k * nthreads, n16 - 1); a[k] = zs_load64(s + 16 * idx); b[k] = zs_load64(s + 16 * idx + 8); }
+        #pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { const uint32_t idx = i + k * nthreads; if (idx < n16) { zs_store64(d + 16 * idx, a[k]); zs_store64(d + 16 * idx + 8, b[k]); } }
+    }
+    for (uint32_t j = (n16 << 4) + tid; j < n; j += nthreads) d[j] = s[j];
+}
 
 extern "C" __global__ void __launch_bounds__(256)
 k_assemble_frames(const uint8_t *__restrict__ src, const ZsChunkDesc *__restrict__ chunks, const ZsBlockDesc *__restrict__ blocks,
@@ -1231,13 +1242,14 @@ k_assemble_frames(const uint8_t *__restrict__ src, const ZsChunkDesc *__restrict
             if (tid == 0) { const uint32_t h = last + (2u << 1) + (total << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); }
             const uint8_t *p1 = litSecAll + (size_t)lb * ZS_LITSEC_STRIDE;
             const uint8_t *p2 = seqSecAll + (size_t)lb * ZS_SEQSEC_STRIDE;
-            for (uint32_t j = tid; j < m.litSecSize; j += blockDim.x) out[pos + 3 + j] = p1[j];
-            for (uint32_t j = tid; j < m.seqSecSize; j += blockDim.x) out[pos + 3 + m.litSecSize + j] = p2[j];
+            zs_block_copy(out + pos + 3, p1, m.litSecSize, tid, blockDim.x);
+            zs_block_copy(out + pos + 3 + m.litSecSize, p2, m.seqHdrSize, tid, blockDim.x);
+            zs_block_copy(out + pos + 3 + m.litSecSize + m.seqHdrSize, p2 + m.seqHdrSize + m.seqGap, m.seqSecSize - m.seqHdrSize, tid, blockDim.x);
             pos += 3 + total;
         } else {
             if (tid == 0) { const uint32_t h = last + (0u << 1) + (n << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); }
             const uint8_t *p = src + bd.srcOff;
-            for (uint32_t j = tid; j < n; j += blockDim.x) out[pos + 3 + j] = p[j];
+            zs_block_copy(out + pos + 3, p, n, tid, blockDim.x);
             pos += 3 + n;
         }
     }
