@@ -168,6 +168,21 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_AC
 
 // Wave-cooperative forward bit writer.  Each put() appends, lane 0 first, up to 96 bits per lane.
 // out32 must be 4-byte aligned; bits are packed little-endian (bit k of the stream = bit k%8 of byte k/8).
+// a workgroup copies n bytes: 16-byte pieces (two unaligned 8-byte accesses), four pieces a thread in flight, then the tail.
+// (A byte a thread and iteration was 100 dependent load -> store rounds per section.)
+__device__ __forceinline__ void zs_block_copy(uint8_t *__restrict__ d, const uint8_t *__restrict__ s, uint32_t n, uint32_t tid, uint32_t nthreads)
+{
+    const uint32_t n16 = n >> 4;
+    for (uint32_t i = tid; i < n16; i += 4 * nthreads) {
+        uint64_t a[4], b[4];
+        #pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { const uint32_t idx = min(i + k * nthreads, n16 - 1); a[k] = zs_load64(s + 16 * idx); b[k] = zs_load64(s + 16 * idx + 8); }
+        #pragma unroll
+        for (uint32_t k = 0; k < 4; k++) { const uint32_t idx = i + k * nthreads; if (idx < n16) { zs_store64(d + 16 * idx, a[k]); zs_store64(d + 16 * idx + 8, b[k]); } }
+    }
+    for (uint32_t j = (n16 << 4) + tid; j < n; j += nthreads) d[j] = s[j];
+}
+
 struct BitSink {
     uint32_t *out32;
     uint32_t *tile;       // LDS, >= 200 words
@@ -761,7 +776,7 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
                 const uint32_t ssz[4] = { ssz0, ssz1, ssz2, ssz3 };
                 for (uint32_t k = 0; k < (single ? 1u : 4u); k++) {
                     const uint8_t *from = streams + k * ZS_STREAM_STRIDE;
-                    for (uint32_t j = tid; j < ssz[k]; j += 256) op[j] = from[j];
+                    zs_block_copy(op, from, ssz[k], tid, 256);
                     op += ssz[k];
                 }
                 if (tid == 0) {
@@ -781,7 +796,7 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
             else if (lh == 2) { const uint32_t h = (1 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); }
             else { const uint32_t h = (3 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); }
         }
-        for (uint32_t j = tid; j < nlit; j += 256) payload[lh + j] = lits[j];
+        zs_block_copy(payload + lh, lits, nlit, tid, 256);
         litSecSize = lh + nlit;
     }
     FINISH(2, litSecSize, 0);
@@ -1189,21 +1204,6 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
 // iff both sections exist and literal section + sequence section < block size (else raw; RLE if flagged).
 // ---------------------------------------------------------------------------------------------
 struct ZsChunkDesc { uint64_t srcOff; uint64_t dstOff; uint32_t size; uint32_t firstBlock; uint32_t nBlocks; uint32_t pad; };
-
-// a workgroup copies n bytes: 16-byte pieces (two unaligned 8-byte accesses), four pieces a thread in flight, then the tail.
-// (A byte a thread and iteration was 100 dependent load -> store rounds per section.)
-__device__ __forceinline__ void zs_block_copy(uint8_t *__restrict__ d, const uint8_t *__restrict__ s, uint32_t n, uint32_t tid, uint32_t nthreads)
-{
-    const uint32_t n16 = n >> 4;
-    for (uint32_t i = tid; i < n16; i += 4 * nthreads) {
-        uint64_t a[4], b[4];
-        #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) { const uint32_t idx = min(i + k * nthreads, n16 - 1); a[k] = zs_load64(s + 16 * idx); b[k] = zs_load64(s + 16 * idx + 8); }
-        #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) { const uint32_t idx = i + k * nthreads; if (idx < n16) { zs_store64(d + 16 * idx, a[k]); zs_store64(d + 16 * idx + 8, b[k]); } }
-    }
-    for (uint32_t j = (n16 << 4) + tid; j < n; j += nthreads) d[j] = s[j];
-}
 
 extern "C" __global__ void __launch_bounds__(256)
 k_assemble_frames(const uint8_t *__restrict__ src, const ZsChunkDesc *__restrict__ chunks, const ZsBlockDesc *__restrict__ blocks,
