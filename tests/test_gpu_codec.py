@@ -4,11 +4,13 @@
            (b) be byte-identical to oracle E (the scalar statement of the same algorithm),
            (c) decode under upstream libzstd when present, (d) keep the stated ratio tolerance.
 Run with -m gpu on an MI355X."""
-import ctypes, os
+import ctypes, os, sys
 import numpy as np
 import pytest
 import _oracle as O
 import _data as D
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = pytest.mark.gpu
 
@@ -269,3 +271,13 @@ def test_one_shot_large_frame(codec):
     for blob in (rnd, bytes(300000), b"\\xAB" * 70001):
         f = ZstdCompressor(3).compress(blob)
         assert f == O.compress(blob, 3) and O.decompress(f, len(blob)) == blob
+
+
+
+def test_pack_frames_device():
+    """zsmi_packFramesDevice: frames left at their worst-case offsets by the batch compressor end up back to back, in order
+    (ragged sizes, so that every copy alignment occurs).  Device buffers come from torch, which has to be loaded before
+    libzsmi.so in its process: the check runs as a script of its own (tools/pack_check.py)."""
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pack_check.py")], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]

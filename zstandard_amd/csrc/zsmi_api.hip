@@ -425,7 +425,7 @@ __global__ void k_pack_copy(const uint8_t *frames, const uint64_t *srcOffsets, c
     const uint32_t i = blockIdx.x;
     const uint32_t sz = sizes[i] > 0xFFFFFF88u ? 0 : sizes[i];
     const uint8_t *s = frames + srcOffsets[i]; uint8_t *d = packed + packedOffsets[i];
-    for (uint32_t j = threadIdx.x; j < sz; j += blockDim.x) d[j] = s[j];
+    zs_block_copy(d, s, sz, threadIdx.x, blockDim.x);
 }
 extern "C" int zsmi_packFramesDevice(zsmi_ctx *c, const void *dFrames, const uint64_t *dstOffsets, const uint32_t *dSizes,
                                      uint32_t n, void *dPacked, uint64_t *dPackedOffsets)
