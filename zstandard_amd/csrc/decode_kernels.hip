@@ -1116,7 +1116,7 @@ k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
                 if (isErr(decoded)) DONE(decoded);
             } else if (btype == 0) {
                 if (cBlockSize > oend - op) DONE(ZE(E_dstSize_tooSmall));
-                for (uint32_t j = lane; j < cBlockSize; j += 64) dstBase[op + j] = src[ipos + j];
+                zs_block_copy(dstBase + op, src + ipos, cBlockSize, lane, 64);    // raw block: 16 bytes a lane (a byte a lane was 2048 dependent rounds for 128 KiB)
                 decoded = cBlockSize;
             } else {
                 if (cSize > oend - op) DONE(ZE(E_dstSize_tooSmall));

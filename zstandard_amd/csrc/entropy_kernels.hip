@@ -182,6 +182,13 @@ __device__ __forceinline__ void zs_block_copy(uint8_t *__restrict__ d, const uin
     }
     for (uint32_t j = (n16 << 4) + tid; j < n; j += nthreads) d[j] = s[j];
 }
+// the same for one wavefront inside a kernel short of registers: one 16-byte piece a lane and round
+__device__ __forceinline__ void zs_wave_copy(uint8_t *__restrict__ d, const uint8_t *__restrict__ s, uint32_t n, uint32_t lane)
+{
+    const uint32_t n16 = n >> 4;
+    for (uint32_t i = lane; i < n16; i += 64) { const uint64_t a = zs_load64(s + 16 * i), b = zs_load64(s + 16 * i + 8); zs_store64(d + 16 * i, a); zs_store64(d + 16 * i + 8, b); }
+    for (uint32_t j = (n16 << 4) + lane; j < n; j += 64) d[j] = s[j];
+}
 
 struct BitSink {
     uint32_t *out32;
