@@ -71,6 +71,7 @@ static U32 highbit32(U32 v) { return 31 - (U32)__builtin_clz(v); }          /* B
 #define LONGNBSEQ 0x7F00
 #define MaxML 52
 #define MaxLL 35
+#define ZSTD_MAGIC_DICTIONARY 0xEC30A437u      /* ZStd.cs */
 #define MaxOff 31
 #define MaxSeq 52
 #define MLFSELog 9
@@ -570,7 +571,9 @@ typedef struct {
     U32 litEntropy, fseEntropy;
     const BYTE *litPtr; size_t litSize;
     BYTE *litBuffer;                /* ZSTD_BLOCKSIZE_MAX + WILDCOPY_OVERLENGTH, :261 */
-    const BYTE *base;               /* start of this frame's output (no dictionary: vBase == base) */
+    const BYTE *base;               /* start of this frame's output */
+    const BYTE *vBase, *dictEnd;    /* dictionary content as the segment in front of it: [dictEnd - (base - vBase), dictEnd)  (:2366-2372, :1911-1920) */
+    const BYTE *dictContent; size_t dictContentSize; U32 dictIDLoaded;   /* what decompress_insertDictionary left for the frame */
     /* frame params */
     U64 frameContentSize, windowSize; U32 checksumFlag, dictID, headerSize;
 } DCtx;
@@ -799,7 +802,8 @@ static Seq decodeSequence(SeqState *st, int longOffsets)
 /* :1265-1352 (+ :1212-1260).  The reference copies with 8-byte wild copies; the bytes it
  * leaves in [op, oMatchEnd) are those of a plain overlap-safe forward byte copy, which is
  * what is restated here together with every check the reference makes. */
-static size_t execSequence(BYTE *op, BYTE *const oend, Seq seq, const BYTE **litPtr, const BYTE *const litLimit, const BYTE *const base)
+static size_t execSequence(BYTE *op, BYTE *const oend, Seq seq, const BYTE **litPtr, const BYTE *const litLimit, const BYTE *const base,
+                           const BYTE *const vBase, const BYTE *const dictEnd)
 {
     BYTE *const oLitEnd = op + seq.litLength;
     size_t const sequenceLength = (size_t)seq.litLength + seq.matchLength;
@@ -809,7 +813,15 @@ static size_t execSequence(BYTE *op, BYTE *const oend, Seq seq, const BYTE **lit
     if (seq.litLength > (size_t)(litLimit - *litPtr)) return ERR(ZSO_corruption_detected);
     memcpy(op, *litPtr, seq.litLength);
     *litPtr = iLitEnd;
-    if (seq.offset > (size_t)(oLitEnd - base)) return ERR(ZSO_corruption_detected);   /* no dictionary: vBase == base, :1293 */
+    if (seq.offset > (size_t)(oLitEnd - base)) {              /* offset beyond the prefix: into the dictionary segment, :1290-1315 */
+        size_t const beyond = seq.offset - (size_t)(oLitEnd - base);
+        if (seq.offset > (size_t)(oLitEnd - vBase)) return ERR(ZSO_corruption_detected);   /* no dictionary: vBase == base, :1293 */
+        match = dictEnd - beyond;
+        if (seq.matchLength <= beyond) { memmove(oLitEnd, match, seq.matchLength); return sequenceLength; }
+        memmove(oLitEnd, match, beyond);                      /* spans the dictionary end and the start of the prefix */
+        { BYTE *o = oLitEnd + beyond; const BYTE *m = base; U32 i, rest = seq.matchLength - (U32)beyond; for (i = 0; i < rest; i++) o[i] = m[i]; }
+        return sequenceLength;
+    }
     match = oLitEnd - seq.offset;
     { U32 i; for (i = 0; i < seq.matchLength; i++) oLitEnd[i] = match[i]; }
     return sequenceLength;
@@ -837,7 +849,7 @@ static size_t decompressSequences(DCtx *d, void *dst, size_t maxDstSize, const v
             nbSeq--;
             {
                 Seq const sequence = decodeSequence(&st, d->windowSize > (1ULL << STREAM_ACCUMULATOR_MIN_32));
-                size_t const one = execSequence(op, oend, sequence, &litPtr, litEnd, d->base);
+                size_t const one = execSequence(op, oend, sequence, &litPtr, litEnd, d->base, d->vBase, d->dictEnd);
                 if (zso_isError(one)) return one;
                 op += one;
             }
@@ -995,7 +1007,8 @@ unsigned long long zso_getDecompressedSize(const void *src, size_t srcSize)
 /* :2478-2499 */
 static void decompressBegin(DCtx *d)
 {
-    d->base = NULL;
+    d->base = NULL; d->vBase = NULL; d->dictEnd = NULL;
+    d->dictContent = NULL; d->dictContentSize = 0; d->dictIDLoaded = 0;
     d->litEntropy = d->fseEntropy = 0;
     d->rep[0] = 1; d->rep[1] = 4; d->rep[2] = 8;          /* repStartValue, ZStdInternal.cs:111 */
     d->LLptr = &d->LL; d->MLptr = &d->ML; d->OFptr = &d->OF;
@@ -1020,11 +1033,14 @@ static size_t decompressFrame(DCtx *d, void *dst, size_t dstCapacity, const void
         r = getFrameHeader(&zfh, ip, fhs);                   /* DecodeFrameHeader :626-637 */
         if (zso_isError(r)) return r;
         if (r > 0) return ERR(ZSO_srcSize_wrong);
-        if (zfh.dictID != 0) return ERR(ZSO_dictionary_wrong);   /* dctx.dictID == 0 always: no dictionary API */
+        if (zfh.dictID != 0 && d->dictIDLoaded != zfh.dictID) return ERR(ZSO_dictionary_wrong);   /* :632-634 */
         d->frameContentSize = zfh.frameContentSize; d->windowSize = zfh.windowSize; d->checksumFlag = zfh.checksumFlag;
         ip += fhs; remainingSize -= fhs;
     }
-    d->base = ostart;
+    /* RefDictContent + CheckContinuity (:2366-2372, :1911-1920): the dictionary content is the segment right in front of this
+     * frame's output; frames of one call do not see each other (DecompressBegin_usingDict runs per frame, :2143) */
+    d->base = ostart; d->vBase = ostart - d->dictContentSize; d->dictEnd = d->dictContent + d->dictContentSize;
+    if (!d->dictContent) { d->vBase = ostart; d->dictEnd = NULL; }
     for (;;) {
         size_t decodedSize;
         U32 lastBlock, blockType, origSize;
@@ -1068,8 +1084,54 @@ static size_t decompressFrame(DCtx *d, void *dst, size_t dstCapacity, const void
     return (size_t)(op - ostart);
 }
 
-/* :2096-2160 (dict == NULL), called from :2174-2180 with a fresh context per call */
-size_t zso_decompress(void *dst, size_t dstCapacity, const void *src, size_t srcSize)
+/* LoadEntropy :2378-2450.  The reference reads the dictionary's Huffman table in the double-symbol layout (HUF_readDTableX4);
+ * the symbols a table decodes do not depend on the layout, so the single-symbol table of this file is built from the same
+ * description.  @return bytes read (magic and dictID included) or an error */
+static size_t loadEntropy(DCtx *d, const void *dict, size_t dictSize)
+{
+    const BYTE *dictPtr = (const BYTE *)dict;
+    const BYTE *const dictEnd = dictPtr + dictSize;
+    S16 norm[MaxSeq + 1];
+    if (dictSize <= 8) return ERR(ZSO_dictionary_corrupted);
+    dictPtr += 8;
+    { size_t const hSize = HUF_readDTable(&d->huf, dictPtr, (size_t)(dictEnd - dictPtr));
+      if (zso_isError(hSize)) return ERR(ZSO_dictionary_corrupted);
+      d->huf.valid = 1; dictPtr += hSize; }
+    { U32 max = MaxOff, log; size_t const h = readNCount(norm, &max, &log, dictPtr, (size_t)(dictEnd - dictPtr));
+      if (zso_isError(h) || max > MaxOff || log > OffFSELog) return ERR(ZSO_dictionary_corrupted);
+      buildFSETable(&d->OF, norm, max, NULL, 1, NULL, log); dictPtr += h; }
+    { U32 max = MaxML, log; size_t const h = readNCount(norm, &max, &log, dictPtr, (size_t)(dictEnd - dictPtr));
+      if (zso_isError(h) || max > MaxML || log > MLFSELog) return ERR(ZSO_dictionary_corrupted);
+      buildFSETable(&d->ML, norm, max, ML_base, 0, ML_bits, log); dictPtr += h; }
+    { U32 max = MaxLL, log; size_t const h = readNCount(norm, &max, &log, dictPtr, (size_t)(dictEnd - dictPtr));
+      if (zso_isError(h) || max > MaxLL || log > LLFSELog) return ERR(ZSO_dictionary_corrupted);
+      buildFSETable(&d->LL, norm, max, LL_base, 0, LL_bits, log); dictPtr += h; }
+    if (dictPtr + 12 > dictEnd) return ERR(ZSO_dictionary_corrupted);
+    { int i; size_t const dictContentSize = (size_t)(dictEnd - (dictPtr + 12));
+      for (i = 0; i < 3; i++) { U32 const rep = rdLE32(dictPtr); dictPtr += 4;
+          if (rep == 0 || rep >= dictContentSize) return ERR(ZSO_dictionary_corrupted);
+          d->rep[i] = rep; } }
+    return (size_t)(dictPtr - (const BYTE *)dict);
+}
+
+/* ZSTD_decompress_insertDictionary :2452-2475 */
+static size_t insertDictionary(DCtx *d, const void *dict, size_t dictSize)
+{
+    if (dictSize >= 8 && rdLE32(dict) == ZSTD_MAGIC_DICTIONARY) {
+        size_t eSize;
+        d->dictIDLoaded = rdLE32((const BYTE *)dict + 4);
+        eSize = loadEntropy(d, dict, dictSize);
+        if (zso_isError(eSize)) return ERR(ZSO_dictionary_corrupted);
+        dict = (const BYTE *)dict + eSize; dictSize -= eSize;
+        d->litEntropy = d->fseEntropy = 1;
+    }
+    d->dictContent = (const BYTE *)dict; d->dictContentSize = dictSize;      /* RefDictContent: pure content (mode) or what follows the tables */
+    return 0;
+}
+
+/* ZSTD_decompress_usingDict :2162-2167 -> DecompressMultiFrame :2096-2160, with a fresh context per call (:2174-2180).
+ * dict == NULL / dictSize == 0: the reference's public Decompress */
+size_t zso_decompress_usingDict(void *dst, size_t dstCapacity, const void *src, size_t srcSize, const void *dict, size_t dictSize)
 {
     DCtx *d = (DCtx *)malloc(sizeof(DCtx));
     BYTE *const dststart = (BYTE *)dst;
@@ -1097,6 +1159,10 @@ size_t zso_decompress(void *dst, size_t dstCapacity, const void *src, size_t src
             result = ERR(ZSO_prefix_unknown); goto done;
         }
         decompressBegin(d);
+        if (dict && dictSize) {                                  /* ZSTD_decompressBegin_usingDict :2501-2508 */
+            size_t const e = insertDictionary(d, dict, dictSize);
+            if (zso_isError(e)) { result = ERR(ZSO_dictionary_corrupted); goto done; }
+        }
         STAT(23);
         {
             size_t const res = decompressFrame(d, op, dstCapacity, &src, &srcSize);
@@ -1109,4 +1175,9 @@ size_t zso_decompress(void *dst, size_t dstCapacity, const void *src, size_t src
 done:
     free(d->litBuffer); free(d);
     return result;
+}
+
+size_t zso_decompress(void *dst, size_t dstCapacity, const void *src, size_t srcSize)
+{
+    return zso_decompress_usingDict(dst, dstCapacity, src, srcSize, NULL, 0);
 }

@@ -24,6 +24,8 @@ enum {
 
 /* oracle D : restatement of ZStdDecompress.Decompress / GetDecompressedSize */
 size_t zso_decompress(void *dst, size_t dstCapacity, const void *src, size_t srcSize);
+/* ZSTD_decompress_usingDict (ZStdDecompress.cs:2162): raw-content or formatted (magic 0xEC30A437) dictionary; NULL / 0 = none */
+size_t zso_decompress_usingDict(void *dst, size_t dstCapacity, const void *src, size_t srcSize, const void *dict, size_t dictSize);
 unsigned long long zso_getDecompressedSize(const void *src, size_t srcSize);
 unsigned zso_isError(size_t code);
 unsigned zso_errorCode(size_t code);

@@ -57,6 +57,18 @@ def decompress(frame: bytes, capacity=None) -> bytes:
     return out.raw[:r]
 
 
+def decompress_using_dict(frame: bytes, capacity: int, dictionary: bytes) -> bytes:
+    """oracle D with a dictionary (ZSTD_decompress_usingDict, ZStdDecompress.cs:2162): raw-content or formatted"""
+    L = lib()
+    L.zso_decompress_usingDict.restype = ctypes.c_size_t
+    L.zso_decompress_usingDict.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t]
+    out = ctypes.create_string_buffer(max(capacity, 1))
+    r = L.zso_decompress_usingDict(out, capacity, frame, len(frame), dictionary, len(dictionary))
+    if L.zso_isError(r):
+        raise OracleError(L.zso_errorCode(r))
+    return out.raw[:r]
+
+
 def compress(data: bytes, level=3) -> bytes:
     L = lib()
     cap = L.zso_compressBound(len(data))
