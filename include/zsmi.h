@@ -53,6 +53,12 @@ unsigned zsmi_getErrorCode(size_t code);
  * Returns the number of bytes written, or an error code. */
 size_t zsmi_decompress(void *dst, size_t dstCapacity, const void *src, size_t srcSize);
 
+/* replaces: ZSTD_decompress_usingDict(dctx, dst, dstCapacity, src, srcSize, dict, dictSize)  csharp/src/ZStdDecompress.cs:2162-2167
+ * (internal in the reference: its public Decompress passes no dictionary, :2171).  dict: raw content, or a formatted dictionary
+ * (magic 0xEC30A437: entropy tables + recent offsets + content, LoadEntropy :2378-2450); NULL / 0 = zsmi_decompress.
+ * Errors as the reference: dictionary_corrupted (30), dictionary_wrong (32: the frame names another dictionary ID, :632-634). */
+size_t zsmi_decompress_usingDict(void *dst, size_t dstCapacity, const void *src, size_t srcSize, const void *dict, size_t dictSize);
+
 /* replaces: ZStdDecompress.GetDecompressedSize(byte[] src, uint srcSize)  csharp/src/ZStdDecompress.cs:590-622
  *           (Java ZstdDecompressor.getDecompressedSize, ZstdDecompressor.java:31)
  * Content size of the first frame; 0 if unknown, on error, or for a skippable frame. Host-only header parse. */
@@ -93,12 +99,21 @@ int zsmi_decompressBatchDevice(zsmi_ctx *ctx, const void *dSrc, const uint64_t *
                                uint32_t n, void *dDst, const uint64_t *dstOffsets, const uint32_t *dstCaps,
                                uint32_t *dDstSizes);
 
+/* The same with one dictionary for every frame of the call (dDict: device memory).  Frames decoded with a dictionary take the
+ * general kernel. */
+int zsmi_decompressBatchDevice_usingDict(zsmi_ctx *ctx, const void *dSrc, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                                         uint32_t n, void *dDst, const uint64_t *dstOffsets, const uint32_t *dstCaps,
+                                         uint32_t *dDstSizes, const void *dDict, size_t dictSize);
+
 /* Host-buffer forms: stage through device memory, run the device form, copy back, synchronise. */
 int zsmi_compressBatchHost(zsmi_ctx *ctx, const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
                            uint32_t n, void *dst, const uint64_t *dstOffsets, uint32_t *dstSizes, int level);
 int zsmi_decompressBatchHost(zsmi_ctx *ctx, const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
                              uint32_t n, void *dst, const uint64_t *dstOffsets, const uint32_t *dstCaps,
                              uint32_t *dstSizes);
+int zsmi_decompressBatchHost_usingDict(zsmi_ctx *ctx, const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                                       uint32_t n, void *dst, const uint64_t *dstOffsets, const uint32_t *dstCaps,
+                                       uint32_t *dstSizes, const void *dict, size_t dictSize);
 
 /* Pack frames that sit at dstOffsets[] (sizes dDstSizes[], device) into one contiguous run at dPacked;
  * dPackedOffsets[n+1] (device, uint64) receives the running offsets.  Asynchronous. */

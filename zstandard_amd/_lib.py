@@ -42,6 +42,7 @@ def lib():
     L.zsmi_getDecompressedSize.restype = ctypes.c_ulonglong; L.zsmi_getDecompressedSize.argtypes = [vp, sz]
     L.zsmi_compress.restype = sz; L.zsmi_compress.argtypes = [vp, sz, vp, sz, i32]
     L.zsmi_decompress.restype = sz; L.zsmi_decompress.argtypes = [vp, sz, vp, sz]
+    L.zsmi_decompress_usingDict.restype = sz; L.zsmi_decompress_usingDict.argtypes = [vp, sz, vp, sz, vp, sz]
     L.zsmi_createCtx.restype = vp; L.zsmi_createCtx.argtypes = [i32, vp]
     L.zsmi_freeCtx.restype = None; L.zsmi_freeCtx.argtypes = [vp]
     L.zsmi_sync.restype = i32; L.zsmi_sync.argtypes = [vp]
@@ -49,6 +50,8 @@ def lib():
     L.zsmi_decompressBatchDevice.restype = i32; L.zsmi_decompressBatchDevice.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
     L.zsmi_compressBatchHost.restype = i32; L.zsmi_compressBatchHost.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, i32]
     L.zsmi_decompressBatchHost.restype = i32; L.zsmi_decompressBatchHost.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp]
+    L.zsmi_decompressBatchHost_usingDict.restype = i32; L.zsmi_decompressBatchHost_usingDict.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, sz]
+    L.zsmi_decompressBatchDevice_usingDict.restype = i32; L.zsmi_decompressBatchDevice_usingDict.argtypes = [vp, vp, vp, vp, u32, vp, vp, vp, vp, vp, sz]
     L.zsmi_packFramesDevice.restype = i32; L.zsmi_packFramesDevice.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     L.zsmi_enableKernelTiming.restype = i32; L.zsmi_enableKernelTiming.argtypes = [vp, i32]
     L.zsmi_getKernelTimes.restype = i32; L.zsmi_getKernelTimes.argtypes = [vp, ctypes.POINTER(KernelTime), i32]
@@ -60,4 +63,5 @@ def lib():
 EXPORTS = ["zsmi_isError", "zsmi_getErrorName", "zsmi_getErrorCode", "zsmi_decompress", "zsmi_getDecompressedSize",
            "zsmi_compress", "zsmi_compressBound", "zsmi_createCtx", "zsmi_freeCtx", "zsmi_sync",
            "zsmi_compressBatchDevice", "zsmi_decompressBatchDevice", "zsmi_compressBatchHost", "zsmi_decompressBatchHost",
+           "zsmi_decompress_usingDict", "zsmi_decompressBatchDevice_usingDict", "zsmi_decompressBatchHost_usingDict",
            "zsmi_packFramesDevice", "zsmi_enableKernelTiming", "zsmi_getKernelTimes", "zsmi_versionString"]

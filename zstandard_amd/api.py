@@ -166,7 +166,9 @@ class BatchCodec:
             raise RuntimeError(f"zsmi_compressBatchHost: error {rc}")
         return arena, do, dsz
 
-    def decompress_host(self, src: np.ndarray, src_offsets, src_sizes, dst_caps):
+    def decompress_host(self, src: np.ndarray, src_offsets, src_sizes, dst_caps, dictionary: bytes = b""):
+        """dictionary: every frame is decoded with it (raw content or a formatted dictionary; ZSTD_decompress_usingDict,
+        ZStdDecompress.cs:2162)"""
         so = np.ascontiguousarray(src_offsets, dtype=np.uint64); ss = np.ascontiguousarray(src_sizes, dtype=np.uint32)
         dc = np.ascontiguousarray(dst_caps, dtype=np.uint32)
         n = len(ss)
@@ -175,7 +177,12 @@ class BatchCodec:
             do[1:] = np.cumsum(dc.astype(np.uint64))[:-1]
         arena = np.zeros(max(int(dc.astype(np.uint64).sum()), 1), dtype=np.uint8)
         dsz = np.zeros(n, dtype=np.uint32)
-        rc = self.L.zsmi_decompressBatchHost(self.ctx, self._p(src), self._p(so), self._p(ss), n, self._p(arena), self._p(do), self._p(dc), self._p(dsz))
+        if dictionary:
+            dbuf = np.frombuffer(dictionary, dtype=np.uint8)
+            rc = self.L.zsmi_decompressBatchHost_usingDict(self.ctx, self._p(src), self._p(so), self._p(ss), n, self._p(arena), self._p(do), self._p(dc), self._p(dsz),
+                                                           self._p(dbuf), len(dbuf))
+        else:
+            rc = self.L.zsmi_decompressBatchHost(self.ctx, self._p(src), self._p(so), self._p(ss), n, self._p(arena), self._p(do), self._p(dc), self._p(dsz))
         if rc:
             raise RuntimeError(f"zsmi_decompressBatchHost: error {rc}")
         return arena, do, dsz

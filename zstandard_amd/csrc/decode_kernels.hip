@@ -642,8 +642,12 @@ struct DState { uint32_t rep[3]; uint32_t litEntropy, fseEntropy; uint32_t llRep
 #define ZS_PF_STAMP(k)
 #define ZS_PF_DUMMY
 #endif
-__device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint32_t *tileML, const uint32_t *tileOff, uint32_t T, uint8_t *dstBase,
-                                             uint64_t frameStart, uint64_t oend, const uint8_t *litPtr, uint32_t litSize, uint64_t &op, uint32_t &litPos ZS_PF_PARAM)
+// DICT: a dictionary's content is the segment in front of the frame (RefDictContent :2366, CheckContinuity :1911): offsets may reach
+// dictSize bytes beyond the frame's start (:1290-1315); dictEnd = one past the content's last byte.
+template <bool DICT>
+__device__ __forceinline__ uint32_t execTileT(const uint32_t *tileLL, const uint32_t *tileML, const uint32_t *tileOff, uint32_t T, uint8_t *dstBase,
+                                              uint64_t frameStart, uint64_t oend, const uint8_t *litPtr, uint32_t litSize, uint64_t &op, uint32_t &litPos,
+                                              const uint8_t *dictEnd, uint32_t dictSize ZS_PF_PARAM)
 {
 #ifdef ZS_EXEC_PROFILE
     uint64_t pfT = __builtin_amdgcn_s_memtime();
@@ -662,7 +666,7 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
         if (lane < T) {
             if ((uint64_t)ll + ml > oend - outStart64 || outStart64 > oend) err = E_dstSize_tooSmall;
             else if (ll > litSize - litStart || litStart > litSize) err = E_corruption_detected;
-            else if (off > outStart64 + ll - frameStart) err = E_corruption_detected;
+            else if (off > outStart64 + ll - frameStart + (DICT ? dictSize : 0u)) err = E_corruption_detected;
         }
         const uint64_t em = __ballot(err != 0);
         if (em) return ZE(wave_get(err, __builtin_ctzll(em)));
@@ -722,8 +726,9 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
         }
         ZS_PF_STAMP(0)                                                        // scans, checks, literals (no wait: the next matches read older output)
         // matches reading only output that existed before this tile
-        const uint32_t msrc = mdst - off;
-        const bool indep = ml && (msrc + ml <= tileStart);
+        const uint32_t msrc = mdst - off;                             // (wraps for a match that starts in the dictionary: not used then)
+        const bool inDict = DICT && ml && off > mdst - (uint32_t)frameStart;
+        const bool indep = ml && !inDict && (msrc + ml <= tileStart);
         if (indep && ml <= 32) {
             if (ml >= 8) {
                 // whole 8-byte pieces, the last one moved back so that it ends with the match (source and destination do not overlap)
@@ -754,10 +759,10 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
         for (uint64_t rem = __ballot(ml && !indep); rem; ) {
             const int g0 = __builtin_ctzll(rem);
             const uint32_t lo = wave_get(mdst, g0);
-            const uint64_t viol = __ballot(((rem >> lane) & 1ull) && (int)lane > g0 && msrc + ml > lo);
+            const uint64_t viol = __ballot(((rem >> lane) & 1ull) && (int)lane > g0 && (inDict || msrc + ml > lo));     // a dictionary match only ever leads a group
             const uint64_t grp = viol ? (rem & ((1ull << __builtin_ctzll(viol)) - 1ull)) : rem;
             const bool in = (grp >> lane) & 1ull;
-            const bool self = in && off < ml;                        // only lane g0 can be
+            const bool self = in && (inDict || off < ml);            // only lane g0 can be
             if (in && !self && ml <= 32) {
                 if (ml >= 8) {
                     uint64_t v[4]; const uint32_t lastAt = ml - 8;
@@ -774,7 +779,13 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
                 const int t = __builtin_ctzll(lm);
                 const uint32_t m2 = wave_get(ml, t), o2 = wave_get(off, t);
                 const uint32_t s2 = wave_get(msrc, t), d2 = wave_get(mdst, t);
-                if (o2 >= m2) { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j]; }
+                if (DICT && wave_get(inDict ? 1u : 0u, t)) {
+                    // the first `beyond` bytes come from the end of the dictionary, the rest from the start of the frame (:1295-1315)
+                    const uint32_t fs = (uint32_t)frameStart, beyond = o2 - (d2 - fs);
+                    if (m2 <= o2) { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = (j < beyond) ? dictEnd[(int32_t)j - (int32_t)beyond] : dstBase[fs + (j - beyond)]; }
+                    else if (lane == 0) { for (uint32_t j = 0; j < m2; j++) dstBase[d2 + j] = (j < beyond) ? dictEnd[(int32_t)j - (int32_t)beyond] : dstBase[fs + (j - beyond)]; }
+                }
+                else if (o2 >= m2) { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j]; }
                 else { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + (j % o2)]; }      // period = offset
             }
             wave_mem_sync();
@@ -786,6 +797,11 @@ __device__ __forceinline__ uint32_t execTile(const uint32_t *tileLL, const uint3
     }
     return 0;
 }
+#ifdef ZS_EXEC_PROFILE
+#define execTile(a, b, c, T, d, fs, oe, lp, ls, op, lpos, pf) execTileT<false>(a, b, c, T, d, fs, oe, lp, ls, op, lpos, nullptr, 0u, pf)
+#else
+#define execTile(a, b, c, T, d, fs, oe, lp, ls, op, lpos) execTileT<false>(a, b, c, T, d, fs, oe, lp, ls, op, lpos, nullptr, 0u)
+#endif
 
 // A fast-path table cell in 16 bits (half the LDS of a 4-byte cell = twice the items a CU decodes at once): the symbol in
 // bits 0-5; above it 1 << (9 - nbBits) | (nextState >> nbBits).  nextState is a multiple of 2^nbBits, one of 2^(tableLog -
@@ -866,8 +882,10 @@ __device__ __forceinline__ uint32_t seqHeaders(DLds &L, const DState &st, const 
 
 // ---- one compressed block (ZSTD_decompressBlock_internal :1868-1909). returns decoded size or error ----
 
+template <bool DICT>
 __device__ __forceinline__ uint32_t decodeBlock(DLds &L, DState &st, uint8_t *dstBase, uint64_t frameStart, uint64_t op, uint64_t oend,
-                                       const uint8_t *src, uint32_t srcSize, uint8_t *litBuf, uint64_t windowSize, uint64_t *g_prof)
+                                       const uint8_t *src, uint32_t srcSize, uint8_t *litBuf, uint64_t windowSize, uint64_t *g_prof,
+                                       const uint8_t *dictEnd, uint32_t dictSize)
 {
     const uint32_t lane = (uint32_t)zs_lane();
     PROF_T0(); (void)g_prof;
@@ -1016,7 +1034,7 @@ __device__ __forceinline__ uint32_t decodeBlock(DLds &L, DState &st, uint8_t *ds
 #ifdef ZS_EXEC_PROFILE
             uint64_t pfDummy[8];
 #endif
-            { const uint32_t e = execTile(L.u.sq.tileLL, L.u.sq.tileML, L.u.sq.tileOff, T, dstBase, frameStart, oend, litPtr, litSize, op, litPos ZS_PF_DUMMY); if (e) return e; }
+            { const uint32_t e = execTileT<DICT>(L.u.sq.tileLL, L.u.sq.tileML, L.u.sq.tileOff, T, dstBase, frameStart, oend, litPtr, litSize, op, litPos, dictEnd, dictSize ZS_PF_DUMMY); if (e) return e; }
             PROF_ADD(3);
             left -= T;
         }
@@ -1039,10 +1057,14 @@ __device__ __forceinline__ uint32_t decodeBlock(DLds &L, DState &st, uint8_t *ds
 // every synchronisation inside an item is wavefront-local (wave_sync): the wavefronts of a workgroup run independently.
 // Every function that touches the LDS workspace is force-inlined: through a call the workspace reference becomes a generic
 // pointer and its accesses flat_* instructions, which complete out of order with the ds_* accesses of the inlined code.
-template <int F>
+// DICT: every frame of every item is decoded with the dictionary dict[0 .. dictBytes) (ZSTD_decompress_usingDict :2162): raw
+// content, or a formatted dictionary (magic 0xEC30A437) whose entropy tables and recent offsets are loaded in front of each frame
+// (ZSTD_decompressBegin_usingDict :2501, LoadEntropy :2378-2450) -- by every wavefront for itself: a dictionary is a few KiB.
+template <int F, bool DICT>
 __global__ void __launch_bounds__(64 * F)
 k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, uint8_t *dstAll,
-                uint32_t *__restrict__ dstSizes, uint8_t *__restrict__ litScratchAll, const uint32_t *__restrict__ doneFlags, uint32_t flagStride)
+                uint32_t *__restrict__ dstSizes, uint8_t *__restrict__ litScratchAll, const uint32_t *__restrict__ doneFlags, uint32_t flagStride,
+                const uint8_t *__restrict__ dict, uint32_t dictBytes)
 {
     __shared__ DLds LS[F];
     const uint32_t item = blockIdx.x * F + (threadIdx.x >> 6);
@@ -1098,9 +1120,43 @@ k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
         if (dictIDCode == 1) { dictID = ip[pos]; pos += 1; } else if (dictIDCode == 2) { dictID = rd16(ip + pos); pos += 2; } else if (dictIDCode == 3) { dictID = rd32(ip + pos); pos += 4; }
         if (fcsID == 0) { if (singleSegment) fcs = ip[pos]; } else if (fcsID == 1) fcs = rd16(ip + pos) + 256; else if (fcsID == 2) fcs = rd32(ip + pos); else fcs = zs_load64(ip + pos);
         if (singleSegment) windowSize = fcs;
-        if (dictID != 0) DONE(ZE(E_dictionary_wrong));
         ipos += fhs;
         DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = 0; st.llRepeatOk = 0;   // DecompressBegin :2478-2499
+        const uint8_t *dictEnd = nullptr; uint32_t dictSize = 0, dictIDLoaded = 0;
+        if (DICT && dict && dictBytes) {                             // ZSTD_decompress_insertDictionary :2452-2475
+            const uint8_t *content = dict; uint32_t contentSize = dictBytes;
+            if (dictBytes >= 8 && rd32(dict) == 0xEC30A437u) {
+                dictIDLoaded = rd32(dict + 4);
+                const uint8_t *p = dict + 8; const uint8_t *const pend = dict + dictBytes;
+                if (dictBytes <= 8) DONE(ZE(E_dictionary_corrupted));
+                { const uint32_t h = readHufTable(L, p, (uint32_t)(pend - p)); if (isErr(h)) DONE(ZE(E_dictionary_corrupted)); p += h; }
+                for (int t = 0; t < 3; t++) {                         // offset codes, match lengths, literal lengths (:2395-2435)
+                    const uint32_t maxS = t == 0 ? 31 : (t == 1 ? 52 : 35), maxLog = t == 0 ? 8 : 9;
+                    SeqSym *cells = t == 0 ? L.OF.cells : (t == 1 ? L.ML.cells : L.LL.cells);
+                    uint32_t *tl = t == 0 ? &L.OF.tableLog : (t == 1 ? &L.ML.tableLog : &L.LL.tableLog);
+                    const uint32_t left = (uint32_t)(pend - p);
+                    hw_stage(L.u.tb.hdrWin, p, left);
+                    if (lane == 0) {
+                        uint32_t tableLog = 0, max = maxS;
+                        const uint32_t h = readNCount(L.u.tb.norm, &max, &tableLog, L.u.tb.hdrWin, left, 0);
+                        L.misc[0] = (isErr(h) || max > maxS || tableLog > maxLog) ? 1u : 0u; L.misc[1] = h; L.misc[3] = max; L.misc[4] = tableLog;
+                    }
+                    wave_sync();
+                    if (L.misc[0]) DONE(ZE(E_dictionary_corrupted));
+                    const uint32_t adv = L.misc[1], bmax = L.misc[3], blog = L.misc[4];
+                    buildSeqTableWave(L, cells, tl, bmax, blog);
+                    wave_sync();
+                    p += adv;
+                }
+                if (p + 12 > pend) DONE(ZE(E_dictionary_corrupted));
+                contentSize = (uint32_t)(pend - (p + 12));
+                for (int i = 0; i < 3; i++) { const uint32_t rep = rd32(p); p += 4; if (rep == 0 || rep >= contentSize) DONE(ZE(E_dictionary_corrupted)); st.rep[i] = rep; }
+                st.litEntropy = 1; st.fseEntropy = 1;
+                content = p;
+            }
+            dictEnd = content + contentSize; dictSize = contentSize;
+        }
+        if (dictID != 0 && dictID != dictIDLoaded) DONE(ZE(E_dictionary_wrong));      // :632-634
         const uint64_t frameStart = op;
         for (;;) {                                                   // block loop :2033-2067
             if (srcSize - ipos < 3) DONE(ZE(E_srcSize_wrong));
@@ -1112,7 +1168,7 @@ k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
             if (cBlockSize > srcSize - ipos) DONE(ZE(E_srcSize_wrong));
             uint32_t decoded;
             if (btype == 2) {
-                decoded = decodeBlock(L, st, dstBase, frameStart, op, oend, src + ipos, cBlockSize, litBuf, windowSize, g_prof);
+                decoded = decodeBlock<DICT>(L, st, dstBase, frameStart, op, oend, src + ipos, cBlockSize, litBuf, windowSize, g_prof, dictEnd, dictSize);
                 if (isErr(decoded)) DONE(decoded);
             } else if (btype == 0) {
                 if (cBlockSize > oend - op) DONE(ZE(E_dstSize_tooSmall));

@@ -138,7 +138,7 @@ struct zsmi_ctx {
                                          // last round is mostly tail, so big launches pay (16384 frames of 32 KiB: 82 GiB/s, 57344: 104 GiB/s)
     PinBuf hItems;
     // staging for host-buffer calls
-    DevBuf sSrc, sDst, sSizes;
+    DevBuf sSrc, sDst, sSizes, sDict;
     // timing
     bool timing = false;
     std::vector<TimedLaunch> launches;
@@ -193,7 +193,7 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
 {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dUnits, &c->dItems, &c->dLitScratch, &c->dFastDesc, &c->dHufTabs, &c->dSeqTabs, &c->dSeqOut, &c->sSrc, &c->sDst, &c->sSizes }) b->release();
+    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dUnits, &c->dItems, &c->dLitScratch, &c->dFastDesc, &c->dHufTabs, &c->dSeqTabs, &c->dSeqOut, &c->sSrc, &c->sDst, &c->sSizes, &c->sDict }) b->release();
     for (int i = 0; i < zsmi_ctx::kMaxLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
         if (L.stream) (void)hipStreamSynchronize(L.stream);
@@ -362,8 +362,9 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
 // ---------------------------------------------------------------------------------------------
 // decompress
 // ---------------------------------------------------------------------------------------------
-extern "C" int zsmi_decompressBatchDevice(zsmi_ctx *c, const void *dSrc, const uint64_t *srcOffsets, const uint32_t *srcSizes,
-                                          uint32_t n, void *dDst, const uint64_t *dstOffsets, const uint32_t *dstCaps, uint32_t *dDstSizes)
+static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                                     uint32_t n, void *dDst, const uint64_t *dstOffsets, const uint32_t *dstCaps, uint32_t *dDstSizes,
+                                     const void *dDict, uint32_t dictSize)
 {
     if (!c) return ZSMI_error_init_missing;
     if (n == 0) return 0;
@@ -375,7 +376,8 @@ extern "C" int zsmi_decompressBatchDevice(zsmi_ctx *c, const void *dSrc, const u
     if (hipMemcpyAsync(c->dItems.p, hi, sizeof(ZsDecItem) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
     const uint32_t cap = std::min<uint32_t>(n, c->maxItemsInFlight);
     if (!c->dLitScratch.reserve((size_t)cap * ((1u << 17) + 64))) return ZSMI_error_memory_allocation;
-    const bool fast = c->decodeFast;
+    const bool useDict = dDict != nullptr && dictSize != 0;
+    const bool fast = c->decodeFast && !useDict;                  // frames that name a dictionary go to the general kernel
     if (fast && (!c->dFastDesc.reserve((size_t)cap * sizeof(ZsFastDesc)) || !c->dHufTabs.reserve((size_t)cap * ZS_FAST_HUFTAB_BYTES) ||
                  !c->dSeqTabs.reserve((size_t)cap * ZS_FAST_SEQTAB_BYTES) || !c->dSeqOut.reserve((size_t)cap * ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)))) return ZSMI_error_memory_allocation;
     for (uint32_t i0 = 0; i0 < n; i0 += cap) {
@@ -396,10 +398,29 @@ extern "C" int zsmi_decompressBatchDevice(zsmi_ctx *c, const void *dSrc, const u
                    (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0);
             doneFlags = &dD->fast;
         }
-        LAUNCH(c, "k_decode_frames", (k_decode_frames<ZS_DEC_GROUP>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc,
-               dI, cnt, (uint8_t *)dDst, dDstSizes + i0, (uint8_t *)c->dLitScratch.p, doneFlags, (uint32_t)(sizeof(ZsFastDesc) / sizeof(uint32_t)));
+        if (useDict)
+            LAUNCH(c, "k_decode_frames_dict", (k_decode_frames<ZS_DEC_GROUP, true>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc,
+                   dI, cnt, (uint8_t *)dDst, dDstSizes + i0, (uint8_t *)c->dLitScratch.p, doneFlags, (uint32_t)(sizeof(ZsFastDesc) / sizeof(uint32_t)), (const uint8_t *)dDict, dictSize);
+        else
+            LAUNCH(c, "k_decode_frames", (k_decode_frames<ZS_DEC_GROUP, false>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc,
+                   dI, cnt, (uint8_t *)dDst, dDstSizes + i0, (uint8_t *)c->dLitScratch.p, doneFlags, (uint32_t)(sizeof(ZsFastDesc) / sizeof(uint32_t)), (const uint8_t *)nullptr, 0u);
     }
     return hipGetLastError() == hipSuccess ? 0 : ZSMI_error_GENERIC;
+}
+
+extern "C" int zsmi_decompressBatchDevice(zsmi_ctx *c, const void *dSrc, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                                          uint32_t n, void *dDst, const uint64_t *dstOffsets, const uint32_t *dstCaps, uint32_t *dDstSizes)
+{
+    return decompressBatchDeviceImpl(c, dSrc, srcOffsets, srcSizes, n, dDst, dstOffsets, dstCaps, dDstSizes, nullptr, 0);
+}
+// every frame of every item is decoded with the dictionary dDict[0 .. dictSize) (device memory; ZSTD_decompress_usingDict,
+// ZStdDecompress.cs:2162): raw content or a formatted dictionary (magic 0xEC30A437)
+extern "C" int zsmi_decompressBatchDevice_usingDict(zsmi_ctx *c, const void *dSrc, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                                                    uint32_t n, void *dDst, const uint64_t *dstOffsets, const uint32_t *dstCaps, uint32_t *dDstSizes,
+                                                    const void *dDict, size_t dictSize)
+{
+    if (dictSize > 0xFFFFFFFFull) return ZSMI_error_dictionary_corrupted;
+    return decompressBatchDeviceImpl(c, dSrc, srcOffsets, srcSizes, n, dDst, dstOffsets, dstCaps, dDstSizes, dDict, (uint32_t)dictSize);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -478,11 +499,18 @@ extern "C" int zsmi_compressBatchHost(zsmi_ctx *c, const void *src, const uint64
     }
     return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : ZSMI_error_GENERIC;
 }
-extern "C" int zsmi_decompressBatchHost(zsmi_ctx *c, const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
-                                        uint32_t n, void *dst, const uint64_t *dstOffsets, const uint32_t *dstCaps, uint32_t *dstSizes)
+static int decompressBatchHostImpl(zsmi_ctx *c, const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                                   uint32_t n, void *dst, const uint64_t *dstOffsets, const uint32_t *dstCaps, uint32_t *dstSizes,
+                                   const void *dict, size_t dictSize)
 {
     if (!c) return ZSMI_error_init_missing;
     if (n == 0) return 0;
+    if (dictSize > 0xFFFFFFFFull) return ZSMI_error_dictionary_corrupted;
+    const bool useDict = dict != nullptr && dictSize != 0;
+    if (useDict) {
+        if (!c->sDict.reserve(dictSize + 64)) return ZSMI_error_memory_allocation;
+        if (hipMemcpyAsync(c->sDict.p, dict, dictSize, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    }
     uint64_t slo, shi, dlo, dhi;
     spanOf(srcOffsets, srcSizes, nullptr, n, slo, shi);
     spanOf(dstOffsets, nullptr, dstCaps, n, dlo, dhi);
@@ -490,7 +518,8 @@ extern "C" int zsmi_decompressBatchHost(zsmi_ctx *c, const void *src, const uint
     std::vector<uint64_t> so(n), dof(n);
     for (uint32_t i = 0; i < n; i++) { so[i] = srcOffsets[i] - slo; dof[i] = dstOffsets[i] - dlo; }
     if (shi > slo && hipMemcpyAsync(c->sSrc.p, (const uint8_t *)src + slo, shi - slo, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
-    const int rc = zsmi_decompressBatchDevice(c, c->sSrc.p, so.data(), srcSizes, n, c->sDst.p, dof.data(), dstCaps, (uint32_t *)c->sSizes.p);
+    const int rc = decompressBatchDeviceImpl(c, c->sSrc.p, so.data(), srcSizes, n, c->sDst.p, dof.data(), dstCaps, (uint32_t *)c->sSizes.p,
+                                             useDict ? c->sDict.p : nullptr, useDict ? (uint32_t)dictSize : 0u);
     if (rc) return rc;
     if (hipMemcpyAsync(dstSizes, c->sSizes.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return ZSMI_error_GENERIC;
@@ -499,6 +528,18 @@ extern "C" int zsmi_decompressBatchHost(zsmi_ctx *c, const void *src, const uint
         if (hipMemcpyAsync((uint8_t *)dst + dstOffsets[i], (const uint8_t *)c->sDst.p + dof[i], dstSizes[i], hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
     }
     return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : ZSMI_error_GENERIC;
+}
+
+extern "C" int zsmi_decompressBatchHost(zsmi_ctx *c, const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                                        uint32_t n, void *dst, const uint64_t *dstOffsets, const uint32_t *dstCaps, uint32_t *dstSizes)
+{
+    return decompressBatchHostImpl(c, src, srcOffsets, srcSizes, n, dst, dstOffsets, dstCaps, dstSizes, nullptr, 0);
+}
+extern "C" int zsmi_decompressBatchHost_usingDict(zsmi_ctx *c, const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                                                  uint32_t n, void *dst, const uint64_t *dstOffsets, const uint32_t *dstCaps, uint32_t *dstSizes,
+                                                  const void *dict, size_t dictSize)
+{
+    return decompressBatchHostImpl(c, src, srcOffsets, srcSizes, n, dst, dstOffsets, dstCaps, dstSizes, dict, dictSize);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -535,6 +576,20 @@ extern "C" size_t zsmi_decompress(void *dst, size_t dstCapacity, const void *src
     const uint64_t so = 0, dof = 0; const uint32_t ss = (uint32_t)srcSize; uint32_t ds = 0;
     const uint32_t cap = (uint32_t)std::min<size_t>(dstCapacity, 0xFFFFFF00u);
     const int rc = zsmi_decompressBatchHost(c, src, &so, &ss, 1, dst, &dof, &cap, &ds);
+    if (rc) return ZSMI_ERR(rc);
+    if (ds > 0xFFFFFF88u) return ZSMI_ERR(0u - ds);
+    return ds;
+}
+
+extern "C" size_t zsmi_decompress_usingDict(void *dst, size_t dstCapacity, const void *src, size_t srcSize, const void *dict, size_t dictSize)
+{
+    if (srcSize > 0xFFFFFFFFull) return ZSMI_ERR(ZSMI_error_srcSize_wrong);
+    std::lock_guard<std::mutex> lk(g_mu);
+    zsmi_ctx *c = defaultCtx();
+    if (!c) return ZSMI_ERR(ZSMI_error_GENERIC);
+    const uint64_t so = 0, dof = 0; const uint32_t ss = (uint32_t)srcSize; uint32_t ds = 0;
+    const uint32_t cap = (uint32_t)std::min<size_t>(dstCapacity, 0xFFFFFF00u);
+    const int rc = zsmi_decompressBatchHost_usingDict(c, src, &so, &ss, 1, dst, &dof, &cap, &ds, dict, dictSize);
     if (rc) return ZSMI_ERR(rc);
     if (ds > 0xFFFFFF88u) return ZSMI_ERR(0u - ds);
     return ds;
