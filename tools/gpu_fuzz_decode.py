@@ -23,6 +23,56 @@ def pieces(rng, total):
     pz = 1.0 / np.arange(1, 257) ** 1.1; yield rng.choice(256, total, p=pz / pz.sum()).astype(np.uint8)
     pg = 0.97 ** np.arange(256); yield rng.choice(256, total, p=pg / pg.sum()).astype(np.uint8)
 
+def dictionary_rounds(bc, rounds):
+    """frames compressed by libzstd WITH a dictionary (raw content of several sizes; a trained one): the batch call with that
+    dictionary must restore every chunk"""
+    import ctypes
+    Z = ctypes.CDLL("libzstd.so.1")
+    sz, vp, cp = ctypes.c_size_t, ctypes.c_void_p, ctypes.c_char_p
+    Z.ZSTD_compressBound.restype = sz; Z.ZSTD_compressBound.argtypes = [sz]
+    Z.ZSTD_createCCtx.restype = vp
+    Z.ZSTD_compress_usingDict.restype = sz; Z.ZSTD_compress_usingDict.argtypes = [vp, vp, sz, cp, sz, cp, sz, ctypes.c_int]
+    Z.ZSTD_isError.restype = ctypes.c_uint; Z.ZSTD_isError.argtypes = [sz]
+    Z.ZDICT_trainFromBuffer.restype = sz; Z.ZDICT_trainFromBuffer.argtypes = [vp, sz, cp, ctypes.POINTER(sz), ctypes.c_uint]
+    Z.ZDICT_isError.restype = ctypes.c_uint; Z.ZDICT_isError.argtypes = [sz]
+    cctx = Z.ZSTD_createCCtx()
+    def comp(data, dic, level):
+        cap = Z.ZSTD_compressBound(len(data)); out = ctypes.create_string_buffer(cap)
+        r = Z.ZSTD_compress_usingDict(cctx, out, cap, data, len(data), dic, len(dic), level); assert not Z.ZSTD_isError(r)
+        return out.raw[:r]
+    bad = 0
+    for rd in range(rounds):
+        rng = np.random.default_rng(500 + rd)
+        srcs = list(pieces(rng, 1 << 20))
+        base = srcs[rd % 5].tobytes()
+        if rd % 2 == 0:
+            dic = base[: int(rng.choice([17, 300, 5000, 100000]))]                      # raw content
+        else:
+            samples = [base[i * 700:i * 700 + 900] for i in range(1000)]
+            buf = b"".join(samples); sizes = (sz * len(samples))(*[len(x) for x in samples])
+            dbuf = ctypes.create_string_buffer(16384)
+            r = Z.ZDICT_trainFromBuffer(dbuf, 16384, buf, sizes, len(samples))
+            dic = dbuf.raw[:r] if not Z.ZDICT_isError(r) else base[:4000]
+        chunks, frames = [], []
+        for i in range(int(rng.integers(40, 120))):
+            n = int(rng.choice([rng.integers(1, 600), rng.integers(600, 20000), rng.integers(20000, 300000)]))
+            a = int(rng.integers(0, len(base) - n))
+            c = base[a:a + n]
+            chunks.append(c); frames.append(comp(c, dic, int(rng.integers(1, 20))))
+        sizes = np.array([len(c) for c in chunks], dtype=np.uint32)
+        fsz = np.array([len(f) for f in frames], dtype=np.uint32)
+        blob = np.frombuffer(b"".join(frames), dtype=np.uint8)
+        fo = np.zeros(len(frames), dtype=np.uint64); fo[1:] = np.cumsum(fsz.astype(np.uint64))[:-1]
+        out, oo, osz = bc.decompress_host(blob, fo, fsz, sizes, dic)
+        for i, c in enumerate(chunks):
+            if int(osz[i]) != len(c) or out[int(oo[i]):int(oo[i]) + len(c)].tobytes() != c:
+                bad += 1; print(f"dictionary round {rd} frame {i} ({len(c)} B, dictionary {len(dic)} B): wrong output, size/status {osz[i]:#x}")
+            elif i % 9 == 0 and O.decompress_using_dict(frames[i], len(c), dic) != c:
+                bad += 1; print(f"dictionary round {rd} frame {i}: oracle D differs")
+        print(f"dictionary round {rd}: {len(frames)} frames, dictionary of {len(dic)} B ({'formatted' if dic[:4] == bytes([0x37, 0xA4, 0x30, 0xEC]) else 'raw content'}): ok so far = {bad == 0}", flush=True)
+    return bad
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     if not O.libzstd():
@@ -68,6 +118,7 @@ def main():
             elif got != len(want) or out2[int(oo2[i]):int(oo2[i]) + got].tobytes() != want:
                 bad += 1; print(f"round {rd} damaged {i}: oracle decodes {len(want)} B, HIP {got:#x}")
         print(f"round {rd}: {len(frames)} frames, {int(sizes.sum()) >> 10} KiB: ok so far = {bad == 0}", flush=True)
+    bad += dictionary_rounds(bc, max(2, rounds // 2))
     print("FUZZ-DECODE", "PASS" if bad == 0 else f"FAIL ({bad})")
     return 1 if bad else 0
 
