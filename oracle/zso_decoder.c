@@ -875,7 +875,7 @@ static size_t decompressBlock_internal(DCtx *d, void *dst, size_t dstCapacity, c
     { size_t const litCSize = decodeLiteralsBlock(d, src, srcSize); if (zso_isError(litCSize)) return litCSize; ip += litCSize; srcSize -= litCSize;
       g_stats[32] += (U32)litCSize; g_stats[31] += (U32)d->litSize; }
     {
-        int nbSeq;
+        int nbSeq = 0;
         size_t const seqHSize = decodeSeqHeaders(d, &nbSeq, ip, srcSize);
         if (zso_isError(seqHSize)) return seqHSize;
         ip += seqHSize; srcSize -= seqHSize;
