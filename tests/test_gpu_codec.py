@@ -281,3 +281,25 @@ def test_pack_frames_device():
     import subprocess
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pack_check.py")], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_checksummed_one_block_frames(codec):
+    """frames with a content checksum (libzstd ZSTD_c_checksumFlag) of the one-block shape: the decoder's fast path checks the
+    XXH64 itself (k_dec_checksum); a wrong checksum is checksum_wrong (22) as in the reference (ZStdDecompress.cs:2076-2083)"""
+    if not O.libzstd():
+        pytest.skip("libzstd not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from gpu_fuzz_decode import zstd_compress_checked
+    data = D.zipf_log(1 << 20, seed_lo=23)
+    chunks = [data[i * 30000:(i + 1) * 30000].tobytes() for i in range(12)]
+    frames = [zstd_compress_checked(c, 3 + (i % 5)) for i, c in enumerate(chunks)]
+    assert all((f[4] >> 2) & 1 for f in frames)                                     # the checksum flag is set
+    bad_sum = [bytes(f[:-1]) + bytes([f[-1] ^ 0x40]) for f in frames[:4]]            # stored checksum damaged
+    res = _decompress_many(codec, frames + bad_sum, [len(c) for c in chunks] + [len(c) for c in chunks[:4]])
+    for (sz, got), c in zip(res[:len(frames)], chunks):
+        assert sz == len(c) and got == c
+    for (sz, _), f, c in zip(res[len(frames):], bad_sum, chunks):
+        assert sz > ERR and (0x100000000 - sz) == 22
+        with pytest.raises(O.OracleError) as e:
+            O.decompress(f, len(c))
+        assert e.value.code == 22

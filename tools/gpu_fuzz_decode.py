@@ -73,6 +73,27 @@ def dictionary_rounds(bc, rounds):
     return bad
 
 
+_zc = None
+def zstd_compress_checked(data, level):
+    """libzstd frame WITH a content checksum (ZSTD_c_checksumFlag): the fast path's k_dec_checksum, or the general kernel's :2076"""
+    global _zc
+    import ctypes
+    if _zc is None:
+        Z = ctypes.CDLL("libzstd.so.1"); sz, vp = ctypes.c_size_t, ctypes.c_void_p
+        Z.ZSTD_createCCtx.restype = vp
+        Z.ZSTD_CCtx_setParameter.restype = sz; Z.ZSTD_CCtx_setParameter.argtypes = [vp, ctypes.c_int, ctypes.c_int]
+        Z.ZSTD_compress2.restype = sz; Z.ZSTD_compress2.argtypes = [vp, vp, sz, ctypes.c_char_p, sz]
+        Z.ZSTD_compressBound.restype = sz; Z.ZSTD_compressBound.argtypes = [sz]
+        Z.ZSTD_isError.restype = ctypes.c_uint; Z.ZSTD_isError.argtypes = [sz]
+        _zc = (Z, Z.ZSTD_createCCtx())
+    Z, cctx = _zc
+    assert not Z.ZSTD_isError(Z.ZSTD_CCtx_setParameter(cctx, 100, level))      # ZSTD_c_compressionLevel
+    assert not Z.ZSTD_isError(Z.ZSTD_CCtx_setParameter(cctx, 201, 1))          # ZSTD_c_checksumFlag
+    cap = Z.ZSTD_compressBound(len(data)); out = ctypes.create_string_buffer(cap)
+    r = Z.ZSTD_compress2(cctx, out, cap, data, len(data)); assert not Z.ZSTD_isError(r)
+    return out.raw[:r]
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
     if not O.libzstd():
@@ -87,7 +108,7 @@ def main():
             n = int(rng.choice([rng.integers(1, 2000), rng.integers(2000, 70000), rng.integers(70000, 400000)]))
             a = int(rng.integers(0, len(s) - n))
             c = s[a:a + n].tobytes()
-            f = O.zstd_compress(c, int(rng.integers(1, 20)))
+            f = zstd_compress_checked(c, int(rng.integers(1, 20))) if i % 3 == 0 else O.zstd_compress(c, int(rng.integers(1, 20)))
             chunks.append(c); frames.append(f)
         sizes = np.array([len(c) for c in chunks], dtype=np.uint32)
         fsz = np.array([len(f) for f in frames], dtype=np.uint32)

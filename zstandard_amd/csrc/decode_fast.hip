@@ -39,7 +39,7 @@ struct ZsFastDesc {                               // per item, global memory, wr
     uint32_t nbSeq, seqOff, seqSize;              // sequence bitstream inside the item's source
     uint32_t llLog, ofLog, mlLog;
     uint32_t contentSize, hasContentSize;
-    uint32_t pad[2];
+    uint32_t hasChecksum, checksum;               // content checksum (low 32 bits of XXH64, ZStdDecompress.cs:2078-2082): checked by k_dec_checksum
 };
 #define ZS_FAST_HUFTAB_BYTES (2u << ZS_FAST_HUFLOG)                       // uint16 entries
 #define ZS_FAST_SEQTAB_BYTES ((512u + 256u + 512u) * 2u)                  // LL, OF, ML cells, 2 bytes each
@@ -79,19 +79,20 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
     ZsFastDesc d;
     d.fast = 0; d.litType = 0; d.litSize = 0; d.litSrc = 0; d.hufLog = 0; d.nStreams = 0;
     for (int k = 0; k < 4; k++) { d.sOff[k] = d.sLen[k] = d.sCnt[k] = d.sOut[k] = 0; }
-    d.nbSeq = d.seqOff = d.seqSize = 0; d.llLog = d.ofLog = d.mlLog = 0; d.contentSize = 0; d.hasContentSize = 0; d.pad[0] = d.pad[1] = 0;
+    d.nbSeq = d.seqOff = d.seqSize = 0; d.llLog = d.ofLog = d.mlLog = 0; d.contentSize = 0; d.hasContentSize = 0; d.hasChecksum = 0; d.checksum = 0;
     if (lane < 36) L.llTab[lane] = d_LL_base[lane] | ((uint32_t)d_LL_bits[lane] << 24);
     if (lane < 53) L.mlTab[lane] = d_ML_base[lane] | ((uint32_t)d_ML_bits[lane] << 24);
     wave_sync();
     do {
-        // ---- frame header (:389-499): one frame, no dictionary, no checksum ----
+        // ---- frame header (:389-499): one frame, no dictionary ----
         if (srcSize < 5 + 1 + 3 || rd32(src) != 0xFD2FB528u) break;
         const uint32_t fhd = src[4];
         const uint32_t dictIDCode = fhd & 3, checksumFlag = (fhd >> 2) & 1, singleSegment = (fhd >> 5) & 1, fcsID = fhd >> 6;
-        if (dictIDCode || checksumFlag || (fhd & 0x08)) break;
+        if (dictIDCode || (fhd & 0x08)) break;
+        const uint32_t tail = checksumFlag ? 4u : 0u;              // the checksum behind the block
         const uint32_t fcsSize = fcsID == 0 ? 0 : (fcsID == 1 ? 2 : (fcsID == 2 ? 4 : 8));
         const uint32_t fhs = 5 + !singleSegment + fcsSize + (singleSegment && !fcsID);
-        if (srcSize < fhs + 3) break;
+        if (srcSize < fhs + 3 + tail) break;
         uint32_t pos = 5;
         if (!singleSegment) { const uint32_t wl = src[pos++]; if ((wl >> 3) + 10 > 30) break; }
         uint64_t fcs = ~0ull;
@@ -102,7 +103,8 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
         const uint32_t bh = rd24(src + fhs);
         const uint32_t lastBlock = bh & 1, btype = (bh >> 1) & 3, cSize = bh >> 3;
         if (!lastBlock || btype != 2 || cSize >= (1u << 17) || cSize < 3) break;
-        if ((uint64_t)fhs + 3 + cSize != srcSize) break;
+        if ((uint64_t)fhs + 3 + cSize + tail != srcSize) break;
+        if (checksumFlag) { d.hasChecksum = 1; d.checksum = rd32(src + srcSize - 4); }
         const uint32_t b0 = fhs + 3;                               // block payload offset in the item
         const uint8_t *bs = src + b0;
         // ---- literals section header (:683-821) ----
@@ -533,4 +535,23 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     }
     if (!bad && d.hasContentSize && op != d.contentSize) bad = true;
     if (lane == 0) { if (bad) descs[item].fast = 0; else dstSizes[item] = (uint32_t)op; }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k_dec_checksum : lane = item.  Items the fast kernels decoded and whose frame carries a content checksum: XXH64 of the
+// output, low 32 bits against the stored value (ZStdDecompress.cs:2076-2083); a mismatch is the item's result (checksum_wrong).
+// Launched only when a call's frames may carry checksums; items without one cost their lane a flag read.
+// ---------------------------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64)
+k_dec_checksum(const ZsDecItem *__restrict__ items, uint32_t nItems, const ZsFastDesc *__restrict__ descs, const uint8_t *__restrict__ dstAll,
+               uint32_t *__restrict__ dstSizes)
+{
+    const uint32_t item = blockIdx.x * 64 + threadIdx.x;
+    if (item >= nItems) return;
+    const ZsFastDesc *d = descs + item;
+    if (!d->fast || !d->hasChecksum) return;
+    const uint32_t size = dstSizes[item];
+    if (size > 0xFFFFFF88u) return;
+    const uint64_t h = xxh64(dstAll + items[item].dstOff, size);
+    if ((uint32_t)h != d->checksum) dstSizes[item] = ZE(E_checksum_wrong);
 }
