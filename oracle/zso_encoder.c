@@ -17,17 +17,14 @@
  *
  * Algorithm (one frame per chunk, blocks of <= 64 KiB; match search works on LZ UNITS of <= 128 KiB =
  * two consecutive blocks of a chunk, so the second block of a unit may copy from the first):
- *  1. candidates: the unit is cut in RANGES of 8 KiB; each range owns a hash table of 2^HASH_LOG
- *     16-bit slots.  A slot holds the position within the range (13 bits) and a 3-bit TAG (the
- *     hash bits below the slot index).  Position p hashes its 4 bytes and takes the slot's
- *     previous owner in its own range if the tag agrees, else the entry of the nearest earlier
- *     range whose slot is filled with the same tag.  A candidate is kept when its 4 bytes equal
- *     those at p.  -> dist[p]
- *  2. parse: the unit is cut again, in walk ranges of 1 KiB; each is walked greedily and
- *     independently: the first LOOK candidates of a 64-position window are scored, the best one
- *     becomes a sequence, extended forward to the range end at most.
- *  3. ranges are concatenated (a range's trailing literals go to the next range's first
- *     sequence), offsets become repcodes through the decoder's 3-entry recent-offset list
+ *  1. candidates: two unit-wide hash tables (short: 5 bytes hashed, long: 8 bytes hashed, level >= 3 only),
+ *     every position inserted in order, last writer keeps the slot, slots carry a 15-bit tag.  A position's
+ *     candidate = previous owner of its long slot, else of its short slot (tag must agree).  -> dist[p]
+ *  2. parse: each block is cut in walk ranges of 1 KiB; each is walked greedily and independently: the first
+ *     LOOK candidate positions of a 64-position window (stage-1 candidates, and repeats of the walker's two
+ *     recent offsets) are scored, the best one becomes a sequence; matches may pass the range end.
+ *  3. stitch: ranges give up what an earlier range's match already covers; the ranges are concatenated,
+ *     offsets become repcodes through the decoder's 3-entry recent-offset list
  *     (inverse of ZStdDecompress.cs:1509-1530).
  *  4. literals: histogram, length-limited (11 bit) Huffman by package-merge, weights
  *     written direct or FSE-compressed (inverse of EntropyCommon.cs:198-269 and
@@ -53,16 +50,12 @@ typedef uint64_t U64;
 /* ---- tunables (the HIP kernels are built with the same values) ---- */
 #define BLOCK_MAX   65536u          /* bytes per block */
 #define UNIT_MAX    131072u         /* bytes per LZ unit (match window): two blocks */
-#define RANGE_LOG   13
-#define RANGE_SIZE  (1u << RANGE_LOG)
-#define MAX_RANGES  (UNIT_MAX / RANGE_SIZE)
-#define WALK_LOG    10              /* the walk cuts the unit in ranges of 1 KiB (the hash tables keep their 8 KiB ranges) */
+#define WALK_LOG    10              /* the walk cuts a block in ranges of 1 KiB */
 #define WALK_SIZE   (1u << WALK_LOG)
-#define WALK_RANGES (UNIT_MAX / WALK_SIZE)
-#define MINMATCH    5               /* shortest match kept (candidates are still found by their first 4 bytes) */
-#define MAX_HASH_LOG 13
-#define TAG_BITS    3               /* RANGE_LOG + TAG_BITS = 16: one slot is a uint16 */
-#define SLOT_EMPTY  0xFFFFu
+#define SEQ_PER_RANGE 256u          /* a range's matches start inside it and are >= 4 bytes long */
+#define CROSS_MAX   16384u           /* a match may pass its range's end by this much (and never the block's end) */
+#define MINMATCH    5               /* shortest match kept; a recent-offset match may be 4 */
+#define MAX_TABLE_LOG 14
 #define HUF_MAXBITS 11
 #define MaxLL 35
 #define MaxML 52
@@ -71,19 +64,12 @@ typedef uint64_t U64;
 #define MLFSELog 9
 #define OffFSELog 8
 
-/* level <= 2 : LOOK 4 ("fast") ; level >= 3 : LOOK 8.  Both: 2^12 slots per 8 KiB range. */
-typedef struct { int hashLog; int look; } EParams;
-static EParams g_override = { 0, 0 };
-/* test hook: lets the ratio-tuning script try parameters without recompiling (0 = keep level default) */
-void zso_encoderOverride(int hashLog, int look)
-{ g_override.hashLog = hashLog > MAX_HASH_LOG ? MAX_HASH_LOG : hashLog; g_override.look = look; }
-
+/* level <= 2 ("fast"): the short table only, LOOK 4 ; level >= 3 ("double"): short + long table, LOOK 8. */
+typedef struct { int useLong; int look; } EParams;
 static EParams paramsForLevel(int level)
 {
     EParams p;
-    p.hashLog = 12; p.look = (level <= 2) ? 4 : 8;
-    if (g_override.hashLog) p.hashLog = g_override.hashLog;
-    if (g_override.look) p.look = g_override.look;
+    p.useLong = level >= 3; p.look = (level <= 2) ? 4 : 8;
     return p;
 }
 
@@ -513,10 +499,14 @@ static size_t writeLiterals(BYTE *dst, size_t cap, const BYTE *lit, U32 nlit)
  *  LZ stage
  * ======================================================================= */
 typedef struct { U32 litLength, matchLength, offset; } Seq;
+typedef struct { U32 start, ml, off; } ASeq;   /* match start (unit position, after backward extension), length, distance */
 
 typedef struct {
-    U32 dist[UNIT_MAX];                       /* verified candidate distance per unit position, 0 = none */
-    U16 tables[MAX_RANGES][1 << MAX_HASH_LOG];          /* per-range hash tables (slot = tag << 13 | position in range) */
+    U32 dist[UNIT_MAX];                       /* candidate distance per unit position, 0 = none */
+    U32 tabS[1u << MAX_TABLE_LOG], tabL[1u << MAX_TABLE_LOG];
+    ASeq rangeSeq[BLOCK_MAX / WALK_SIZE][SEQ_PER_RANGE];
+    U32 rangeN[BLOCK_MAX / WALK_SIZE];
+    struct { U32 first, nseq, trailing, litSum; } hdr[BLOCK_MAX / WALK_SIZE];
     Seq seqs[BLOCK_MAX / 3 + 8];
     BYTE lits[BLOCK_MAX + 8];
     BYTE llCode[BLOCK_MAX / 3 + 8], mlCode[BLOCK_MAX / 3 + 8], ofCode[BLOCK_MAX / 3 + 8];
@@ -524,44 +514,43 @@ typedef struct {
     BYTE tmp[BLOCK_MAX + 1024];
 } Work;
 
-/* stage 1, once per unit.  Positions are taken in STEPS of 64 (one wavefront): all 64 read the tables
- * first, then all 64 write their own range's table, the highest position winning a shared slot; so a
- * position never sees a candidate from its own step.  A distance of exactly 65536 is not kept (the GPU
- * keeps the low 16 bits of the distance in one array and bit 16 in another; low bits 0 = no candidate). */
-#define STEP 64u
-static U32 slotOf(U32 v, int hashLog) { return (v * 2654435761u) >> (32 - hashLog); }
-static U32 tagOf(U32 v, int hashLog) { return ((v * 2654435761u) >> (32 - hashLog - TAG_BITS)) & ((1u << TAG_BITS) - 1); }
+/* stage 1, once per unit: two unit-wide hash tables, every position inserted in position order, the last writer
+ * keeps a slot.
+ *   short: hash of 5 bytes, long: hash of 8 bytes (level >= 3 only); 2^13 slots for units <= 64 KiB, 2^14 above.
+ *   slot = tag (15 hash bits below the index bits) << 17 | position; a lookup whose tag differs is a miss.
+ * A position's candidate is the previous owner of its long slot if the tag agrees, else that of its short slot.
+ * Candidates are NOT compared with the bytes here (28 hash bits agree; the walk measures every match it uses).
+ * On the GPU one wavefront per table takes 64 positions per LDS exchange instruction (ds_wrxchg_rtn_b32);
+ * the LDS resolves lanes that hit the same slot in ascending lane order (probed: tools/probe/lds_xchg.hip), which
+ * is exactly this loop. */
+#define SLOT_EMPTY 0xFFFFFFFFu
+static U32 hashShort(const BYTE *p) { return rd32(p) * 0x9E3779B1u + (U32)p[4] * 0x9E3779u; }
+static U32 rotl32(U32 v, int r) { return (v << r) | (v >> (32 - r)); }
+static U32 hashLong(const BYTE *p) { return (rd32(p + 4) ^ rotl32(rd32(p) * 0x9E3779B1u, 15)) * 0x85EBCA77u; }
+static U32 tableLogFor(U32 unitN) { return unitN > BLOCK_MAX ? MAX_TABLE_LOG : MAX_TABLE_LOG - 1; }
 static void findCandidates(Work *w, const BYTE *src, U32 n, const EParams *prm)
 {
-    U32 const nRanges = (n + RANGE_SIZE - 1) >> RANGE_LOG;
-    U32 const last = (n >= 4) ? n - 4 : 0;          /* last position whose 4 bytes exist */
-    U32 r, p, base;
+    U32 const tlog = tableLogFor(n);
+    U32 p;
     memset(w->dist, 0, n * sizeof(U32));
-    if (n < 4) return;
-    for (r = 0; r < nRanges; r++) memset(w->tables[r], 0xFF, sizeof(U16) << prm->hashLog);
-    for (r = 0; r < nRanges; r++) {
-        U32 const start = r << RANGE_LOG;
-        U32 end = start + RANGE_SIZE; if (end > last + 1) end = last + 1;
-        for (base = start; base < end; base += STEP) {
-            U32 const stop = base + STEP < end ? base + STEP : end;
-            for (p = base; p < stop; p++) {
-                U32 const v = rd32(src + p);
-                U32 const h = slotOf(v, prm->hashLog), tag = tagOf(v, prm->hashLog);
-                int q;
-                for (q = (int)r; q >= 0; q--) {
-                    U32 const e = w->tables[q][h];
-                    if (e != SLOT_EMPTY && (e >> RANGE_LOG) == tag) {
-                        U32 const cand = ((U32)q << RANGE_LOG) + (e & (RANGE_SIZE - 1));
-                        if (rd32(src + cand) == v && p - cand != 65536u) w->dist[p] = p - cand;
-                        break;
-                    }
-                }
-            }
-            for (p = base; p < stop; p++) {
-                U32 const v = rd32(src + p);
-                w->tables[r][slotOf(v, prm->hashLog)] = (U16)((tagOf(v, prm->hashLog) << RANGE_LOG) | (p & (RANGE_SIZE - 1)));
-            }
+    if (n < 8) return;
+    memset(w->tabS, 0xFF, sizeof(U32) << tlog);
+    if (prm->useLong) memset(w->tabL, 0xFF, sizeof(U32) << tlog);
+    for (p = 0; p + 8 <= n; p++) {
+        U32 const hs = hashShort(src + p);
+        U32 const es = (((hs >> (32 - tlog - 15)) & 0x7FFFu) << 17) | p;
+        U32 const os = w->tabS[hs >> (32 - tlog)];
+        U32 d = 0;
+        w->tabS[hs >> (32 - tlog)] = es;
+        if (os != SLOT_EMPTY && ((os ^ es) >> 17) == 0) d = p - (os & 0x1FFFFu);
+        if (prm->useLong) {
+            U32 const hl = hashLong(src + p);
+            U32 const el = (((hl >> (32 - tlog - 15)) & 0x7FFFu) << 17) | p;
+            U32 const ol = w->tabL[hl >> (32 - tlog)];
+            w->tabL[hl >> (32 - tlog)] = el;
+            if (ol != SLOT_EMPTY && ((ol ^ el) >> 17) == 0) d = p - (ol & 0x1FFFFu);
         }
+        w->dist[p] = d;
     }
 }
 
@@ -572,44 +561,79 @@ static U32 matchLen(const BYTE *src, U32 a, U32 b, U32 limit)   /* common prefix
     return l;
 }
 
-/* stage 2 : one range, walked by one wavefront on the GPU.
- * Each step looks at the WINDOW = 64 positions from ip, takes the first LOOK (<= 8) of them that hold a
- * candidate, and scores each: forward match length (compared over at most FCAP bytes for the score),
- * backward extension into the pending literals (at most BCAP bytes), offset cost, literals skipped.
- * The best one becomes a sequence; if its forward compare hit FCAP it is then extended in full.
- * Matches stop at the range end. */
+/* stage 2 : one walk range [start, end), walked by 8 lanes on the GPU; matches may run on to `limit` (> end: the next
+ * ranges' territory, given back by the stitch below).
+ * Each step looks at the WINDOW = 64 positions from ip.  A position holds a candidate if (in this order of preference)
+ * one of the walker's two recent offsets repeats 4 bytes there (only the first REPWIN positions of the window are
+ * tried) or stage 1 left a distance.  The first LOOK (<= 8) such positions are scored: forward match length (the score
+ * counts at most FCAP bytes), backward extension into the pending literals (at most BCAP bytes), offset cost (none
+ * for a recent offset), literals skipped.  The best one becomes a sequence with its full forward length. */
 #define WINDOW 64u
+#define REPWIN 16u
 #define FCAP 8u
 #define BCAP 8u
-static U32 walkRange(Work *w, const BYTE *src, U32 n, U32 start, U32 end, const EParams *prm, Seq *out, U32 *trailingLits)
+#define REPMIN 4u
+static U32 walkRange(Work *w, const BYTE *src, U32 n, U32 start, U32 end, U32 limit, const EParams *prm, ASeq *out)
 {
-    U32 ip = start, anchor = start, nseq = 0;
-    U32 const lastStart = (n >= 4) ? n - 4 : 0;
+    U32 ip = start, anchor = start, nseq = 0, rep0 = 0, rep1 = 0;
+    U32 const hashable = (n >= 8) ? n - 7 : 0;
     U32 const look = (U32)prm->look;
-    U32 const scanEnd = (end < lastStart + 1) ? end : lastStart + 1;     /* candidates start below this */
+    U32 const scanEnd = (end < hashable) ? end : hashable;     /* candidates start below this */
     while (ip < scanEnd) {
         int bestGain = 0, have = 0; U32 bestQ = 0, bestFwd = 0, bestBack = 0, bestOff = 0, q, seen = 0;
         U32 const wend = (ip + WINDOW < scanEnd) ? ip + WINDOW : scanEnd;
         for (q = ip; q < wend && seen < look; q++) {
-            U32 const off = w->dist[q];
-            U32 fwd, back = 0, cap;
-            int gain;
+            U32 off = 0, fwd, back = 0; int isRep = 0, gain;
+            if (q < ip + REPWIN && q + 4 <= limit) {
+                if (rep0 && q >= rep0 && rd32(src + q) == rd32(src + q - rep0)) { off = rep0; isRep = 1; }
+                else if (rep1 && q >= rep1 && rd32(src + q) == rd32(src + q - rep1)) { off = rep1; isRep = 1; }
+            }
+            if (!off) off = w->dist[q];
             if (!off) continue;
             seen++;
-            cap = end - q; if (cap > FCAP) cap = FCAP;
-            fwd = matchLen(src, q, q - off, q + cap);
-            if (fwd < MINMATCH) continue;
+            fwd = matchLen(src, q, q - off, limit);
+            if (fwd < (isRep ? REPMIN : MINMATCH)) continue;
             while (back < BCAP && q - back > anchor && q - off - back > 0 && src[q - back - 1] == src[q - off - back - 1]) back++;
-            gain = (int)(fwd + back) * 4 - (int)highbit32(off + 1) - 4 * ((int)(q - back) - (int)ip) - (int)(q - ip);
+            gain = (int)((fwd > FCAP ? FCAP : fwd) + back) * 4 - (isRep ? 0 : (int)highbit32(off + 1)) - 4 * ((int)(q - back) - (int)ip) - (int)(q - ip);
             if (!have || gain > bestGain) { have = 1; bestGain = gain; bestQ = q; bestFwd = fwd; bestBack = back; bestOff = off; }
         }
         if (!have) { ip = wend; continue; }
-        if (bestFwd == FCAP) bestFwd = matchLen(src, bestQ, bestQ - bestOff, end);
-        out[nseq].litLength = bestQ - bestBack - anchor; out[nseq].matchLength = bestBack + bestFwd; out[nseq].offset = bestOff; nseq++;
+        out[nseq].start = bestQ - bestBack; out[nseq].ml = bestBack + bestFwd; out[nseq].off = bestOff; nseq++;
         ip = bestQ + bestFwd; anchor = ip;
+        if (bestOff == rep1) { rep1 = rep0; rep0 = bestOff; }
+        else if (bestOff != rep0) { rep1 = rep0; rep0 = bestOff; }
     }
-    *trailingLits = end - anchor;
     return nseq;
+}
+
+/* stage 3a, the stitch: reach[r] = farthest match end of the ranges up to r (as walked).  Range r owns the territory
+ * [max(start_r, reach[r-1]), max(end_r, reach[r])): its sequences that end inside an earlier range's match are dropped, one
+ * that straddles the border loses its front (and goes if fewer than MINMATCH bytes are left).  What a range keeps is a
+ * suffix [first, first + nseq) of its list.  Every range decides from reach[] alone: one lane per range on the GPU, which
+ * also leaves litSum (literals in front of the kept matches inside the territory) and trailing (behind the last one). */
+static void stitch(Work *w, U32 blockOff, U32 n)
+{
+    U32 const nRanges = (n + WALK_SIZE - 1) >> WALK_LOG;
+    U32 const blockEnd = blockOff + n;
+    U32 reach = blockOff, r;
+    for (r = 0; r < nRanges; r++) {
+        U32 const own = reach;                         /* reach[r-1] */
+        U32 const ns = w->rangeN[r];
+        U32 const rs = blockOff + (r << WALK_LOG), re = (rs + WALK_SIZE < blockEnd) ? rs + WALK_SIZE : blockEnd;
+        U32 const le = ns ? w->rangeSeq[r][ns - 1].start + w->rangeSeq[r][ns - 1].ml : 0;
+        U32 es, te, f = 0, k, sumMl = 0, lastEnd;
+        if (le > reach) reach = le;
+        es = rs > own ? rs : own; te = re > reach ? re : reach;
+        while (f < ns) {
+            ASeq *s = &w->rangeSeq[r][f];
+            if (s->start + s->ml <= own) { f++; continue; }
+            if (s->start < own) { U32 const cut = own - s->start; if (s->ml - cut < MINMATCH) { f++; continue; } s->start += cut; s->ml -= cut; }
+            break;
+        }
+        for (k = f; k < ns; k++) sumMl += w->rangeSeq[r][k].ml;
+        lastEnd = (ns > f) ? le : es;
+        w->hdr[r].first = f; w->hdr[r].nseq = ns - f; w->hdr[r].trailing = te - lastEnd; w->hdr[r].litSum = (lastEnd - es) - sumMl;
+    }
 }
 
 /* ======================================================================= *
@@ -617,6 +641,7 @@ static U32 walkRange(Work *w, const BYTE *src, U32 n, U32 start, U32 end, const 
  *  returns payload size, or 0 if the block should be stored raw
  * ======================================================================= */
 /* src / unitN: the LZ unit (findCandidates has run on it); the block is src[blockOff .. blockOff + n) */
+static size_t encodeParsed(Work *w, BYTE *dst, size_t cap, U32 nseq, U32 nlit, int firstBlock);
 static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32 unitN, U32 blockOff, U32 n, const EParams *prm, int firstBlock)
 {
     U32 nseq = 0, nlit = 0;
@@ -624,28 +649,33 @@ static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32
     U32 const blockEnd = blockOff + n;
     U32 r;
     if (n < 16) return 0;
-    {
-        /* stage 2 + 3a: walk ranges, concatenate */
-        U32 carry = 0, pos = blockOff;
-        static __thread Seq rangeSeq[WALK_SIZE / 3 + 8];
+    /* stage 2: every range on its own */
+    for (r = 0; r < nRanges; r++) {
+        U32 const start = blockOff + (r << WALK_LOG);
+        U32 const end = (start + WALK_SIZE < blockEnd) ? start + WALK_SIZE : blockEnd;
+        U32 const limit = (end + CROSS_MAX < blockEnd) ? end + CROSS_MAX : blockEnd;
+        w->rangeN[r] = walkRange(w, src, unitN, start, end, limit, prm, w->rangeSeq[r]);
+    }
+    stitch(w, blockOff, n);
+    {   /* concatenate what the ranges keep; what lies between kept matches is literals */
+        U32 pos = blockOff;                            /* end of the last kept match */
         for (r = 0; r < nRanges; r++) {
-            U32 const start = blockOff + (r << WALK_LOG);
-            U32 const end = (start + WALK_SIZE < blockEnd) ? start + WALK_SIZE : blockEnd;
-            U32 trailing, k;
-            U32 const ns = walkRange(w, src, unitN, start, end, prm, rangeSeq, &trailing);
-            for (k = 0; k < ns; k++) {
-                Seq s = rangeSeq[k];
-                if (k == 0) s.litLength += carry;
-                memcpy(w->lits + nlit, src + pos, s.litLength); nlit += s.litLength; w->seqs[nseq++] = s;
-                pos += s.litLength + s.matchLength;
+            U32 k;
+            for (k = w->hdr[r].first; k < w->hdr[r].first + w->hdr[r].nseq; k++) {
+                ASeq const s = w->rangeSeq[r][k];
+                w->seqs[nseq].litLength = s.start - pos; w->seqs[nseq].matchLength = s.ml; w->seqs[nseq].offset = s.off; nseq++;
+                memcpy(w->lits + nlit, src + pos, s.start - pos); nlit += s.start - pos;
+                pos = s.start + s.ml;
             }
-            carry = ns ? trailing : carry + trailing;
         }
         memcpy(w->lits + nlit, src + pos, blockEnd - pos); nlit += blockEnd - pos;    /* last literals */
     }
-    if (nseq == 0 && nlit == n) {
-        /* no match at all: only worth a compressed block if Huffman alone wins; handled below with nbSeq = 0 */
-    }
+    return encodeParsed(w, dst, cap, nseq, nlit, firstBlock);
+}
+
+/* stages 3b-6 for one block whose sequences (w->seqs) and literals (w->lits) are in place */
+static size_t encodeParsed(Work *w, BYTE *dst, size_t cap, U32 nseq, U32 nlit, int firstBlock)
+{
     {
         /* stage 3b: offsets -> offset field values through the 3-entry recent-offset list
          * (inverse of ZStdDecompress.cs:1509-1530).  Blocks after the first start from an unknown
@@ -828,24 +858,33 @@ int zso_debugCandidates(uint32_t *distOut, const void *src, uint32_t n, int leve
     free(w);
     return 0;
 }
-/* seqOut: per walk range r (1 KiB), up to 256 triples (litLength, matchLength, offset) at seqOut[(r*256 + k)*3];
- * hdrOut[r*2] = number of sequences, hdrOut[r*2+1] = trailing literals of the range */
+/* after the stitch, as the GPU walk kernel leaves it.  The unit's blocks are taken in turn; per walk range r (1 KiB) of the unit:
+ * hdrOut[r*4 ..] = first, nseq, trailing, litSum; seqOut[(r*256 + k)*3 ..] = (start in its block, matchLength, offset) of record k */
 int zso_debugWalk(uint32_t *seqOut, uint32_t *hdrOut, const void *src, uint32_t n, int level)
 {
     EParams const prm = paramsForLevel(level);
     Work *w = (Work *)malloc(sizeof(Work));
-    Seq *tmp = (Seq *)malloc(sizeof(Seq) * (WALK_SIZE / 3 + 8));
-    U32 r, nRanges = (n + WALK_SIZE - 1) >> WALK_LOG;
-    if (!w || !tmp || n > UNIT_MAX) { free(w); free(tmp); return -1; }
+    U32 blockOff;
+    if (!w || n > UNIT_MAX) { free(w); return -1; }
     findCandidates(w, (const BYTE *)src, n, &prm);
-    for (r = 0; r < nRanges; r++) {
-        U32 const start = r << WALK_LOG;
-        U32 const end = (start + WALK_SIZE < n) ? start + WALK_SIZE : n;
-        U32 trailing, k;
-        U32 const ns = walkRange(w, (const BYTE *)src, n, start, end, &prm, tmp, &trailing);
-        hdrOut[r * 2] = ns; hdrOut[r * 2 + 1] = trailing;
-        for (k = 0; k < ns; k++) { seqOut[(r * 256 + k) * 3] = tmp[k].litLength; seqOut[(r * 256 + k) * 3 + 1] = tmp[k].matchLength; seqOut[(r * 256 + k) * 3 + 2] = tmp[k].offset; }
+    for (blockOff = 0; blockOff < n; blockOff += BLOCK_MAX) {
+        U32 const bn = (n - blockOff < BLOCK_MAX) ? n - blockOff : BLOCK_MAX;
+        U32 const blockEnd = blockOff + bn, nRanges = (bn + WALK_SIZE - 1) >> WALK_LOG;
+        U32 r, k;
+        if (bn < 16) { for (r = 0; r < nRanges; r++) w->rangeN[r] = 0; }
+        else for (r = 0; r < nRanges; r++) {
+            U32 const start = blockOff + (r << WALK_LOG);
+            U32 const end = (start + WALK_SIZE < blockEnd) ? start + WALK_SIZE : blockEnd;
+            U32 const limit = (end + CROSS_MAX < blockEnd) ? end + CROSS_MAX : blockEnd;
+            w->rangeN[r] = walkRange(w, (const BYTE *)src, n, start, end, limit, &prm, w->rangeSeq[r]);
+        }
+        stitch(w, blockOff, bn);
+        for (r = 0; r < nRanges; r++) {
+            U32 const ur = (blockOff >> WALK_LOG) + r;
+            hdrOut[ur * 4] = w->hdr[r].first; hdrOut[ur * 4 + 1] = w->hdr[r].nseq; hdrOut[ur * 4 + 2] = w->hdr[r].trailing; hdrOut[ur * 4 + 3] = w->hdr[r].litSum;
+            for (k = 0; k < w->rangeN[r]; k++) { seqOut[(ur * 256 + k) * 3] = w->rangeSeq[r][k].start - blockOff; seqOut[(ur * 256 + k) * 3 + 1] = w->rangeSeq[r][k].ml; seqOut[(ur * 256 + k) * 3 + 2] = w->rangeSeq[r][k].off; }
+        }
     }
-    free(w); free(tmp);
+    free(w);
     return 0;
 }

@@ -31,7 +31,6 @@ def lib():
         L.zso_errorCode.restype = ctypes.c_uint; L.zso_errorCode.argtypes = [sz]
         L.zso_xxh64.restype = ctypes.c_uint64; L.zso_xxh64.argtypes = [vp, sz, ctypes.c_uint64]
         L.zso_statsGet.argtypes = [vp]
-        L.zso_encoderOverride.argtypes = [ctypes.c_int] * 2
         L.zso_compressBatch.restype = ctypes.c_int
         L.zso_compressBatch.argtypes = [vp, vp, vp, vp, vp, vp, ctypes.c_uint32, ctypes.c_int, ctypes.c_int]
         L.zso_decompressBatch.restype = ctypes.c_int

@@ -55,16 +55,36 @@ def test_ratio_vs_libzstd(cs, level):
     assert e <= z * 1.01, (e, z)
 
 
+@pytest.mark.skipif(not O.libzstd(), reason="libzstd not present")
+@pytest.mark.parametrize("cs,level", [(65536, 3), (131072, 1), (131072, 3), (65536, 1), (32768, 3)])
+def test_ratio_vs_libzstd_mixed_corpus(cs, level):
+    """the same 1 % tolerance per class of the mixed corpus (tests/_corpus.py: text, source code, ELF, JSON / CSV / XML
+    records, binary tables, very repetitive data): compressed size <= 1.01 x libzstd's at the same level and chunk size"""
+    import _corpus as C
+    worst = {}
+    for name, data in C.corpus(1 << 20).items():
+        e = z = 0
+        for i in range(0, len(data), cs):
+            c = data[i:i + cs]
+            f = O.compress(c, level)
+            if i == 0:
+                assert O.decompress(f, len(c)) == c
+            e += len(f)
+            z += len(O.zstd_compress(c, level))
+        worst[name] = round(e / z, 4)
+    assert all(v <= 1.01 for v in worst.values()), worst
+
+
 def test_far_offsets_reach_the_first_block():
-    """second block of an LZ unit copies from the first: offsets beyond 65535 appear, except the unsupported distance 65536"""
+    """second block of an LZ unit copies from the first: offsets beyond 65535 appear, distance exactly 65536 included"""
     rng = np.random.default_rng(3)
     b = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
     f = O.compress(b + b, 3)
     # raw first block (65536) + 4464 new literals + matches into the first block + 8928 bytes of a second unit without history
     assert len(f) < 80000 and O.decompress(f, 140000) == b + b
     b = rng.integers(0, 256, 65536, dtype=np.uint8).tobytes()
-    f = O.compress(b + b, 3)                     # distance exactly 65536 is dropped by design: both blocks stay raw
-    assert len(f) > 131072 and O.decompress(f, 131072) == b + b
+    f = O.compress(b + b, 3)
+    assert len(f) < 66000 and O.decompress(f, 131072) == b + b
 
 
 def test_batch_threads_agree():

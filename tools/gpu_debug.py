@@ -38,20 +38,27 @@ def main():
                 hi = np.zeros(16384, dtype=np.uint8); Z.zsmi_dbg_copyScratch(bc.ctx, 4, hi.ctypes.data_as(ctypes.c_void_p), 16384)
                 dist_g |= np.unpackbits(hi, bitorder="little")[:n0].astype(np.uint32) << 16
                 dist_g[dist_lo[:n0] == 0] = 0
+            mask = np.zeros(16384, dtype=np.uint8); Z.zsmi_dbg_copyScratch(bc.ctx, 6, mask.ctypes.data_as(ctypes.c_void_p), 16384)
+            mbits = np.unpackbits(mask, bitorder="little")[:n0].astype(bool)
+            if n0 <= 65536: dist_g = dist_lo[:n0].astype(np.uint32)
+            dist_g[~mbits] = 0
             bad = np.nonzero(dist_e != dist_g)[0]
             print(f"   dist mismatches (unit 0): {len(bad)}", bad[:8], dist_e[bad[:8]], dist_g[bad[:8]])
-            seq_e = np.zeros(128 * 256 * 3, dtype=np.uint32); hdr_e = np.zeros(256, dtype=np.uint32)
+            seq_e = np.zeros(128 * 256 * 3, dtype=np.uint32); hdr_e = np.zeros(512, dtype=np.uint32)
             L.zso_debugWalk(seq_e.ctypes.data_as(ctypes.c_void_p), hdr_e.ctypes.data_as(ctypes.c_void_p), blk, n0, 3)
-            hdr_g4 = np.zeros(512, dtype=np.uint32); Z.zsmi_dbg_copyScratch(bc.ctx, 2, hdr_g4.ctypes.data_as(ctypes.c_void_p), 2048); hdr_g = hdr_g4.reshape(128, 4)[:, :2].reshape(-1).copy()
-            seq_g = np.zeros(128 * 256 * 4, dtype=np.uint16); Z.zsmi_dbg_copyScratch(bc.ctx, 1, seq_g.ctypes.data_as(ctypes.c_void_p), 128 * 256 * 8)
-            print("   hdr E", hdr_e[:2 * nr].tolist()); print("   hdr G", hdr_g[:2 * nr].tolist())
-            se = seq_e.reshape(128, 256, 3); sg = seq_g.reshape(128, 256, 4)
+            hdr_g4 = np.zeros(512, dtype=np.uint32); Z.zsmi_dbg_copyScratch(bc.ctx, 2, hdr_g4.ctypes.data_as(ctypes.c_void_p), 2048)
+            hg = hdr_g4.reshape(128, 4)[:, [3, 0, 1, 2]]; he = hdr_e.reshape(128, 4)      # first, nseq, trailing, litSum
+            seq_g = np.zeros(128 * 256 * 2, dtype=np.uint32); Z.zsmi_dbg_copyScratch(bc.ctx, 1, seq_g.ctypes.data_as(ctypes.c_void_p), 128 * 256 * 8)
+            se = seq_e.reshape(128, 256, 3); sg = seq_g.reshape(128, 256, 2)
             for r in range(nr):
-                ns = min(hdr_e[2 * r], hdr_g[2 * r])
-                g3 = np.stack([sg[r, :ns, 0], sg[r, :ns, 1] & 0x1FFF, sg[r, :ns, 2].astype(np.uint32) | ((sg[r, :ns, 1].astype(np.uint32) >> 13) & 1) << 16], axis=1).astype(np.uint32)
-                d = np.nonzero((se[r, :ns] != g3).any(axis=1))[0]
+                if (hg[r] != he[r]).any():
+                    print(f"   range {r}: hdr (first, nseq, trailing, litSum) E={he[r].tolist()} G={hg[r].tolist()}")
+                f, ns = int(he[r, 0]), int(min(he[r, 1], hg[r, 1]))
+                x, y = sg[r, f:f + ns, 0], sg[r, f:f + ns, 1]
+                g3 = np.stack([y >> 16, (x >> 11) & 0x7FFF, (y & 0xFFFF) | (((x >> 26) & 1) << 16)], axis=1)
+                d = np.nonzero((se[r, f:f + ns] != g3).any(axis=1))[0]
                 if len(d):
-                    k = d[0]; print(f"   range {r}: first seq mismatch at {k}: E={se[r, k].tolist()} G={sg[r, k].tolist()}"); break
+                    k = d[0]; print(f"   range {r}: first seq mismatch at {f + k}: E(start,ml,off)={se[r, f + k].tolist()} G={g3[k].tolist()}"); break
             if frame is not None:
                 m = next((i for i in range(min(len(frame), len(ref))) if frame[i] != ref[i]), None)
                 print("   first byte diff at", m, "gpu", frame[max(0,(m or 0)-4):(m or 0)+12].hex(), "E", ref[max(0,(m or 0)-4):(m or 0)+12].hex())

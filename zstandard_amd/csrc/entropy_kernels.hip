@@ -113,6 +113,7 @@ struct K3Lds {                       // literals kernel
     } u;
     uint32_t misc[16];
     uint32_t rngN[ZS_WALK_RANGES], rngCarry[ZS_WALK_RANGES], litBase[ZS_WALK_RANGES];
+    uint8_t  rngFirst[ZS_WALK_RANGES];   // index of a range's first record that counts (after the walk kernel's stitch)
     uint32_t wcount[16]; int16_t wnorm[16]; uint32_t rankStart[16], rankCount[16];   // small tables kept out of scratch memory
 };
 struct SeqLds {                      // sequences kernel.  Kept under 10 KiB: 16 workgroups per CU = one round for 4096 blocks
@@ -128,6 +129,7 @@ struct SeqLds {                      // sequences kernel.  Kept under 10 KiB: 16
     uint32_t tile[208];              // bit-packing tile
     uint32_t misc[16];
     uint32_t rngN[ZS_WALK_RANGES], rngCarry[ZS_WALK_RANGES], rngStart[ZS_WALK_RANGES + 1];
+    uint8_t  rngFirst[ZS_WALK_RANGES];   // index of a range's first record that counts (after the walk kernel's stitch)
 };
 
 // ---------------------------------------------------------------------------------------------
@@ -565,7 +567,7 @@ __device__ __forceinline__ int lastFlagBelow(bool flag)
 //   rngN[r] sequences, rngStart[r] index of its first sequence in block order, rngCarry[r] literals carried into its first
 //   sequence (trailing literals of the ranges since the last one that had a sequence), litBase[r] (optional) index of its
 //   first own literal; returns the literals left after the last sequence of the block and the total literal count.
-__device__ __forceinline__ void loadRangesWave(const ZsRangeHdr *hdr, uint32_t *rngN, uint32_t *rngCarry, uint32_t *rngStart, uint32_t *litBase,
+__device__ __forceinline__ void loadRangesWave(const ZsRangeHdr *hdr, uint32_t *rngN, uint32_t *rngCarry, uint32_t *rngStart, uint32_t *litBase, uint8_t *rngFirst,
                                                uint32_t *lastLits, uint32_t *allLits)
 {
     const uint32_t lane = (uint32_t)zs_lane();
@@ -575,7 +577,7 @@ __device__ __forceinline__ void loadRangesWave(const ZsRangeHdr *hdr, uint32_t *
     const uint32_t P = trIncl - tr;                                     // trailing literals of the ranges before me
     const int j = lastFlagBelow(ns != 0);
     const uint32_t Pj = (uint32_t)__shfl((int)P, max(j, 0));
-    rngN[lane] = ns; if (rngStart) rngStart[lane] = nsIncl - ns; rngCarry[lane] = (j >= 0) ? P - Pj : P;
+    rngN[lane] = ns; rngFirst[lane] = (uint8_t)h.first; if (rngStart) rngStart[lane] = nsIncl - ns; rngCarry[lane] = (j >= 0) ? P - Pj : P;
     if (litBase) litBase[lane] = lsIncl - lsum;
     const uint64_t has = __ballot(ns != 0);
     const uint32_t total = wave_last(trIncl);
@@ -625,7 +627,7 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     }
     if (n < 16) FINISH(0, 0, 0);
 
-    if (wave == 0) loadRangesWave(hdr, L.rngN, L.rngCarry, nullptr, L.litBase, &L.misc[1], &L.misc[2]);
+    if (wave == 0) loadRangesWave(hdr, L.rngN, L.rngCarry, nullptr, L.litBase, L.rngFirst, &L.misc[1], &L.misc[2]);
     #pragma unroll
     for (uint32_t k = 0; k < 8; k++) L.u.hist[k][tid] = 0;
     __syncthreads();
@@ -652,7 +654,7 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
                 rec[g] = make_uint2(0, 0);
                 if (r < ZS_WALK_RANGES) {
                     const uint32_t ns = rangeN(r), k = base + lane;
-                    if (k < ns) rec[g] = *reinterpret_cast<const uint2 *>(seqBase + (size_t)r * ZS_SEQ_PER_RANGE + k);
+                    if (k < ns) rec[g] = *reinterpret_cast<const uint2 *>(seqBase + (size_t)r * ZS_SEQ_PER_RANGE + L.rngFirst[r] + k);
                     base += 64;
                     if (base >= ns) { base = 0; r += 4; while (r < ZS_WALK_RANGES && rangeN(r) == 0) r += 4; }
                 }
@@ -664,11 +666,11 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
                 ll[g] = 0; dstOff[g] = 0; srcPos[g] = 0; w0[g] = 0; w1[g] = 0;
                 if (tr[g] < ZS_WALK_RANGES) {
                     const uint32_t k = tb[g] + lane;
-                    uint32_t l = (k < rangeN(tr[g])) ? (rec[g].x & 0xFFFFu) : 0u;
+                    uint32_t l = (k < rangeN(tr[g])) ? zs_rec_ll(rec[g].x) : 0u;
                     if (k == 0) l += L.rngCarry[tr[g]];
                     if (tb[g] == 0) done = L.litBase[tr[g]] - L.rngCarry[tr[g]];
                     const uint32_t incl = wave_incl_scan(l);
-                    ll[g] = l; dstOff[g] = done + incl - l; srcPos[g] = (rec[g].y >> 16) - l;
+                    ll[g] = l; dstOff[g] = done + incl - l; srcPos[g] = zs_rec_pos(rec[g].y) - l;
                     done += wave_last(incl);
                     // short runs by their own lane (one round of loads), long runs by the whole wavefront
                     if (l && l <= 16) {
@@ -921,7 +923,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
     bool live = false;                                  // this wavefront has a bitstream to write in part 2
     do {
         if (!exists || n < 16) break;
-        loadRangesWave(hdr, L.rngN, L.rngCarry, L.rngStart, nullptr, &L.misc[1], &L.misc[2]);
+        loadRangesWave(hdr, L.rngN, L.rngCarry, L.rngStart, nullptr, L.rngFirst, &L.misc[1], &L.misc[2]);
         for (uint32_t i = lane; i < 192; i += 64) L.count[i] = 0;
         wave_sync();
         nseq = L.rngStart[ZS_WALK_RANGES];
@@ -951,7 +953,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                 #pragma unroll
                 for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
                 kOut = g - L.rngStart[rr]; rrOut = rr;
-                return seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + kOut;
+                return seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + L.rngFirst[rr] + kOut;
             };
             // (a record travels as its two raw words and is taken apart only where it is used: unpacked next to the load, the
             // compiler waits for the load on the spot)
@@ -964,10 +966,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                 const uint2 raw = rawN; ZsSeqRec *rp = rpN; const uint32_t k = kN, rr = rrN;
                 if (g + 64 < nseq) { rpN = locate(g + 64, kN, rrN); rawN = *reinterpret_cast<const uint2 *>(rpN); }
                 uint32_t off = 0, ll = 0, ml = 0;
-                if (in) {                                                    // ZsSeqRec: ll, ml (low word), off, flags (high word)
-                    const uint32_t recMl = raw.x >> 16;
-                    off = (raw.y & 0xFFFFu) | ((recMl >> 13) & 1u) << 16; ll = raw.x & 0xFFFFu; ml = recMl & 0x1FFFu; if (k == 0) ll += rngCarry[rr];
-                }
+                if (in) { off = zs_rec_off(raw.x, raw.y); ll = zs_rec_ll(raw.x); ml = zs_rec_ml(raw.x); if (k == 0) ll += rngCarry[rr]; }
                 uint32_t prev = ZS_DPP(0, off, 0x138, 0xF, true); if (lane == 0) prev = cPrev;      // wave_shr:1        // rep0 before me
                 const bool change = in && !(ll > 0 && off == prev);
                 const int j = lastFlagBelow(change);                                                  // last changing sequence before me
@@ -981,7 +980,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                     uint32_t val;
                     if (ll) { val = (off == prev) ? 1u : (off == a) ? 2u : (off == b) ? 3u : 0u; }
                     else    { val = (off == a) ? 1u : (off == b) ? 2u : 0u; }
-                    rp->ml = (uint16_t)(ml | ((off >> 16) << 13) | (val << 14));
+                    rp->x = (raw.x & 0x07FFFFFFu) | (val << 27);
                     const uint32_t v = val ? val : off + 3;
                     atomicAdd(&L.count[llCodeOf(ll)], 1u);
                     atomicAdd(&L.count[64 + zs_highbit(v)], 1u);
@@ -1083,7 +1082,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
             #pragma unroll
             for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
             const uint32_t k = g - L.rngStart[rr];
-            recN = *reinterpret_cast<const uint2 *>(seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + k);
+            recN = *reinterpret_cast<const uint2 *>(seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + L.rngFirst[rr] + k);
             carryN = (k == 0) ? L.rngCarry[rr] : 0u;
             validN = true;
         }
@@ -1098,11 +1097,10 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
             const uint2 raw = recN; const uint32_t carry = carryN; const bool valid = validN;
             if (remaining > T) fetch(remaining - T);
             uint2 o0 = make_uint2(0, 0), o1 = o0, o2 = o0;
-            if (valid) {                                                     // ZsSeqRec: ll, ml (low word), off, flags (high word)
-                const uint32_t recMl = raw.x >> 16;
-                ll = (raw.x & 0xFFFFu) + carry;
-                ml = recMl & 0x1FFFu; const uint32_t rep = recMl >> 14;
-                val = rep ? rep : ((raw.y & 0xFFFFu) | ((recMl >> 13) & 1u) << 16) + 3;
+            if (valid) {
+                ll = zs_rec_ll(raw.x) + carry;
+                ml = zs_rec_ml(raw.x); const uint32_t rep = zs_rec_rep(raw.x);
+                val = rep ? rep : zs_rec_off(raw.x, raw.y) + 3;
                 llc = llCodeOf(ll); mlc = mlCodeOf(ml - 3); ofc = zs_highbit(val);
                 o0 = make_uint2(L.ct[0].deltaNbBits[llc], (uint32_t)L.ct[0].deltaFindState[llc]);
                 o1 = make_uint2(L.ct[1].deltaNbBits[ofc], (uint32_t)L.ct[1].deltaFindState[ofc]);

@@ -1,6 +1,7 @@
 // LZ stage of the block encoder: candidate search (k_lz_candidates) and greedy walk with
-// look-ahead (k_lz_walk).  The scalar statement of the same algorithm is oracle/zso_encoder.c
-// (findCandidates / walkRange); the two must agree bit for bit.
+// look-ahead, recent-offset candidates and the stitch of the walk ranges (k_lz_walk).  The scalar statement
+// of the same algorithm is oracle/zso_encoder.c (findCandidates / walkRange / the stitch in compressBlock);
+// the two must agree bit for bit.
 //
 // There is no reference code for this stage (the reference has no encoder);
 // what it emits is consumed by entropy_kernels.hip, whose output the reference decoder must accept.
@@ -8,274 +9,135 @@
 #include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
-// k_lz_candidates<NR, WPR> : one workgroup per LZ unit (<= NR ranges of 8 KiB), NR * WPR wavefronts.
-//   <8, 2>  units of <= 64 KiB (one block),  LDS  64 KiB at 2^12 slots, two workgroups per CU
-//   <16, 1> units of <= 128 KiB (two blocks), LDS 128 KiB
-// LDS: NR hash tables of 2^hashLog 16-bit slots: tag (3 hash bits) << 13 | position in the range; 0xFFFF = empty.
-// Positions are taken 64 at a time: all lanes read the table, then all lanes write it (same-slot writes of one
-// instruction: the highest lane stays -- probed on MI355X by tools/probe/lds_order.hip).
-// Phase A (one wavefront per range: table order matters) fills the tables and leaves each position's distance to its
-// own-range predecessor (same slot, same tag) in dist[].  Phase B (after a barrier: every table is final) takes the
-// positions without one, falls back to the nearest earlier range holding the slot with the same tag, checks the 4 bytes
-// of every candidate and writes the match distance: low 16 bits to dist[], bit 16 to distHi (NR == 16 only), and the
-// "has a candidate" bit plane.  Phase B work is dealt in trips of 64 * U positions from a queue in LDS, last trip first:
-// a trip of range r probes r tables, so fixed shares would leave the wavefronts of the low ranges waiting at the end.
-// Trips that lie wholly inside the hashable positions run without bound checks; the one trip that may not (the last
-// of the unit) has its own guarded code.
-// Scalar statement: findCandidates in oracle/zso_encoder.c.
-// HBM/L2 traffic per unit: reads n (twice, second time from cache) + n gathers; writes 2n (dist twice).
-// What bounds it on MI355X (profiles/r1_h_*): the vector-memory path.  TA_TA_BUSY 95 % of the kernel's cycles, three
-// quarters of it the verification gathers (64 lanes = 64 cache lines an instruction); vector ALU issue 82 %.
+// k_lz_candidates<TLOG, NT> : one workgroup of NT wavefronts per LZ unit; wavefront t owns table t in LDS.
+//   table 0 "short": hash of the 5 bytes at p, table 1 "long" (NT == 2: level >= 3): hash of the 8 bytes at p;
+//   2^TLOG 32-bit slots each (TLOG 13: units <= 64 KiB, 64 KiB of LDS for both; TLOG 14: units <= 128 KiB, 128 KiB).
+//   slot = tag (the 15 hash bits below the index bits) << 17 | position; 0xFFFFFFFF = empty.
+// A wavefront takes 64 consecutive positions per LDS exchange (ds_wrxchg_rtn_b32): every lane leaves its entry and gets the
+// slot's previous content back.  Lanes of one instruction that hit the same slot are served in ascending lane order
+// (tools/probe/lds_xchg.hip: 0 violations in 2e9 same-slot pairs on MI355X), and a wavefront's LDS instructions execute in
+// order: so position p receives exactly the last earlier position inserted with the same slot -- the sequential loop of
+// findCandidates in oracle/zso_encoder.c.  Same tag -> distance p - that position; the long table's distance wins.
+// Candidates are not compared with the source bytes here (index + tag = 28 hash bits agree; the walk measures every match).
+// The two wavefronts work in groups of G steps: each writes its G x 64 distances to an LDS exchange buffer, a barrier, then
+// each merges and stores half of the group:  dist[] (low 16 bits), distHi (bit 16, big units), distMask ("has a candidate").
+// HBM traffic per unit: reads n (both wavefronts, the second from cache), writes 2 n + n / 8 (+ n / 8).
 // ---------------------------------------------------------------------------------------------
-#define ZS_TAG_BITS 3
-#ifndef ZS_CAND_WPR
-#define ZS_CAND_WPR 2              // wavefronts per range of the small-unit candidates kernel (8 ranges): 1 -> 512 threads, 2 -> 1024
+#ifndef ZS_CAND_G
+#define ZS_CAND_G 8                // steps of 64 positions per group (loads in flight per lane)
 #endif
-#define ZS_SLOT_EMPTY 0xFFFFu
-#define ZS_CAND_LDS(NR) (((size_t)(NR) << ZS_HASH_LOG) * 2 + 16)      // the tables + the trip queue
-__device__ __forceinline__ uint32_t zs_slot_entry(uint32_t hh, int hashLog, uint32_t p)
-{ return (((hh >> (32 - hashLog - ZS_TAG_BITS)) & ((1u << ZS_TAG_BITS) - 1)) << ZS_RANGE_LOG) | (p & (ZS_RANGE_SIZE - 1)); }
+#define ZS_CAND_LDS(TLOG, NT) ((size_t)(NT) * (4u << (TLOG)) + ((NT) > 1 ? 2u * (NT) * ZS_CAND_G * 64u * 4u : 0u))
+#define ZS_SLOT_EMPTY 0xFFFFFFFFu
+__device__ __forceinline__ uint32_t zs_hash_short(uint32_t lo, uint32_t hi) { return lo * 0x9E3779B1u + (hi & 0xFFu) * 0x9E3779u; }
+__device__ __forceinline__ uint32_t zs_hash_long(uint32_t lo, uint32_t hi) { return (hi ^ __builtin_amdgcn_alignbit(lo * 0x9E3779B1u, lo * 0x9E3779B1u, 17)) * 0x85EBCA77u; }   // rotl 15
 
-// measured on MI355X (4096 x 64 KiB, ms per launch): WPR 1: U 8 1.13, U 4 0.96, U 2 1.39; WPR 2 with 2 workgroups per CU
-// (<= 64 VGPRs): U 8 1.02, U 4 0.91, U 3 0.90, U 2 1.12, U 1 1.51
-#ifndef ZS_CAND_U
-#define ZS_CAND_U 4                // steps of 64 positions per trip (loads in flight per lane)
-#endif
-#ifndef ZS_CAND_U_BIG
-#define ZS_CAND_U_BIG 8
-#endif
-#ifndef ZS_CAND_MINWG
-#define ZS_CAND_MINWG 2            // small-unit kernel: 64 KiB of LDS, so two workgroups share a CU if the registers allow
-#endif
-template <int NR, int WPR>
-__global__ void __launch_bounds__(NR * WPR * 64, (NR == 8 ? ZS_CAND_MINWG : 1))
+template <int TLOG, int NT>
+__global__ void __launch_bounds__(64 * NT)
 k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units, uint32_t block0,
-                uint16_t *__restrict__ distAll, uint8_t *__restrict__ distHiAll, uint8_t *__restrict__ distMaskAll, int hashLogArg)
+                uint16_t *__restrict__ distAll, uint8_t *__restrict__ distHiAll, uint8_t *__restrict__ distMaskAll)
 {
-    extern __shared__ __attribute__((aligned(16))) uint16_t tables[];
-    constexpr int hashLog = ZS_HASH_LOG;                              // fixed: table strides become instruction immediates
-    if (hashLogArg != hashLog) return;                                // the host passes ZS_HASH_LOG (zsmi_api.hip)
-    uint32_t *queue = reinterpret_cast<uint32_t *>(tables + ((size_t)NR << hashLog));      // next phase-B trip
+    extern __shared__ __attribute__((aligned(16))) uint32_t candLds[];
+    constexpr bool BIG = TLOG > ZS_TABLE_LOG_SMALL;
+    constexpr uint32_t G = ZS_CAND_G, GP = G * 64u, H = (NT > 1) ? G / 2 : G;     // H: steps of a group a wavefront stores
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    uint32_t *T = candLds + ((size_t)wave << TLOG);
+    uint32_t *xbuf = candLds + ((size_t)NT << TLOG);                  // [group parity][table][GP]
     const ZsUnitDesc ud = units[blockIdx.x];
     const uint8_t *s = src + ud.srcOff;
     const uint32_t n = ud.size;
-    uint16_t *dist = distAll + (size_t)(ud.firstBlock - block0) * ZS_BLOCK_MAX;
-    uint8_t *distHi = distHiAll + (size_t)(ud.firstBlock - block0) * (ZS_BLOCK_MAX / 8);
-    uint8_t *distMask = distMaskAll + (size_t)(ud.firstBlock - block0) * (ZS_BLOCK_MAX / 8);     // bit p: position p has a candidate
+    const size_t slot = (size_t)(ud.firstBlock - block0);
+    uint16_t *dist = distAll + slot * ZS_BLOCK_MAX;
+    uint8_t *distHi = distHiAll + slot * (ZS_BLOCK_MAX / 8);
+    uint8_t *distMask = distMaskAll + slot * (ZS_BLOCK_MAX / 8);     // bit p: position p has a candidate
 
-#ifdef ZS_K1_PROFILE          // development aid (tools/k1_profile.py): s_memtime at the phase boundaries, left in the unit's distHi plane
-    uint64_t profT[4]; profT[0] = __builtin_amdgcn_s_memtime();
-#endif
-    {   // clear the tables
-        const uint32_t words = ((uint32_t)NR << hashLog) >> 1;      // 32-bit words
-        uint32_t *t32 = reinterpret_cast<uint32_t *>(tables);
-        for (uint32_t i = threadIdx.x; i < words; i += blockDim.x) t32[i] = 0xFFFFFFFFu;
-        if (threadIdx.x == 0) *queue = 0;
+    {   // each wavefront clears its own table (its LDS instructions execute in order: no barrier needed before it uses it)
+        uint4 *t4 = reinterpret_cast<uint4 *>(T);
+        const uint4 e = make_uint4(ZS_SLOT_EMPTY, ZS_SLOT_EMPTY, ZS_SLOT_EMPTY, ZS_SLOT_EMPTY);
+        #pragma unroll 8
+        for (uint32_t i = lane; i < (1u << TLOG) / 4; i += 64) t4[i] = e;
     }
-    __syncthreads();
+    const uint32_t hashable = (n >= 8) ? n - 7 : 0;                   // positions [0, hashable) have 8 bytes
+    const uint32_t nGroups = (hashable + GP - 1) / GP;
 
-    // wavefront-uniform values are made scalars (readfirstlane): range bounds, trip bases and the loop control live in SGPRs
-    const uint32_t waveAll = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
-    const uint32_t hashable = (n >= 4) ? n - 3 : 0;                   // positions [0, hashable) have 4 bytes
-    // U steps of 64 positions per trip.  The loads of trip t+1 are issued before trip t is worked on (registers
-    // double-buffered), so the table work of a trip runs under the memory latency of the next one.
-    constexpr uint32_t U = (NR > 8) ? ZS_CAND_U_BIG : ZS_CAND_U;      // the 128 KiB shape runs one workgroup per CU: more loads in flight per wavefront
-    constexpr uint32_t TRIP = 64 * U;
-    using Whole = std::true_type; using Guarded = std::false_type;
-
-#ifdef ZS_K1_PROFILE
-    profT[1] = __builtin_amdgcn_s_memtime();
-#endif
-    // ---- phase A: wavefront r fills table r in position order
-    if (waveAll < NR) {
-        const uint32_t start = waveAll << ZS_RANGE_LOG, end = min(start + ZS_RANGE_SIZE, hashable);
-        uint16_t *T = tables + ((size_t)waveAll << hashLog);
-        auto load = [&](auto tag, uint32_t base, uint32_t (&v)[U]) {
-            constexpr bool WHOLE = decltype(tag)::value;
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) { const uint32_t p = base + u * 64 + lane; v[u] = (WHOLE || p < end) ? zs_load32(s + p) : 0u; }
-        };
-        auto insert = [&](auto tag, uint32_t base, const uint32_t (&v)[U]) {
-            constexpr bool WHOLE = decltype(tag)::value;
-            // all U reads and writes of the trip go to the LDS back to back (it keeps their order); the distances are worked
-            // out afterwards, so the trip pays the LDS latency once
-            uint32_t own[U], mine[U];
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t p = base + u * 64 + lane;
-                if (WHOLE || p < end) {
-                    const uint32_t hh = v[u] * 2654435761u;
-                    const uint32_t h = __builtin_amdgcn_ubfe(hh, 32 - hashLog, hashLog);
-                    mine[u] = zs_slot_entry(hh, hashLog, p);
-                    own[u] = T[h];
-                    T[h] = (uint16_t)mine[u];
-                }
-            }
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t p = base + u * 64 + lane;
-                if (WHOLE || p < end) {
-                    // same tag: the distance to the slot's position; an empty slot reads as (tag 7, position 8191), which no
-                    // position of the range lies behind: its "distance" is <= 0 and becomes 0 = no predecessor
-                    const int d = (int)mine[u] - (int)own[u];
-                    dist[p] = (uint16_t)(((own[u] ^ mine[u]) < ZS_RANGE_SIZE) ? max(d, 0) : 0);
-                }
-            }
-        };
-        if (start < end) {
-            uint32_t v[U], vn[U];
-            if (start + TRIP <= end) load(Whole{}, start, v); else load(Guarded{}, start, v);
-            // the first trip's values are waited for here, in front of the loop: left to the loop body, the wait lands behind the
-            // next trip's loads and takes them along (every trip would then sit out a full memory round trip)
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) asm volatile("" : "+v"(v[u]));
-            uint32_t base = start;
-            for (; base + TRIP <= end; base += TRIP) {
-                const uint32_t nbase = base + TRIP;
-                if (nbase + TRIP <= end) load(Whole{}, nbase, vn); else if (nbase < end) load(Guarded{}, nbase, vn);
-                insert(Whole{}, base, v);
-                #pragma unroll
-                for (uint32_t u = 0; u < U; u++) v[u] = vn[u];
-            }
-            if (base < end) insert(Guarded{}, base, v);
+    auto load = [&](uint32_t base, uint64_t (&v)[G]) {
+        #pragma unroll
+        for (uint32_t u = 0; u < G; u++) { const uint32_t p = base + u * 64 + lane; v[u] = (p < hashable) ? zs_load64(s + p) : 0ull; }
+    };
+    uint64_t v[G], vn[G];
+    if (nGroups) load(0, v);
+    #pragma unroll
+    for (uint32_t u = 0; u < G; u++) asm volatile("" : "+v"(v[u]));    // the first group is waited for here, not behind the next group's loads
+    for (uint32_t g = 0; g < nGroups; g++) {
+        const uint32_t base = g * GP;
+        if (g + 1 < nGroups) load(base + GP, vn);
+        uint32_t entry[G], old[G], d[G];
+        #pragma unroll
+        for (uint32_t u = 0; u < G; u++) {                               // the G exchanges go to the LDS back to back
+            const uint32_t p = base + u * 64 + lane;
+            const uint32_t lo = (uint32_t)v[u], hi = (uint32_t)(v[u] >> 32);
+            const uint32_t h = (wave == 0) ? zs_hash_short(lo, hi) : zs_hash_long(lo, hi);
+            entry[u] = ((h << TLOG) & 0xFFFE0000u) | p;
+            old[u] = ZS_SLOT_EMPTY;
+            if (p < hashable) old[u] = atomicExch(&T[h >> (32 - TLOG)], entry[u]);
         }
+        #pragma unroll
+        for (uint32_t u = 0; u < G; u++) {
+            const uint32_t p = base + u * 64 + lane;
+            const int dd = (int)p - (int)(old[u] & 0x1FFFFu);            // an empty slot reads as position 131071: never behind p
+            d[u] = (((old[u] ^ entry[u]) >> 17) == 0 && dd > 0) ? (uint32_t)dd : 0u;
+        }
+        if (NT > 1) {
+            uint32_t *xb = xbuf + (size_t)(g & 1u) * NT * GP;
+            #pragma unroll
+            for (uint32_t u = 0; u < G; u++) xb[wave * GP + u * 64 + lane] = d[u];
+            __syncthreads();
+            #pragma unroll
+            for (uint32_t uu = 0; uu < H; uu++) {
+                const uint32_t u = wave * H + uu;
+                const uint32_t dS = xb[u * 64 + lane], dL = xb[GP + u * 64 + lane];
+                d[uu] = dL ? dL : dS;
+            }
+        }
+        // candidate bits (and bit 16 of the distances) of this wavefront's H steps: lane uu keeps step uu's word,
+        // so each plane takes one store of H * 8 contiguous bytes
+        const uint32_t sbase = base + ((NT > 1) ? wave * H * 64u : 0u);
+        uint64_t pmMine = 0, hiMine = 0;
+        #pragma unroll
+        for (uint32_t uu = 0; uu < H; uu++) {
+            const uint32_t p = sbase + uu * 64 + lane;
+            const uint32_t dm = d[uu];
+            if (BIG) { const uint64_t hi = __ballot((dm >> 16) != 0); if (lane == uu) hiMine = hi; }
+            const uint64_t pm = __ballot(dm != 0);
+            if (lane == uu) pmMine = pm;
+            if (p < hashable) dist[p] = (uint16_t)dm;
+        }
+        if (lane < H) {
+            *reinterpret_cast<uint64_t *>(distMask + ((sbase + lane * 64) >> 3)) = pmMine;
+            if (BIG) *reinterpret_cast<uint64_t *>(distHi + ((sbase + lane * 64) >> 3)) = hiMine;
+        }
+        #pragma unroll
+        for (uint32_t u = 0; u < G; u++) v[u] = vn[u];
     }
-#ifdef ZS_K1_PROFILE
-    profT[2] = __builtin_amdgcn_s_memtime();
-#endif
-    __syncthreads();
-#ifdef ZS_K1_PROFILE
-    profT[3] = __builtin_amdgcn_s_memtime();
-#endif
-
-    // ---- phase B
-    {
-        // (v, own-range distance) of a trip are loaded one trip ahead; the trip's verification gathers are issued, then the
-        // previous trip's gathers are compared and stored.  d = distance to the candidate, 0 = none.
-        auto load = [&](auto tag, uint32_t base, uint32_t (&v)[U], uint32_t (&d)[U]) {
-            constexpr bool WHOLE = decltype(tag)::value;
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t p = base + u * 64 + lane; const bool in = WHOLE || p < hashable;
-                v[u] = in ? zs_load32(s + p) : 0u; d[u] = in ? (uint32_t)dist[p] : 0u;
-            }
-        };
-        auto probe = [&](auto tag, uint32_t base, const uint32_t (&v)[U], uint32_t (&d)[U]) {
-            constexpr bool WHOLE = decltype(tag)::value;
-            uint32_t rangeV;                                          // the trip's range, as a per-lane value: the table reads below
-            asm volatile("v_mov_b32 %0, %1" : "=v"(rangeV) : "s"(base >> ZS_RANGE_LOG));      // are masked, not branched around
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t p = base + u * 64 + lane;
-                if ((WHOLE || p < hashable) && !d[u]) {
-                    // the earlier ranges are read at once (independent LDS reads, range q at byte offset q << (hashLog + 1): an
-                    // immediate of the instruction); the nearest one holding the slot with this tag wins
-                    const uint32_t hh = v[u] * 2654435761u;
-                    const uint32_t h = __builtin_amdgcn_ubfe(hh, 32 - hashLog, hashLog);
-                    const uint32_t tagv = zs_slot_entry(hh, hashLog, 0);
-                    // slot ^ tagv < 8192 <=> same tag, and then it is the position in the range.  The empty slot 0xFFFF would pass
-                    // as (tag 7, position 8191): with tag 7 the limit drops to 8191.  Ascending ranges, each hit replacing the last;
-                    // "none" is the position itself (distance 0).  (Ending the chain at the trip's own range count through scalar
-                    // branches halves its instructions and buys nothing: the kernel is bound by the vector-memory path, TA busy 95 %.)
-                    const uint32_t limit = ZS_RANGE_SIZE - (tagv == (7u << ZS_RANGE_LOG) ? 1u : 0u);
-                    const uint16_t *Th = tables + h;
-                    uint32_t c[NR - 1];
-                    #pragma unroll
-                    for (uint32_t q = 0; q < NR - 1; q++) c[q] = (q < rangeV) ? (uint32_t)Th[(size_t)q << hashLog] : ZS_SLOT_EMPTY;
-                    uint32_t best = p;
-                    #pragma unroll
-                    for (uint32_t q = 0; q < NR - 1; q++) {
-                        const uint32_t x = c[q] ^ tagv;
-                        best = (x < limit) ? x + (q << ZS_RANGE_LOG) : best;
-                    }
-                    d[u] = p - best;
-                }
-            }
-        };
-        auto gather = [&](uint32_t base, const uint32_t (&d)[U], uint32_t (&cv)[U]) {
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) cv[u] = d[u] ? zs_load32(s + (base + u * 64 + lane - d[u])) : 0u;
-        };
-        auto finish = [&](auto tag, uint32_t fbase, const uint32_t (&pv)[U], const uint32_t (&pd)[U], const uint32_t (&pcv)[U]) {
-            constexpr bool WHOLE = decltype(tag)::value;
-            // candidate bits (and bit 16 of the distances) of the trip's U groups of 64 positions: lane u keeps group u's word,
-            // so each plane takes one store of U * 8 contiguous bytes.  Without a candidate the gathered word is 0 and so is d.
-            uint64_t pmMine = 0, hiMine = 0;
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) {
-                const uint32_t p = fbase + u * 64 + lane;
-                uint32_t d = (pcv[u] == pv[u]) ? pd[u] : 0u;
-                if (NR > 8) {
-                    if (d == 65536u) d = 0;
-                    const uint64_t hi = __ballot((d >> 16) != 0);
-                    if (lane == u) hiMine = hi;
-                }
-                const uint64_t pm = __ballot(d != 0);
-                if (lane == u) pmMine = pm;
-                if (WHOLE || p < hashable) dist[p] = (uint16_t)d;
-            }
-            if (lane < U && (WHOLE || fbase + lane * 64 < hashable)) {
-                *reinterpret_cast<uint64_t *>(distMask + ((fbase + lane * 64) >> 3)) = pmMine;
-                if (NR > 8) *reinterpret_cast<uint64_t *>(distHi + ((fbase + lane * 64) >> 3)) = hiMine;
-            }
-        };
-        auto grab = [&]() -> uint32_t {
-            uint32_t i = 0;
-            if (lane == 0) i = atomicAdd(queue, 1u);
-            return __builtin_amdgcn_readfirstlane(i);
-        };
-
-        const uint32_t nWhole = hashable / TRIP;                      // trips [t * TRIP, (t + 1) * TRIP) wholly hashable
-        uint32_t v[U], d[U], vn[U], dn[U], pv[U], pd[U], pcv[U], cv[U];
-        if (waveAll == NR * WPR - 1 && nWhole * TRIP < hashable) {    // the unit's last, partial trip: on its own, not pipelined
-            const uint32_t base = nWhole * TRIP;
-            load(Guarded{}, base, v, d);
-            probe(Guarded{}, base, v, d);
-            gather(base, d, cv);
-            finish(Guarded{}, base, v, d, cv);
-        }
-        uint32_t cur = grab(), pbase = 0; bool havePrev = false;
-        if (cur < nWhole) {
-            load(Whole{}, (nWhole - 1 - cur) * TRIP, v, d);
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) asm volatile("" : "+v"(v[u]), "+v"(d[u]));      // as in phase A: wait in front of the loop
-        }
-        while (cur < nWhole) {
-            const uint32_t base = (nWhole - 1 - cur) * TRIP;
-            const uint32_t nxt = grab();
-            if (nxt < nWhole) load(Whole{}, (nWhole - 1 - nxt) * TRIP, vn, dn);
-            probe(Whole{}, base, v, d);
-            gather(base, d, cv);
-            if (havePrev) finish(Whole{}, pbase, pv, pd, pcv);
-            #pragma unroll
-            for (uint32_t u = 0; u < U; u++) { pv[u] = v[u]; pd[u] = d[u]; pcv[u] = cv[u]; v[u] = vn[u]; d[u] = dn[u]; }
-            pbase = base; havePrev = true; cur = nxt;
-        }
-        if (havePrev) finish(Whole{}, pbase, pv, pd, pcv);
-    }
-#ifdef ZS_K1_PROFILE
-    if (NR == 8 && lane == 0) {           // per wavefront: start, phase A begin / end, phase B begin / end
-        uint64_t *o = reinterpret_cast<uint64_t *>(distHi) + waveAll * 8;
-        o[0] = profT[0]; o[1] = profT[1]; o[2] = profT[2]; o[3] = profT[3]; o[4] = __builtin_amdgcn_s_memtime();
-    }
-#endif
-    // positions without 4 bytes left: no candidate
-    if (waveAll == 0) for (uint32_t p = hashable + lane; p < n; p += 64) dist[p] = 0;
 }
 
 // ---------------------------------------------------------------------------------------------
 // k_lz_walk<NW> : one workgroup of NW / 8 wavefronts per LZ unit; NW = 64 (unit <= 64 KiB) or 128 (<= 128 KiB).
 // The unit's source bytes are staged in LDS once (NW KiB + pads), so every compare of the walk is an LDS read and
 // the unit is fetched from HBM once.  The lanes are NW independent walkers of 8 lanes; walker g walks the walk
-// range g (1 KiB).  A walker step: its 8 lanes read dist[ip .. ip+64) (8 positions each, global, coalesced); the
-// first LOOK positions holding a candidate go one per lane; a lane compares 16 bytes forward (the score counts
-// ZS_FCAP of them) and 8 bytes backward (into the pending literals) for its candidate, scores it; the
-// best one of the walker becomes a sequence (extended by the walker's 8 lanes if it hit the 16-byte cap).
-// Scalar statement: walkRange in oracle/zso_encoder.c.
+// range g (1 KiB).  A walker step looks at the 64 positions from ip: the candidate bits of stage 1 (LDS copy of the
+// bit plane), plus, for the first ZS_REPWIN positions, the positions where one of the walker's two recent offsets repeats
+// 4 bytes (lane sub tries ip + sub and ip + sub + 8).  The first LOOK positions holding a candidate go one per lane; a lane
+// takes the recent offset or fetches the stage-1 distance (global), compares 16 bytes forward (the score counts ZS_FCAP of
+// them) and 8 bytes backward (into the pending literals) and scores; the best one of the walker becomes a sequence
+// (extended by the walker's 8 lanes if it hit the 16-byte cap).  A match may run past the range end, ZS_CROSS_MAX bytes at most.
+// After a barrier one lane per range stitches (compressBlock in oracle/zso_encoder.c): reach = running maximum of the
+// ranges' last match ends; a range drops the records an earlier range's match covers and cuts the front of one that
+// straddles; its header gets first / nseq / litSum / trailing for its territory [max(start, reach before), max(end, reach)).
+// Scalar statement: walkRange + the stitch in oracle/zso_encoder.c.
 // ---------------------------------------------------------------------------------------------
 #define ZS_WALK_FRONT 16u          // LDS bytes in front of the unit (backward reads near position 0)
 #define ZS_WALK_TAIL  144u         // zero bytes behind the unit (forward reads near the end)
-#define ZS_WALK_LDS(CAPB) (ZS_WALK_FRONT + (CAPB) + ZS_WALK_TAIL + (CAPB) / 8 + 16)   // source + candidate bit plane
+#define ZS_WALK_LDS(CAPB) (ZS_WALK_FRONT + (CAPB) + ZS_WALK_TAIL + (CAPB) / 8 + 16 + ((CAPB) >> ZS_WALK_LOG) * 16)   // source + candidate bit plane + per-range results
 
 // K dwords of the LDS copy starting at any byte offset, fetched as K + 1 aligned dwords and shifted into place
 // (an unaligned ds_read_b64 / b128 costs the LDS several passes: SQ_LDS_UNALIGNED_STALL was 80 % of its busy time)
@@ -291,14 +153,21 @@ __device__ __forceinline__ void lds_span(const uint8_t *ldsBase, uint32_t byteOf
     for (int k = 0; k < K; k++) out[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
 }
 __device__ __forceinline__ uint64_t zs_u64(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
+// the 4 bytes at byteOff and the 4 bytes at byteOff + 8 of the LDS copy
+__device__ __forceinline__ void lds_two(const uint8_t *ldsBase, uint32_t byteOff, uint32_t &a, uint32_t &b)
+{
+    const uint32_t *d = reinterpret_cast<const uint32_t *>(ldsBase + (byteOff & ~3u));
+    const uint32_t w0 = d[0], w1 = d[1], w2 = d[2], w3 = d[3], sh = byteOff & 3u;
+    a = __builtin_amdgcn_alignbyte(w1, w0, sh); b = __builtin_amdgcn_alignbyte(w3, w2, sh);
+}
 
-template <int NW, int WLOG>
+template <int NW>
 __global__ void __launch_bounds__(NW * 8)
 k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units, uint32_t block0,
           const uint16_t *__restrict__ distAll, const uint8_t *__restrict__ distHiAll, const uint8_t *__restrict__ distMaskAll,
           ZsSeqRec *__restrict__ seqAll, ZsRangeHdr *__restrict__ hdrAll, int look)
 {
-    constexpr uint32_t WSIZE = 1u << WLOG;                                        // bytes per walk range
+    constexpr uint32_t WLOG = ZS_WALK_LOG, WSIZE = 1u << WLOG;                     // bytes per walk range
     constexpr uint32_t CAP = NW * WSIZE;                                          // unit capacity in bytes
     constexpr bool BIG = CAP > ZS_BLOCK_MAX;
     extern __shared__ __attribute__((aligned(16))) uint8_t walkLds[];
@@ -312,6 +181,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
     const uint8_t *distHi = distHiAll + (size_t)slot * (ZS_BLOCK_MAX / 8);
     const uint64_t *distMask = reinterpret_cast<const uint64_t *>(distMaskAll + (size_t)slot * (ZS_BLOCK_MAX / 8));
     uint64_t *lm = reinterpret_cast<uint64_t *>(walkLds + ZS_WALK_FRONT + CAP + ZS_WALK_TAIL);     // lm: bit p set = position p has a candidate
+    uint4 *res = reinterpret_cast<uint4 *>(walkLds + ZS_WALK_FRONT + CAP + ZS_WALK_TAIL + CAP / 8 + 16);   // per range: nseq, last match end, sum of match lengths
     const uint32_t grp = lane >> 3, sub = lane & 7u;
     const uint32_t walker = wave * 8 + grp;
     ZsSeqRec *seqs = seqAll + (size_t)slot * (ZS_BLOCK_MAX / 4) + (size_t)walker * (WSIZE / 4);
@@ -346,9 +216,10 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
             if (i + 16 <= CAP + ZS_WALK_TAIL) *reinterpret_cast<uint4 *>(ls + i) = w;
         }
     }
+    const uint32_t hashable = (n >= 8) ? n - 7 : 0;
     // candidate bits of the positions that can start a match; the word behind them reads as zero
     {
-        const uint32_t hashableAll = (n >= 4) ? n - 3 : 0, words = (hashableAll + 63) >> 6;
+        const uint32_t words = (hashable + 63) >> 6;
         for (uint32_t i = tid; i <= words; i += NW * 8) lm[i] = (i < words) ? distMask[i] : 0ull;
     }
     __syncthreads();
@@ -356,24 +227,42 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
     const uint32_t start = walker << WLOG;
     const uint32_t blockStart = start & ~(ZS_BLOCK_MAX - 1);                     // the walker's block inside the unit
     const uint32_t blockN = (blockStart < n) ? min(n - blockStart, ZS_BLOCK_MAX) : 0u;
+    const uint32_t blockEnd = blockStart + blockN;
     const bool alive = (start < n) && (blockN >= 16);
     const uint32_t end = min(start + WSIZE, n);
-    const uint32_t hashable = (n >= 4) ? n - 3 : 0;
+    const uint32_t limit = min(end + ZS_CROSS_MAX, blockEnd);                     // matches end at or before this
     const uint32_t scanEnd = alive ? min(end, hashable) : 0;
 
-    uint32_t ip = start, anchor = start, nseq = 0, litSum = 0;
+    uint32_t ip = start, anchor = start, nseq = 0, mlSum = 0, rep0 = 0, rep1 = 0;
     for (;;) {
         const bool run = ip < scanEnd;
         if (!__any(run)) break;
         const uint32_t wend = min(ip + ZS_WINDOW, scanEnd);
-        // ---- window: candidate bits of [ip, ip + 64) from LDS (the same for the walker's 8 lanes); lane sub takes the
-        //      sub-th candidate and fetches its distance ----
+        // ---- recent offsets: lane sub tries positions ip + sub and ip + sub + 8 ----
+        uint32_t rm0 = 0, rm1 = 0;                                               // bit i: rep0 / rep1 repeats 4 bytes at ip + i
+        {
+            const uint32_t q = ip + sub;
+            const bool t0 = run && rep0 != 0, t1 = run && rep1 != 0;
+            uint32_t a0, a8, b0, b8, c0, c8;
+            lds_two(walkLds, ZS_WALK_FRONT + q, a0, a8);
+            lds_two(walkLds, ZS_WALK_FRONT + ((t0 && q >= rep0) ? q - rep0 : q), b0, b8);
+            lds_two(walkLds, ZS_WALK_FRONT + ((t1 && q >= rep1) ? q - rep1 : q), c0, c8);
+            const bool in0 = q < wend && q + 4 <= limit, in8 = q + 8 < wend && q + 12 <= limit;
+            const uint64_t m00 = __ballot(t0 && in0 && q >= rep0 && a0 == b0), m08 = __ballot(t0 && in8 && q + 8 >= rep0 && a8 == b8);
+            const uint64_t m10 = __ballot(t1 && in0 && q >= rep1 && a0 == c0), m18 = __ballot(t1 && in8 && q + 8 >= rep1 && a8 == c8);
+            const uint32_t sh = 8u * grp;
+            rm0 = ((uint32_t)(m00 >> sh) & 0xFFu) | (((uint32_t)(m08 >> sh) & 0xFFu) << 8);
+            rm1 = ((uint32_t)(m10 >> sh) & 0xFFu) | (((uint32_t)(m18 >> sh) & 0xFFu) << 8);
+        }
+        // ---- window: candidate bits of [ip, ip + 64) from LDS (the same for the walker's 8 lanes) or'ed with the recent-offset
+        //      bits; lane sub takes the sub-th candidate position ----
         uint64_t m64 = 0;
         if (run) {
             const uint32_t wi = ip >> 6, sh = ip & 63u, wlen = wend - ip;
             const uint64_t lo = lm[wi], hi = lm[wi + 1];
             m64 = (lo >> sh) | ((hi << 1) << (63u - sh));
             if (wlen < 64u) m64 &= (1ull << wlen) - 1ull;
+            m64 |= (uint64_t)(rm0 | rm1);
         }
         const uint32_t mlo = (uint32_t)m64, mhi = (uint32_t)(m64 >> 32);
         const uint32_t clo = (uint32_t)__popc(mlo);
@@ -389,9 +278,14 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
             { const uint32_t t = mm & (mm - 1); mm = (skip & 1u) ? t : mm; }
             idx = mm ? (uint32_t)__builtin_ctz(mm) + (upper ? 32u : 0u) : 0u;
         }
-        uint32_t off = active ? (uint32_t)dist[ip + idx] : 0u;
-        if (BIG) { if (active) off |= (((uint32_t)distHi[(ip + idx) >> 3] >> ((ip + idx) & 7u)) & 1u) << 16; }
         const uint32_t q = ip + idx;
+        const bool isR0 = active && idx < 16u && ((rm0 >> (idx & 15u)) & 1u) != 0, isR1 = active && !isR0 && idx < 16u && ((rm1 >> (idx & 15u)) & 1u) != 0;
+        const bool isRep = isR0 || isR1;
+        uint32_t off = isR0 ? rep0 : (isR1 ? rep1 : 0u);
+        if (active && !isRep) {
+            off = (uint32_t)dist[q];
+            if (BIG) off |= (((uint32_t)distHi[q >> 3] >> (q & 7u)) & 1u) << 16;
+        }
         // ---- compare from LDS: 16 bytes forward, 8 bytes backward, both sides ----
         uint32_t fwd = 0, back = 0;
         int key = 0;
@@ -400,52 +294,38 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
             lds_span<6>(walkLds, ZS_WALK_FRONT + q - 8, a);
             lds_span<6>(walkLds, ZS_WALK_FRONT + q - off - 8, b);
             const uint64_t xb = zs_u64(a[0] ^ b[0], a[1] ^ b[1]), x0 = zs_u64(a[2] ^ b[2], a[3] ^ b[3]), x1 = zs_u64(a[4] ^ b[4], a[5] ^ b[5]);
-            const uint32_t cap = min(end - q, ZS_LCAP);
+            const uint32_t cap = min(limit - q, ZS_LCAP);
             const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
             const uint32_t n1 = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u;
             fwd = min((n0 < 8u) ? n0 : 8u + n1, cap);
             const uint32_t maxBack = min(min(q - anchor, q - off), ZS_BCAP);
             back = min(xb ? ((uint32_t)__builtin_clzll(xb) >> 3) : 8u, maxBack);
-            if (fwd >= ZS_MINMATCH) {
-                const int gain = (int)(min(fwd, ZS_FCAP) + back) * 4 - (int)zs_highbit(off + 1) - 4 * ((int)(q - back) - (int)ip) - (int)(q - ip);
+            if (fwd >= (isRep ? ZS_REPMIN : ZS_MINMATCH)) {
+                const int gain = (int)(min(fwd, ZS_FCAP) + back) * 4 - (isRep ? 0 : (int)zs_highbit(off + 1)) - 4 * ((int)(q - back) - (int)ip) - (int)(q - ip);
                 key = ((gain + 2048) << 3) | (int)(7u - sub);
             }
         }
         // best candidate of the walker's 8 lanes, by data-parallel-primitive moves (xor 1, xor 2 inside a quad, then the mirrored
-        // lane of the other quad).  64 KiB units: a max over 64-bit words -- high word key << 17 | distance (keys differ between
-        // lanes, so the key decides), low word (q - ip, fwd, back) -- leaves every lane with the winner's words and no LDS
-        // round trip (walk 0.857 -> 0.833 ms).  128 KiB units (one workgroup per CU, issue-bound): a max over the keys and two
-        // ds_bpermute reads of the winner's words is the shorter instruction sequence (1.00 vs 1.04 ms).
-        uint32_t whi = ((uint32_t)key << 17) | off, wlo = idx | (fwd << 8) | (back << 16);
-        int best; uint32_t packed, boff;
-        if (BIG) {
-            best = key;
-            best = max(best, __builtin_amdgcn_update_dpp(0, best, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
-            best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
-            best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x141, 0xF, 0xF, false));    // row_half_mirror: lane i <- lane 7 - i
-            const uint32_t bl = (lane & ~7u) + (7u - (uint32_t)(best & 7));      // lane holding the best candidate
-            packed = (uint32_t)__shfl((int)wlo, (int)bl);
-            boff = (uint32_t)__shfl((int)off, (int)bl);
-        } else {
-            #define ZS_WMAX(ctrl) { const uint32_t ohi = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)whi, ctrl, 0xF, 0xF, false), \
-                                                   olo = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)wlo, ctrl, 0xF, 0xF, false); \
-                                    const bool t_ = ohi > whi; whi = t_ ? ohi : whi; wlo = t_ ? olo : wlo; }
-            ZS_WMAX(0xB1) ZS_WMAX(0x4E) ZS_WMAX(0x141)
-            #undef ZS_WMAX
-            best = (int)(whi >> 17); packed = wlo; boff = whi & 0x1FFFFu;
-        }
+        // lane of the other quad): a max over the keys, then two ds_bpermute reads of the winner's words
+        int best = key;
+        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
+        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
+        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x141, 0xF, 0xF, false));    // row_half_mirror: lane i <- lane 7 - i
+        const uint32_t bl = (lane & ~7u) + (7u - (uint32_t)(best & 7));          // lane holding the best candidate
+        const uint32_t packed = (uint32_t)__shfl((int)(idx | (fwd << 8) | (back << 16)), (int)bl);
+        const uint32_t boff = (uint32_t)__shfl((int)off, (int)bl);
         const uint32_t bq = ip + (packed & 0xFFu);
         uint32_t bfwd = (packed >> 8) & 0xFFu;
         const uint32_t bback = packed >> 16;
         const bool took = run && best != 0;
         // ---- long match: the walker's 8 lanes extend it, 128 bytes per round (LDS) ----
-        bool need = took && bfwd == ZS_LCAP && (end - bq) > ZS_LCAP;
+        bool need = took && bfwd == ZS_LCAP && (limit - bq) > ZS_LCAP;
         const bool extended = need;
         uint32_t pos = bq + ZS_LCAP;
         while (__any(need)) {
             uint32_t nb = 0;
             if (need) {
-                const uint32_t cap = end - pos;            // pos < end while need
+                const uint32_t cap = limit - pos;          // pos < limit while need
                 const uint32_t fo = 16 * sub;
                 if (fo < cap) {
                     uint32_t a[4], b[4];
@@ -463,20 +343,58 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
             const uint32_t part = (uint32_t)__shfl((int)nb, (int)((lane & ~7u) + f));
             if (need) {
                 if (g8) { pos += 16 * f + part; need = false; }
-                else { pos += 128; if (pos >= end) { pos = end; need = false; } }
+                else { pos += 128; if (pos >= limit) { pos = limit; need = false; } }
             }
         }
         if (extended) bfwd = pos - bq;
         if (took) {
-            if (sub == 0) {
-                ZsSeqRec r;
-                // ml bit 13: bit 16 of the offset; flags: position of the match start in its block
-                r.ll = (uint16_t)(bq - bback - anchor); r.ml = (uint16_t)((bback + bfwd) | ((boff >> 16) << 13)); r.off = (uint16_t)boff; r.flags = (uint16_t)(bq - bback);
-                seqs[nseq] = r;
-            }
-            nseq++; litSum += bq - bback - anchor;
+            const uint32_t mstart = bq - bback, ml = bback + bfwd;
+            if (sub == 0) { ZsSeqRec r; r.x = zs_rec_x(mstart - anchor, ml, boff); r.y = zs_rec_y(boff, mstart - blockStart); seqs[nseq] = r; }
+            nseq++; mlSum += ml;
             ip = bq + bfwd; anchor = ip;
+            if (boff == rep1) { rep1 = rep0; rep0 = boff; }
+            else if (boff != rep0) { rep1 = rep0; rep0 = boff; }
         } else if (run) ip = wend;
     }
-    if (sub == 0) { ZsRangeHdr h; h.nseq = nseq; h.trailing = alive ? end - anchor : ((start < n) ? end - start : 0u); h.litSum = litSum; h.pad = 0; hdrAll[(size_t)slot * (ZS_BLOCK_MAX >> WLOG) + walker] = h; }
+    if (sub == 0) res[walker] = make_uint4(nseq, nseq ? anchor : 0u, mlSum, 0u);
+    __syncthreads();
+
+    // ---- the stitch: wavefront b takes block b of the unit, lane r its walk range r ----
+    if (wave < (BIG ? 2u : 1u)) {
+        const uint32_t bStart = wave * ZS_BLOCK_MAX;
+        const uint32_t bN = (bStart < n) ? min(n - bStart, ZS_BLOCK_MAX) : 0u;
+        const uint32_t bEnd = bStart + bN;
+        const uint32_t rg = wave * 64 + lane;                                     // range index in the unit
+        const uint4 rr = res[rg];
+        const uint32_t ns = rr.x, le = rr.y;
+        uint32_t sumMl = rr.z;
+        // reach before me: maximum of the earlier ranges' last match ends (and the block start)
+        uint32_t incl = max(le, bStart);
+        #pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if ((int)lane >= d) incl = max(incl, o); }
+        uint32_t own = (uint32_t)__shfl_up((int)incl, 1); if (lane == 0) own = bStart;
+        const uint32_t reach = incl;
+        const uint32_t rs = min(rg << WLOG, bEnd), re = min((rg << WLOG) + WSIZE, bEnd);   // the range, cut at the block end
+        const uint32_t es = max(rs, own), te = max(re, reach);
+        ZsSeqRec *recs = seqAll + (size_t)slot * (ZS_BLOCK_MAX / 4) + (size_t)rg * (WSIZE / 4);
+        uint32_t f = 0;
+        if (ns && own > rs) {
+            while (f < ns) {
+                const ZsSeqRec r = recs[f];
+                const uint32_t st = zs_rec_pos(r.y) + bStart, ml = zs_rec_ml(r.x), off = zs_rec_off(r.x, r.y);
+                if (st + ml <= own) { sumMl -= ml; f++; continue; }              // covered by an earlier range's match
+                if (st < own) {                                                  // straddles: the front goes
+                    const uint32_t left = st + ml - own;
+                    if (left < ZS_MINMATCH) { sumMl -= ml; f++; continue; }
+                    ZsSeqRec w; w.x = zs_rec_x(0, left, off); w.y = zs_rec_y(off, own - bStart); recs[f] = w;
+                    sumMl -= ml - left;
+                } else { ZsSeqRec w; w.x = zs_rec_x(st - es, ml, off); w.y = r.y; recs[f] = w; }   // first kept one: its literals count from es
+                break;
+            }
+        }
+        const uint32_t kept = ns - f;
+        const uint32_t lastEnd = kept ? le : es;
+        ZsRangeHdr h; h.nseq = kept; h.first = f; h.trailing = te - lastEnd; h.litSum = (lastEnd - es) - sumMl;
+        hdrAll[(size_t)slot * ZS_WALK_RANGES + rg] = h;
+    }
 }

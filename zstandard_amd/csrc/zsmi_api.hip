@@ -168,11 +168,16 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     if (hipStream) { c->stream = (hipStream_t)hipStream; c->ownStream = false; }
     else { if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return nullptr; } c->ownStream = true; }
     // dynamic LDS beyond the 64 KiB default
-    (void)hipFuncSetAttribute((const void *)k_lz_candidates<8, ZS_CAND_WPR>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZS_CAND_LDS(8));
-    (void)hipFuncSetAttribute((const void *)k_lz_candidates<16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZS_CAND_LDS(16));
-    (void)hipFuncSetAttribute((const void *)k_lz_walk<64, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_BLOCK_MAX));
-    (void)hipFuncSetAttribute((const void *)k_lz_walk<128, 9>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_BLOCK_MAX));
-    (void)hipFuncSetAttribute((const void *)k_lz_walk<128, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_UNIT_MAX));
+    {   // dynamic LDS beyond the 64 KiB default: refused requests fail here, not at the first launch
+        bool ok = true;
+        ok &= hipFuncSetAttribute((const void *)k_lz_candidates<ZS_TABLE_LOG_SMALL, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZS_CAND_LDS(ZS_TABLE_LOG_SMALL, 1)) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void *)k_lz_candidates<ZS_TABLE_LOG_SMALL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZS_CAND_LDS(ZS_TABLE_LOG_SMALL, 2)) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void *)k_lz_candidates<ZS_TABLE_LOG_BIG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZS_CAND_LDS(ZS_TABLE_LOG_BIG, 1)) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void *)k_lz_candidates<ZS_TABLE_LOG_BIG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZS_CAND_LDS(ZS_TABLE_LOG_BIG, 2)) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void *)k_lz_walk<64>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_BLOCK_MAX)) == hipSuccess;
+        ok &= hipFuncSetAttribute((const void *)k_lz_walk<128>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_UNIT_MAX)) == hipSuccess;
+        if (!ok) { (void)hipGetLastError(); if (c->ownStream) (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
+    }
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_OVERLAP")) c->overlapEntropy = atoi(e) != 0;
     if (const char *e = getenv("ZSMI_DEC_FAST")) c->decodeFast = atoi(e) != 0;
@@ -251,7 +256,8 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
     if (!c) return ZSMI_error_init_missing;
     if (n == 0) return 0;
     if (hipSetDevice(c->device) != hipSuccess) return ZSMI_error_GENERIC;
-    const int hashLog = ZS_HASH_LOG, look = level <= 2 ? 4 : 8;
+    const int look = level <= 2 ? 4 : 8;             // level <= 2: short table only ("fast"); level >= 3: short + long table ("double")
+    const bool useLong = level >= 3;
     // plan: chunks -> blocks.  The device-side plan is reused when the chunk layout repeats (steady-state batches).
     std::vector<uint64_t> key((size_t)n * 3 + 1);
     key[0] = n;
@@ -329,15 +335,14 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         // match search per LZ unit: small units (one block) and big units (two blocks) have their own kernel shapes
         const uint32_t s0 = c->smallBefore[chunk0], ns = c->smallBefore[chunk1] - s0, b0 = c->bigBefore[chunk0], nbig = c->bigBefore[chunk1] - b0;
         const ZsUnitDesc *dUS = (const ZsUnitDesc *)c->dUnits.p + s0, *dUB = (const ZsUnitDesc *)c->dUnits.p + c->planSmall + b0;
-        if (ns) LAUNCH_ON(c, st, "k_lz_candidates", (k_lz_candidates<8, ZS_CAND_WPR>), dim3(ns), dim3(8 * ZS_CAND_WPR * 64), ZS_CAND_LDS(8), (const uint8_t *)dSrc, dUS, block0,
-                          (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, (uint8_t *)L.dDistMask.p, hashLog);
-        if (nbig) LAUNCH_ON(c, st, "k_lz_candidates_big", (k_lz_candidates<16, 1>), dim3(nbig), dim3(1024), ZS_CAND_LDS(16), (const uint8_t *)dSrc, dUB, block0,
-                            (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, (uint8_t *)L.dDistMask.p, hashLog);
-        if (ns && getenv("ZSMI_EXP_WALK")) LAUNCH_ON(c, st, "k_lz_walk_exp", (k_lz_walk<128, 9>), dim3(ns), dim3(1024), ZS_WALK_LDS(ZS_BLOCK_MAX), (const uint8_t *)dSrc, dUS, block0, (const uint16_t *)L.dDist.p,
-                          (const uint8_t *)L.dDistHi.p, (const uint8_t *)L.dDistMask.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dLits.p, look);
-        if (ns) LAUNCH_ON(c, st, "k_lz_walk", (k_lz_walk<64, 10>), dim3(ns), dim3(512), ZS_WALK_LDS(ZS_BLOCK_MAX), (const uint8_t *)dSrc, dUS, block0, (const uint16_t *)L.dDist.p,
+        #define CAND_LAUNCH(name, TL, NT, cnt, du) LAUNCH_ON(c, st, name, (k_lz_candidates<TL, NT>), dim3(cnt), dim3(64 * NT), ZS_CAND_LDS(TL, NT), (const uint8_t *)dSrc, du, block0, \
+                          (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, (uint8_t *)L.dDistMask.p)
+        if (ns) { if (useLong) CAND_LAUNCH("k_lz_candidates", ZS_TABLE_LOG_SMALL, 2, ns, dUS); else CAND_LAUNCH("k_lz_candidates", ZS_TABLE_LOG_SMALL, 1, ns, dUS); }
+        if (nbig) { if (useLong) CAND_LAUNCH("k_lz_candidates_big", ZS_TABLE_LOG_BIG, 2, nbig, dUB); else CAND_LAUNCH("k_lz_candidates_big", ZS_TABLE_LOG_BIG, 1, nbig, dUB); }
+        #undef CAND_LAUNCH
+        if (ns) LAUNCH_ON(c, st, "k_lz_walk", (k_lz_walk<64>), dim3(ns), dim3(512), ZS_WALK_LDS(ZS_BLOCK_MAX), (const uint8_t *)dSrc, dUS, block0, (const uint16_t *)L.dDist.p,
                           (const uint8_t *)L.dDistHi.p, (const uint8_t *)L.dDistMask.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
-        if (nbig) LAUNCH_ON(c, st, "k_lz_walk_big", (k_lz_walk<128, 10>), dim3(nbig), dim3(1024), ZS_WALK_LDS(ZS_UNIT_MAX), (const uint8_t *)dSrc, dUB, block0, (const uint16_t *)L.dDist.p,
+        if (nbig) LAUNCH_ON(c, st, "k_lz_walk_big", (k_lz_walk<128>), dim3(nbig), dim3(1024), ZS_WALK_LDS(ZS_UNIT_MAX), (const uint8_t *)dSrc, dUB, block0, (const uint16_t *)L.dDist.p,
                             (const uint8_t *)L.dDistHi.p, (const uint8_t *)L.dDistMask.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
         // the two entropy kernels are independent of each other: the sequences kernel runs on a side stream beside the literals kernel
         const bool overlap = c->overlapEntropy;
@@ -603,7 +608,7 @@ extern "C" int zsmi_dbg_copyScratch(zsmi_ctx *c, int which, void *hostDst, size_
     if (!c) return -1;
     (void)hipStreamSynchronize(c->stream);
     zsmi_ctx::Scratch &L0 = c->lanes[0];
-    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : which == 4 ? &L0.dDistHi : which == 5 ? &c->dLitScratch : &L0.dMetas;
+    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : which == 4 ? &L0.dDistHi : which == 6 ? &L0.dDistMask : which == 5 ? &c->dLitScratch : &L0.dMetas;
     if (bytes > b->cap) return -2;
     return hipMemcpy(hostDst, b->p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }

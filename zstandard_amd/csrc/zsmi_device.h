@@ -6,18 +6,20 @@
 
 #define ZS_BLOCK_MAX   65536u     // bytes per block; block positions fit 16 bits
 #define ZS_UNIT_MAX    131072u    // bytes per LZ unit (match window): two consecutive blocks of a chunk
-#define ZS_RANGE_LOG   13
-#define ZS_RANGE_SIZE  (1u << ZS_RANGE_LOG)   // hash-table ranges (8 KiB): 8 per block, 16 per full unit
-#define ZS_HASH_LOG    12         // slots per range table
+#define ZS_TABLE_LOG_SMALL 13     // slots of each candidate table, units <= 64 KiB
+#define ZS_TABLE_LOG_BIG   14     // units <= 128 KiB
 #define ZS_WALK_LOG    10
 #define ZS_WALK_SIZE   (1u << ZS_WALK_LOG)   // the walk cuts the block in ranges of 1 KiB
 #define ZS_WALK_RANGES 64u        // per block
-#define ZS_MINMATCH    5u         // shortest match kept (candidates are found by their first 4 bytes)
-#define ZS_WINDOW      64u        // positions looked at per walk step (one wavefront)
+#define ZS_CROSS_MAX   16384u     // a match may pass its walk range's end by this much (never the block's end)
+#define ZS_MINMATCH    5u         // shortest match kept
+#define ZS_REPMIN      4u         // shortest match at one of the walker's two recent offsets
+#define ZS_REPWIN      16u        // positions of a walk step's window tried for recent-offset matches
+#define ZS_WINDOW      64u        // positions looked at per walk step
 #define ZS_FCAP        8u         // forward bytes compared when scoring a candidate
 #define ZS_BCAP        8u         // backward bytes compared when scoring a candidate
 #define ZS_LCAP        16u        // forward bytes a walker lane compares in its one round of loads; longer matches are extended
-#define ZS_SEQ_PER_RANGE 256u     // record slots per walk range (1024 / 4)
+#define ZS_SEQ_PER_RANGE 256u     // record slots per walk range: its matches start inside it and are >= 4 bytes long
 #define ZS_HUF_MAXBITS 11u
 
 // one 64 KiB block of one chunk
@@ -36,10 +38,22 @@ struct ZsUnitDesc {
     uint32_t firstBlock;  // index of its first block in the call's block list
 };
 
-// one sequence as the walk kernel leaves it (per range) / as the encode kernel consumes it
-struct ZsSeqRec { uint16_t ll, ml, off, flags; };   // off: low 16 bits of the offset, ml bit 13: its bit 16; flags: block position of the match start; ml bits 14-15: repcode (encode kernel)
+// one sequence as the walk kernel leaves it (per range) / as the entropy kernels consume it: two 32-bit words
+//   x: bits 0-10 literals in front of it inside its range's territory (< 1024), bits 11-25 match length (<= 1024 + ZS_CROSS_MAX + ZS_BCAP),
+//      bit 26 bit 16 of the offset, bits 27-28 recent-offset code (written by the sequences kernel)
+//   y: bits 0-15 low 16 bits of the offset, bits 16-31 block position of the match start
+struct ZsSeqRec { uint32_t x, y; };
+__device__ __forceinline__ uint32_t zs_rec_ll(uint32_t x) { return x & 0x7FFu; }
+__device__ __forceinline__ uint32_t zs_rec_ml(uint32_t x) { return (x >> 11) & 0x7FFFu; }
+__device__ __forceinline__ uint32_t zs_rec_rep(uint32_t x) { return (x >> 27) & 3u; }
+__device__ __forceinline__ uint32_t zs_rec_off(uint32_t x, uint32_t y) { return (y & 0xFFFFu) | (((x >> 26) & 1u) << 16); }
+__device__ __forceinline__ uint32_t zs_rec_pos(uint32_t y) { return y >> 16; }
+__device__ __forceinline__ uint32_t zs_rec_x(uint32_t ll, uint32_t ml, uint32_t off) { return ll | (ml << 11) | ((off >> 16) << 26); }
+__device__ __forceinline__ uint32_t zs_rec_y(uint32_t off, uint32_t pos) { return (off & 0xFFFFu) | (pos << 16); }
 
-struct ZsRangeHdr { uint32_t nseq, trailing, litSum, pad; };   // litSum: literal bytes in front of the range's matches
+// a walk range after the stitch: its records [first, first + nseq) count; litSum: literal bytes in front of those matches inside the
+// range's territory; trailing: literal bytes behind the last of them (the whole territory if there is none)
+struct ZsRangeHdr { uint32_t nseq, trailing, litSum, first; };
 
 // per-block result of the encode kernel
 struct ZsBlockResult { uint32_t payloadSize; uint32_t type; /* 0 raw, 1 rle, 2 compressed */ uint32_t rleByte; uint32_t pad; };
@@ -52,6 +66,5 @@ __device__ __forceinline__ uint64_t zs_load64(const uint8_t *p) { uint64_t v; __
 __device__ __forceinline__ void zs_store16(uint8_t *p, uint16_t v) { __builtin_memcpy(p, &v, 2); }
 __device__ __forceinline__ void zs_store32(uint8_t *p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
 __device__ __forceinline__ void zs_store64(uint8_t *p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
-__device__ __forceinline__ uint32_t zs_hash4(uint32_t v, int hashLog) { return (v * 2654435761u) >> (32 - hashLog); }
 __device__ __forceinline__ uint32_t zs_highbit(uint32_t v) { return 31u - (uint32_t)__builtin_clz(v); }
 __device__ __forceinline__ int zs_lane() { return (int)(threadIdx.x & 63u); }
