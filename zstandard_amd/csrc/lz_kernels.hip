@@ -26,7 +26,11 @@
 #ifndef ZS_CAND_G
 #define ZS_CAND_G 8                // steps of 64 positions per group (loads in flight per lane)
 #endif
-#define ZS_CAND_LDS(TLOG, NT) ((size_t)(NT) * (4u << (TLOG)) + ((NT) > 1 ? 2u * (NT) * ZS_CAND_G * 64u * 4u : 0u))
+#ifndef ZS_CAND_DEPTH
+#define ZS_CAND_DEPTH 4            // a register set holds the source loads of this many groups (two sets: 4 .. 8 groups in flight)
+#endif
+#define ZS_CAND_RING (4u * ZS_CAND_G * 64u + 16u)                 // source bytes of 4 groups + the mirror of the first 16
+#define ZS_CAND_LDS(TLOG, NT) ((size_t)(NT) * (4u << (TLOG)) + ((NT) > 1 ? 2u * (NT) * ZS_CAND_G * 64u * 4u : 0u) + ZS_CAND_RING + (NT) * 256u)   // tables, exchange buffers, source ring, a dummy word per lane
 #define ZS_SLOT_EMPTY 0xFFFFFFFFu
 __device__ __forceinline__ uint32_t zs_hash_short(uint32_t lo, uint32_t hi) { return lo * 0x9E3779B1u + (hi & 0xFFu) * 0x9E3779u; }
 __device__ __forceinline__ uint32_t zs_hash_long(uint32_t lo, uint32_t hi) { return (hi ^ __builtin_amdgcn_alignbit(lo * 0x9E3779B1u, lo * 0x9E3779B1u, 17)) * 0x85EBCA77u; }   // rotl 15
@@ -39,9 +43,13 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     extern __shared__ __attribute__((aligned(16))) uint32_t candLds[];
     constexpr bool BIG = TLOG > ZS_TABLE_LOG_SMALL;
     constexpr uint32_t G = ZS_CAND_G, GP = G * 64u, H = (NT > 1) ? G / 2 : G;     // H: steps of a group a wavefront stores
+    constexpr uint32_t M = ZS_CAND_DEPTH;
+    constexpr uint32_t PART = GP / NT, PW = PART / 256;               // source bytes of a group a wavefront stages; dwords per lane
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     uint32_t *T = candLds + ((size_t)wave << TLOG);
     uint32_t *xbuf = candLds + ((size_t)NT << TLOG);                  // [group parity][table][GP]
+    uint8_t *ring = reinterpret_cast<uint8_t *>(xbuf + ((NT > 1) ? 2u * NT * GP : 0u));       // source bytes of 4 groups + 16
+    const uint32_t dummy = (uint32_t)((reinterpret_cast<uint32_t *>(ring) + ZS_CAND_RING / 4 + threadIdx.x) - T);   // a word of this lane's own behind everything
     const ZsUnitDesc ud = units[blockIdx.x];
     const uint8_t *s = src + ud.srcOff;
     const uint32_t n = ud.size;
@@ -58,66 +66,121 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     }
     const uint32_t hashable = (n >= 8) ? n - 7 : 0;                   // positions [0, hashable) have 8 bytes
     const uint32_t nGroups = (hashable + GP - 1) / GP;
+    if (nGroups == 0) return;
+    const uint32_t lastWord = n - 4;                                  // loads are clamped, never branched around
 
-    auto load = [&](uint32_t base, uint64_t (&v)[G]) {
+    // The source bytes reach the hashing lanes through a ring in LDS: group g lies at ring[(g & 3) * GP ...), staged by the NT
+    // wavefronts a part each with one coalesced load per lane (a lane fetching its own 8 bytes at p, p + 1, ... is an unaligned
+    // access per lane: the texture addresser serialised them and bound the kernel).  A lane reads the three dwords around its
+    // position and shifts (lane & 3 is its byte offset in every step).  The ring's first 16 bytes are mirrored behind its end.
+    auto loadPart = [&](uint32_t g, uint32_t (&w)[PW]) {
         #pragma unroll
-        for (uint32_t u = 0; u < G; u++) { const uint32_t p = base + u * 64 + lane; v[u] = (p < hashable) ? zs_load64(s + p) : 0ull; }
+        for (uint32_t k = 0; k < PW; k++) w[k] = zs_load32(s + min(g * GP + wave * PART + k * 256u + lane * 4u, lastWord));
     };
-    uint64_t v[G], vn[G];
-    if (nGroups) load(0, v);
-    #pragma unroll
-    for (uint32_t u = 0; u < G; u++) asm volatile("" : "+v"(v[u]));    // the first group is waited for here, not behind the next group's loads
-    for (uint32_t g = 0; g < nGroups; g++) {
-        const uint32_t base = g * GP;
-        if (g + 1 < nGroups) load(base + GP, vn);
-        uint32_t entry[G], old[G], d[G];
+    auto stagePart = [&](uint32_t g, const uint32_t (&w)[PW]) {
+        uint8_t *dst = ring + (g & 3u) * GP + wave * PART + lane * 4u;
         #pragma unroll
-        for (uint32_t u = 0; u < G; u++) {                               // the G exchanges go to the LDS back to back
-            const uint32_t p = base + u * 64 + lane;
-            const uint32_t lo = (uint32_t)v[u], hi = (uint32_t)(v[u] >> 32);
-            const uint32_t h = (wave == 0) ? zs_hash_short(lo, hi) : zs_hash_long(lo, hi);
-            entry[u] = ((h << TLOG) & 0xFFFE0000u) | p;
-            old[u] = ZS_SLOT_EMPTY;
-            if (p < hashable) old[u] = atomicExch(&T[h >> (32 - TLOG)], entry[u]);
-        }
+        for (uint32_t k = 0; k < PW; k++) *reinterpret_cast<uint32_t *>(dst + k * 256u) = w[k];
+        if ((g & 3u) == 0 && wave == 0 && lane < 4) *reinterpret_cast<uint32_t *>(ring + 4u * GP + lane * 4u) = w[0];
+    };
+    // Software pipeline over the groups (a wavefront is alone on its SIMD: nothing else hides its latencies).  Iteration g:
+    //   1. distances of group g - 1 from the exchange results that came back during the last iteration -> LDS exchange buffer
+    //   2. stage this wavefront's part of group g + 1 (loaded M .. 2 M iterations earlier); 3. barrier
+    //   4. issue the reads of this wavefront's half of both tables' distances of group g - 1 and of the source bytes of group g
+    //   5. hash group g and issue its G exchanges (they run while 6 is done and until the next iteration's step 1)
+    //   6. merge, candidate bits, stores of group g - 1
+    // Loads in flight live in two register sets A and B of M groups each, addressed statically; the loop body is
+    // [load B | M iterations on A | load A | M iterations on B].  The compiler puts a full s_waitcnt vmcnt(0) at the loop head (it
+    // cannot count loads across the back edge): there it only meets the loads of A issued M iterations earlier.
+    auto run = [&](auto roleTag) {
+        constexpr bool LONG = decltype(roleTag)::value;
+        uint32_t bufA[M][PW], bufB[M][PW];
+        auto loadM = [&](uint32_t g0, uint32_t (&buf)[M][PW]) {
+            #pragma unroll
+            for (uint32_t k = 0; k < M; k++) loadPart(min(g0 + k, nGroups), buf[k]);
+        };
+        uint32_t entry[G], old[G];
         #pragma unroll
-        for (uint32_t u = 0; u < G; u++) {
-            const uint32_t p = base + u * 64 + lane;
-            const int dd = (int)p - (int)(old[u] & 0x1FFFFu);            // an empty slot reads as position 131071: never behind p
-            d[u] = (((old[u] ^ entry[u]) >> 17) == 0 && dd > 0) ? (uint32_t)dd : 0u;
-        }
-        if (NT > 1) {
-            uint32_t *xb = xbuf + (size_t)(g & 1u) * NT * GP;
+        for (uint32_t u = 0; u < G; u++) { entry[u] = 0; old[u] = ZS_SLOT_EMPTY; }
+        auto iter = [&](auto wholeTag, uint32_t g, const uint32_t (&wNext)[PW]) {
+            constexpr bool WHOLE = decltype(wholeTag)::value;                // group g lies wholly inside the hashable positions
+            const uint32_t pbase = (g - 1) * GP;                             // group g - 1 (nothing of it is kept when g == 0)
+            uint32_t d[G];
             #pragma unroll
-            for (uint32_t u = 0; u < G; u++) xb[wave * GP + u * 64 + lane] = d[u];
-            __syncthreads();
-            #pragma unroll
-            for (uint32_t uu = 0; uu < H; uu++) {
-                const uint32_t u = wave * H + uu;
-                const uint32_t dS = xb[u * 64 + lane], dL = xb[GP + u * 64 + lane];
-                d[uu] = dL ? dL : dS;
+            for (uint32_t u = 0; u < G; u++) {
+                // same tag: entry - old is the distance (the tags cancel).  It counts if it is positive: an empty slot reads as
+                // position 131071, behind every position; both conditions in one compare: max(old ^ entry, entry - old) < 2^17.
+                const uint32_t x = old[u] ^ entry[u], dd = entry[u] - old[u];
+                d[u] = (max(x, dd) < (1u << 17)) ? dd : 0u;
             }
+            uint32_t mS[H], mL[H];
+            if (NT > 1) {
+                uint32_t *xb = xbuf + (size_t)(g & 1u) * NT * GP;
+                #pragma unroll
+                for (uint32_t u = 0; u < G; u++) xb[wave * GP + u * 64 + lane] = d[u];
+                stagePart(g + 1, wNext);
+                __syncthreads();
+                #pragma unroll
+                for (uint32_t uu = 0; uu < H; uu++) { const uint32_t u = wave * H + uu; mS[uu] = xb[u * 64 + lane]; mL[uu] = xb[GP + u * 64 + lane]; }
+            } else stagePart(g + 1, wNext);
+            {
+                const uint32_t base = g * GP;                                // group g (behind the last group: dummy exchanges)
+                const uint32_t *rp = reinterpret_cast<const uint32_t *>(ring + (g & 3u) * GP + (lane & ~3u));
+                uint32_t w0[G], w1[G], w2[G];
+                #pragma unroll
+                for (uint32_t u = 0; u < G; u++) { w0[u] = rp[u * 16]; w1[u] = rp[u * 16 + 1]; w2[u] = rp[u * 16 + 2]; }
+                #pragma unroll
+                for (uint32_t u = 0; u < G; u++) {                           // the G exchanges go to the LDS back to back
+                    const uint32_t p = base + u * 64 + lane;
+                    const uint32_t lo = __builtin_amdgcn_alignbyte(w1[u], w0[u], lane & 3u), hi = __builtin_amdgcn_alignbyte(w2[u], w1[u], lane & 3u);
+                    uint32_t h = LONG ? zs_hash_long(lo, hi) : zs_hash_short(lo, hi);
+                    asm volatile("" : "+v"(h));                              // (keeps the compiler from folding the shifts below into two more multiplies)
+                    entry[u] = ((h << TLOG) & 0xFFFE0000u) | (p & 0x1FFFFu);
+                    const uint32_t idx = h >> (32 - TLOG);
+                    old[u] = atomicExch(&T[(WHOLE || p < hashable) ? idx : dummy], entry[u]);
+                }
+            }
+            if (g > 0) {
+                // candidate bits (and bit 16 of the distances) of this wavefront's H steps of group g - 1: lane uu keeps step uu's
+                // word, so each plane takes one store of H * 8 contiguous bytes.  (What is stored for positions behind the
+                // hashable ones is never read: the walk stops at them.)
+                const uint32_t sbase = pbase + ((NT > 1) ? wave * H * 64u : 0u);
+                uint64_t pmMine = 0, hiMine = 0;
+                #pragma unroll
+                for (uint32_t uu = 0; uu < H; uu++) {
+                    const uint32_t dm = (NT > 1) ? (mL[uu] ? mL[uu] : mS[uu]) : d[uu];
+                    if (BIG) { const uint64_t hi = __ballot((dm >> 16) != 0); if (lane == uu) hiMine = hi; }
+                    const uint64_t pm = __ballot(dm != 0);
+                    if (lane == uu) pmMine = pm;
+                    dist[sbase + uu * 64 + lane] = (uint16_t)dm;
+                }
+                if (lane < H) {
+                    *reinterpret_cast<uint64_t *>(distMask + ((sbase + lane * 64) >> 3)) = pmMine;
+                    if (BIG) *reinterpret_cast<uint64_t *>(distHi + ((sbase + lane * 64) >> 3)) = hiMine;
+                }
+            }
+        };
+        auto step = [&](uint32_t g, const uint32_t (&wNext)[PW]) {
+            if (g > nGroups) return;
+            if ((g + 1) * GP <= hashable) iter(std::true_type{}, g, wNext); else iter(std::false_type{}, g, wNext);
+        };
+        {   // group 0 into the ring; register set A = the parts of groups 1 .. M (staged by iterations 0 .. M - 1)
+            uint32_t w[PW];
+            loadPart(0, w);
+            stagePart(0, w);
+            loadM(1, bufA);
+            if (NT > 1) __syncthreads();
         }
-        // candidate bits (and bit 16 of the distances) of this wavefront's H steps: lane uu keeps step uu's word,
-        // so each plane takes one store of H * 8 contiguous bytes
-        const uint32_t sbase = base + ((NT > 1) ? wave * H * 64u : 0u);
-        uint64_t pmMine = 0, hiMine = 0;
-        #pragma unroll
-        for (uint32_t uu = 0; uu < H; uu++) {
-            const uint32_t p = sbase + uu * 64 + lane;
-            const uint32_t dm = d[uu];
-            if (BIG) { const uint64_t hi = __ballot((dm >> 16) != 0); if (lane == uu) hiMine = hi; }
-            const uint64_t pm = __ballot(dm != 0);
-            if (lane == uu) pmMine = pm;
-            if (p < hashable) dist[p] = (uint16_t)dm;
+        for (uint32_t g0 = 0; g0 <= nGroups; g0 += 2 * M) {
+            loadM(g0 + M + 1, bufB);
+            #pragma unroll
+            for (uint32_t k = 0; k < M; k++) step(g0 + k, bufA[k]);
+            loadM(g0 + 2 * M + 1, bufA);
+            #pragma unroll
+            for (uint32_t k = 0; k < M; k++) step(g0 + M + k, bufB[k]);
         }
-        if (lane < H) {
-            *reinterpret_cast<uint64_t *>(distMask + ((sbase + lane * 64) >> 3)) = pmMine;
-            if (BIG) *reinterpret_cast<uint64_t *>(distHi + ((sbase + lane * 64) >> 3)) = hiMine;
-        }
-        #pragma unroll
-        for (uint32_t u = 0; u < G; u++) v[u] = vn[u];
-    }
+    };
+    if (wave == 0) run(std::false_type{}); else run(std::true_type{});
 }
 
 // ---------------------------------------------------------------------------------------------
