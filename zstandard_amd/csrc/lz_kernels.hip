@@ -75,7 +75,11 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     // position and shifts (lane & 3 is its byte offset in every step).  The ring's first 16 bytes are mirrored behind its end.
     auto loadPart = [&](uint32_t g, uint32_t (&w)[PW]) {
         #pragma unroll
-        for (uint32_t k = 0; k < PW; k++) w[k] = zs_load32(s + min(g * GP + wave * PART + k * 256u + lane * 4u, lastWord));
+        for (uint32_t k = 0; k < PW; k++) {
+            // a word that would pass the unit's end is read at the last whole word and shifted down: the bytes below the end stay right
+            const uint32_t o = g * GP + wave * PART + k * 256u + lane * 4u, oc = min(o, lastWord);
+            w[k] = zs_load32(s + oc) >> (8u * min(o - oc, 3u));
+        }
     };
     auto stagePart = [&](uint32_t g, const uint32_t (&w)[PW]) {
         uint8_t *dst = ring + (g & 3u) * GP + wave * PART + lane * 4u;
