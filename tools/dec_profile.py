@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
 """Development aid (GPU box, library built with -DZS_DEC_PROFILE): cycles per decoder phase, averaged over the frames."""
+import os; os.environ["ZSMI_DEBUG_LIB"] = "1"          # the library built with -DZSMI_DEBUG_HOOKS (zstandard_amd/_lib.py)
 import sys, os, ctypes
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

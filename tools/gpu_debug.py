@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Stage-by-stage comparison of the HIP encoder with oracle E on a few inputs (development aid, GPU box)."""
 import sys, os, ctypes
+os.environ["ZSMI_DEBUG_LIB"] = "1"          # the library built with -DZSMI_DEBUG_HOOKS (zstandard_amd/_lib.py)
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -3,7 +3,10 @@
 import ctypes, os, subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libzsmi.so")
+# development tools (tools/gpu_debug.py, tools/time_kernels.py) set ZSMI_DEBUG_LIB=1: a second library built with
+# -DZSMI_DEBUG_HOOKS (scratch read-back, stage-stop timing aids); the product library has neither
+DEBUG = os.environ.get("ZSMI_DEBUG_LIB", "") == "1"
+LIB_PATH = os.path.join(_HERE, "lib", "libzsmi_debug.so" if DEBUG else "libzsmi.so")
 CSRC = os.path.join(_HERE, "csrc")
 
 
@@ -14,7 +17,9 @@ def build(force=False):
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH, os.path.join(CSRC, "zsmi_api.hip")]
-    cmd += os.environ.get("ZSMI_HIPCC_FLAGS", "").split()          # kernel-shape experiments (-DZS_CAND_WPR=2 ...)
+    cmd += os.environ.get("ZSMI_HIPCC_FLAGS", "").split()          # kernel-shape experiments (-DZS_CAND_G=4 ...)
+    if DEBUG:
+        cmd.append("-DZSMI_DEBUG_HOOKS")
     subprocess.check_call(cmd)
     return LIB_PATH
 
@@ -55,7 +60,8 @@ def lib():
     L.zsmi_packFramesDevice.restype = i32; L.zsmi_packFramesDevice.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     L.zsmi_enableKernelTiming.restype = i32; L.zsmi_enableKernelTiming.argtypes = [vp, i32]
     L.zsmi_getKernelTimes.restype = i32; L.zsmi_getKernelTimes.argtypes = [vp, ctypes.POINTER(KernelTime), i32]
-    L.zsmi_dbg_copyScratch.restype = i32; L.zsmi_dbg_copyScratch.argtypes = [vp, i32, vp, sz]
+    if DEBUG:
+        L.zsmi_dbg_copyScratch.restype = i32; L.zsmi_dbg_copyScratch.argtypes = [vp, i32, vp, sz]
     _lib = L
     return L
 

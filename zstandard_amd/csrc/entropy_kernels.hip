@@ -7,6 +7,13 @@
 //   sequences header/tables <-> DecodeSeqHeaders, BuildFSETable ZStdDecompress.cs:958-1180, EntropyCommon.cs:79-188
 //   sequences bitstream     <-> DecodeSequence, decompressSequences_body  ZStdDecompress.cs:1473-1608
 #include "zsmi_device.h"
+// timing aids of the development tools (tools/time_kernels.py): end a kernel after a stage.  Compiled in only with
+// -DZSMI_DEBUG_HOOKS (the library the product ships ignores the stopAt argument).
+#ifdef ZSMI_DEBUG_HOOKS
+#define ZS_STOP_AT(v) (stopAt == (v))
+#else
+#define ZS_STOP_AT(v) false
+#endif
 
 #define MaxLL 35
 #define MaxML 52
@@ -727,7 +734,7 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
         L.count[tid] = c;
     }
     __syncthreads();
-    if (stopAt == 1) FINISH(0, 0, 0);            // timing aid (ZSMI_STOP_LIT): stop after the literal gather
+    if (ZS_STOP_AT(1)) FINISH(0, 0, 0);            // timing aid (ZSMI_STOP_LIT): stop after the literal gather
 
     // ---- literals section (inverse of DecodeLiteralsBlock, ZStdDecompress.cs:683-821) ----
     if (wave == 0) {
@@ -756,14 +763,14 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     }
     if (!done && nlit >= 64) {
         const uint32_t tableLog = huffLengths(L, maxSym, ZS_HUF_MAXBITS);
-        if (stopAt == 2) FINISH(0, 0, 0);    // stop after the code lengths
+        if (ZS_STOP_AT(2)) FINISH(0, 0, 0);    // stop after the code lengths
         const uint32_t lhSize = 3 + (nlit >= 1024) + (nlit >= 16384);
         const bool single = nlit < 256;
         huffCodesAndWeights(L, maxSym, tableLog);
         if (tid == 0) L.misc[0] = writeHuffHeader(L, payload + lhSize, cap - lhSize, maxSym, tableLog);
         __syncthreads();
         const uint32_t hsz = L.misc[0];
-        if (stopAt == 3) FINISH(0, 0, 0);    // stop after codes + table description
+        if (ZS_STOP_AT(3)) FINISH(0, 0, 0);    // stop after codes + table description
         if (hsz) {
             const uint32_t seg = (nlit + 3) / 4;
             if (single) { if (wave == 0) { const uint32_t z = huffEncodeStream(L, L.u.tile[0], streams, lits, 0, nlit); if (lane == 0) L.misc[8] = z; } }
@@ -996,7 +1003,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
             }
         }
         wave_sync();
-        if (stopAt == 1) break;                         // timing aid (ZSMI_STOP_SEQ): stop after repcodes + histograms
+        if (ZS_STOP_AT(1)) break;                         // timing aid (ZSMI_STOP_SEQ): stop after repcodes + histograms
 
         // ---- modes and tables ----
         uint32_t pos = hdrBytes + 1;                        // after nbSeq and the modes byte
@@ -1046,7 +1053,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
             wave_sync();
         }
         if (fail) break;
-        if (stopAt == 2) break;                         // stop after the tables
+        if (ZS_STOP_AT(2)) break;                         // stop after the tables
         if (lane == 0) out[hdrBytes] = (uint8_t)modeByte;
         bitstreamOff = pos;
         live = true;
@@ -1117,7 +1124,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
             SeqLds &B = LS[g];
             const uint32_t Tg = chainLane ? B.misc[3] : 0u;
             const uint32_t Tmax = wave_max(Tg);
-            if (chainLane && stopAt != 3) {                    // stopAt 3: timing aid, no chains
+            if (chainLane && !ZS_STOP_AT(3)) {                    // stopAt 3: timing aid, no chains
                 const FseCT &ct = B.ct[c];
                 const uint2 *op = B.u.tile.op[c];
                 uint32_t *outp = B.u.tile.tileState[c];
@@ -1156,7 +1163,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
             }
         }
         __syncthreads();
-        if (mine && stopAt != 4) {                             // stopAt 4: timing aid, no packing
+        if (mine && !ZS_STOP_AT(4)) {                             // stopAt 4: timing aid, no packing
             uint64_t lo = 0; uint32_t hi = 0, nb = 0;
             if (lane < T) {
                 #define PUTB(v, b) { const uint32_t b_ = (b); if (b_) { const uint64_t v_ = (uint64_t)(v); if (nb < 64) { lo |= v_ << nb; if (nb + b_ > 64) hi |= (uint32_t)(v_ >> (64 - nb)); } else hi |= (uint32_t)(v_ << (nb - 64)); nb += b_; } }

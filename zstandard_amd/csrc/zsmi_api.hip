@@ -123,7 +123,7 @@ struct zsmi_ctx {
     Scratch lanes[kMaxLanes];
     int nLanes = 1;
     bool overlapEntropy = false;           // ZSMI_OVERLAP=1: sequences kernel on a side stream beside the literals kernel (measured slower: both want the whole LDS)
-    int stopLit = 0, stopSeq = 0;          // timing aids (ZSMI_STOP_LIT / ZSMI_STOP_SEQ): end a kernel after a stage; output is then invalid
+    int stopLit = 0, stopSeq = 0;          // timing aids of a -DZSMI_DEBUG_HOOKS build (ZSMI_STOP_LIT / ZSMI_STOP_SEQ): end a kernel after a stage; always 0 in the product
     hipEvent_t evStart = nullptr;
     PinBuf hBlocks, hChunks, hUnits;
     std::vector<uint32_t> smallBefore, bigBefore;   // per chunk (n + 1 entries): small / big units in front of it
@@ -182,8 +182,10 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     if (const char *e = getenv("ZSMI_OVERLAP")) c->overlapEntropy = atoi(e) != 0;
     if (const char *e = getenv("ZSMI_DEC_FAST")) c->decodeFast = atoi(e) != 0;
     if (const char *e = getenv("ZSMI_ITEMS_IN_FLIGHT")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->maxItemsInFlight = (uint32_t)v; }
+#ifdef ZSMI_DEBUG_HOOKS
     if (const char *e = getenv("ZSMI_STOP_LIT")) c->stopLit = atoi(e);
     if (const char *e = getenv("ZSMI_STOP_SEQ")) c->stopSeq = atoi(e);
+#endif
     if (const char *e = getenv("ZSMI_LANES")) { long v = atol(e); if (v >= 1 && v <= zsmi_ctx::kMaxLanes) c->nLanes = (int)v; }
     // sub-batches of one call run on internal streams so that the latency-bound kernels of different sub-batches overlap
     for (int i = 0; i < c->nLanes; i++) {
@@ -601,6 +603,7 @@ extern "C" size_t zsmi_decompress_usingDict(void *dst, size_t dstCapacity, const
     return ds;
 }
 
+#ifdef ZSMI_DEBUG_HOOKS
 // ---- test hook (not in include/zsmi.h): copy a scratch buffer of the last compress sub-batch to the host.
 //      which: 0 dist (u16 x 65536 per block), 1 sequences (ZsSeqRec x 8 x 2048 per block), 2 range headers, 3 block results ----
 extern "C" int zsmi_dbg_copyScratch(zsmi_ctx *c, int which, void *hostDst, size_t bytes)
@@ -612,3 +615,4 @@ extern "C" int zsmi_dbg_copyScratch(zsmi_ctx *c, int which, void *hostDst, size_
     if (bytes > b->cap) return -2;
     return hipMemcpy(hostDst, b->p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
+#endif
