@@ -303,3 +303,101 @@ def test_checksummed_one_block_frames(codec):
         with pytest.raises(O.OracleError) as e:
             O.decompress(f, len(c))
         assert e.value.code == 22
+
+
+# ------------------------------------------------------------------ mixed corpus, BASELINE configs, in-flight limits
+@pytest.mark.parametrize("cs,level", [(65536, 3), (131072, 1), (131072, 3)])
+def test_mixed_corpus_matches_oracle_and_ratio(codec, cs, level):
+    """every class of the mixed corpus (tests/_corpus.py): HIP frames byte-identical to oracle E, decode under oracle D,
+    and the ratio contract per class: compressed size <= 1.01 x libzstd's at the same level and chunk size"""
+    import _corpus as C
+    worst = {}
+    for name, data in C.corpus(1 << 20).items():
+        chunks = [data[i:i + cs] for i in range(0, len(data), cs)]
+        frames = _compress_many(codec, chunks, level)
+        ea, eo, es = O.compress_batch(np.frombuffer(data, dtype=np.uint8), np.arange(0, len(data), cs, dtype=np.uint64),
+                                      np.array([len(c) for c in chunks], dtype=np.uint32), level, 8)
+        for i, (f, c) in enumerate(zip(frames, chunks)):
+            assert f == ea[int(eo[i]):int(eo[i]) + int(es[i])].tobytes(), (name, i)
+        assert O.decompress(frames[0], len(chunks[0])) == chunks[0] and O.decompress(frames[-1], len(chunks[-1])) == chunks[-1]
+        got = _decompress_many(codec, frames, [len(c) for c in chunks])
+        assert all(g == (len(c), c) for g, c in zip(got, chunks)), name
+        if O.libzstd():
+            worst[name] = round(sum(len(f) for f in frames) / sum(len(O.zstd_compress(c, level)) for c in chunks), 4)
+    assert all(v <= 1.01 for v in worst.values()), worst
+
+
+def test_one_mib_of_zeros_level3(codec):
+    """BASELINE config 1 (1 MiB zero-filled buffer, level 3): through the one-shot call (one frame of 16 RLE blocks of 64 KiB:
+    73 bytes; libzstd cuts 128 KiB blocks and needs 50) and as a batch of 16 chunks; both against oracle E / D"""
+    from zstandard_amd import ZstdCompressor, ZStdDecompress
+    data = bytes(1 << 20)
+    f = ZstdCompressor(3).compress(data)
+    assert f == O.compress(data, 3) and len(f) == 73
+    assert O.decompress(f, len(data)) == data
+    out = bytearray(len(data))
+    assert ZStdDecompress.Decompress(out, f) == len(data) and bytes(out) == data
+    if O.libzstd():
+        assert O.zstd_decompress(f, len(data)) == data
+    chunks = [data[i:i + 65536] for i in range(0, len(data), 65536)]
+    frames = _compress_many(codec, chunks, 3)
+    assert all(fr == O.compress(c, 3) for fr, c in zip(frames, chunks)) and len(frames[0]) == 11
+    assert all(g == (65536, c) for g, c in zip(_decompress_many(codec, frames, [65536] * 16), chunks))
+
+
+_CHILD = r'''
+import sys, os, numpy as np
+sys.path.insert(0, sys.argv[1]); sys.path.insert(0, os.path.join(sys.argv[1], "tests"))
+import _oracle as O, _data as D
+from zstandard_amd import BatchCodec
+ERR = 0xFFFFFF88
+bc = BatchCodec()
+data = D.zipf_log(24 << 20, seed_lo=4242)
+rng = np.random.default_rng(21)
+# 150 chunks of 0 .. 3 blocks: the compress sub-batch loop (> 64 blocks in flight) turns over several times and meets chunks of
+# every block count at the boundaries; 150 frames, then 700 small frames: the decode launch loop (> 64 items in flight)
+sizes = np.concatenate([rng.integers(0, 190000, 150), [65536] * 70, [131072] * 10]).astype(np.uint32)
+offs = np.zeros(len(sizes), dtype=np.uint64); offs[1:] = np.cumsum(sizes.astype(np.uint64))[:-1]
+assert int(offs[-1]) + int(sizes[-1]) <= len(data)
+for level in (3, 1):
+    arena, do, dsz = bc.compress_host(data, offs, sizes, level)
+    assert (dsz < ERR).all()
+    ea, eo, es = O.compress_batch(data, offs, sizes, level, 8)
+    assert (dsz == es).all(), np.nonzero(dsz != es)[0][:5]
+    for i in range(len(sizes)):
+        assert (arena[int(do[i]):int(do[i]) + int(dsz[i])] == ea[int(eo[i]):int(eo[i]) + int(es[i])]).all(), i
+frames = np.concatenate([arena[int(do[i]):int(do[i]) + int(dsz[i])] for i in range(len(sizes))])
+fo = np.zeros(len(sizes), dtype=np.uint64); fo[1:] = np.cumsum(dsz.astype(np.uint64))[:-1]
+out, oo, osz = bc.decompress_host(frames, fo, dsz, np.maximum(sizes, 1))
+assert (osz == sizes).all()
+for i in range(len(sizes)):
+    assert (out[int(oo[i]):int(oo[i]) + int(sizes[i])] == data[int(offs[i]):int(offs[i]) + int(sizes[i])]).all(), i
+small = rng.integers(1, 5000, 700).astype(np.uint32)
+so = np.zeros(len(small), dtype=np.uint64); so[1:] = np.cumsum(small.astype(np.uint64))[:-1]
+a2, d2, s2 = bc.compress_host(data, so, small, 3)
+fr = np.concatenate([a2[int(d2[i]):int(d2[i]) + int(s2[i])] for i in range(len(small))])
+f2 = np.zeros(len(small), dtype=np.uint64); f2[1:] = np.cumsum(s2.astype(np.uint64))[:-1]
+# every 7th frame damaged: its status must be the oracle's error code, its neighbours untouched
+frd = fr.copy()
+for i in range(0, len(small), 7):
+    if s2[i] > 12: frd[int(f2[i]) + int(s2[i]) // 2] ^= 0x5A
+out2, o2, z2 = bc.decompress_host(frd, f2, s2, small)
+for i in range(len(small)):
+    fb = frd[int(f2[i]):int(f2[i]) + int(s2[i])].tobytes()
+    try:
+        want = O.decompress(fb, int(small[i])); code = 0
+    except O.OracleError as e:
+        want = None; code = e.code
+    if code: assert int(z2[i]) == (1 << 32) - code, (i, hex(int(z2[i])), code)
+    else: assert int(z2[i]) == len(want) and out2[int(o2[i]):int(o2[i]) + len(want)].tobytes() == want, i
+print("CHILD-OK")
+'''
+
+
+def test_in_flight_limits_cross_both_ways():
+    """ZSMI_BLOCKS_IN_FLIGHT=64 / ZSMI_ITEMS_IN_FLIGHT=64 in a child process: the compress sub-batch loop and the decode
+    launch loop (zsmi_api.hip) run many turns on a small batch; every item compared with the oracle"""
+    import subprocess
+    env = dict(os.environ, ZSMI_BLOCKS_IN_FLIGHT="64", ZSMI_ITEMS_IN_FLIGHT="64")
+    r = subprocess.run([sys.executable, "-c", _CHILD, ROOT], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "CHILD-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
