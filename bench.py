@@ -9,7 +9,11 @@ A step = one pass of the compress path (candidates -> walk -> entropy -> frame a
 64 KiB chunks, level 3); the Silesia corpus is not available offline, so the chunks come from the synthetic
 Zipf-token log stream of SURVEY.md 8(d) unless --corpus PATH is given.  Chunks shard across ranks with no
 data-path collective (weak scaling: every GPU gets its own --chunks chunks).
-Rank 0 prints one JSON line.
+Rank 0 prints one JSON line.  The same line carries "decode" (BASELINE config 4 shape: many ~32 KiB frames, the one path the
+reference implements itself), "ratio_by_class" (HIP encoder vs upstream libzstd on the mixed corpus of tests/_corpus.py) and
+"libzstd_yardstick" (upstream libzstd on the host cores: NOT the reference, which has no encoder and cannot run here).
+
+--gpus N without a torch.distributed environment (no WORLD_SIZE) starts the N ranks itself, before anything touches the GPU.
 """
 import argparse, ctypes, json, os, sys, time
 import numpy as np
@@ -36,12 +40,112 @@ def usable_cores():
     return min(n, 64)
 
 
+def source_fingerprint():
+    """sha256 over the kernel sources: profiles/*_traffic.json carries the one it was measured at"""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "zstandard_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def self_launch(args):
+    """--gpus N given, no rank environment: run the N ranks under torch.distributed.run (one process per GPU) and pass its
+    output through.  Nothing in this process has touched the GPU yet."""
+    import subprocess
+    port = os.environ.get("MASTER_PORT", str(29500 + os.getpid() % 2000))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd)
+
+
+def threaded(fn, items, threads):
+    """ctypes calls release the GIL: a thread pool keeps `threads` host cores busy"""
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(threads) as ex:
+        return list(ex.map(fn, items))
+
+
 def load_corpus(path, nbytes, rank):
     data = np.fromfile(path, dtype=np.uint8)
     if len(data) == 0:
         raise SystemExit("empty corpus")
     reps = (nbytes + len(data) - 1) // len(data)
     return np.tile(data, reps)[:nbytes]
+
+
+def decode_leg(bc, args, rank, world, distributed, barrier, torch, dist):
+    """BASELINE config 4 shape: nf frames of ~32 KiB (level-3 output of this codec's encoder, built on the device), decoded
+    per step; timed like the compress leg (barrier + synchronize on both sides, max over ranks); the whole output is compared
+    with the input after the timed region.  Returns the "decode" object (rank 0) or None."""
+    import _data as D, _oracle as O
+    nf, fs = args.decode_frames, args.decode_frame_size
+    host = D.zipf_log(nf * fs, seed_lo=0xDEC0DE + 7919 * rank, threads=min(32, os.cpu_count() or 1))
+    d_src = torch.from_numpy(host).cuda()
+    bound = int(bc.L.zsmi_compressBound(fs)); stride = (bound + 255) // 256 * 256
+    d_frames = torch.empty(nf * stride, dtype=torch.uint8, device="cuda"); d_fsz = torch.zeros(nf, dtype=torch.int32, device="cuda")
+    offs = np.arange(nf, dtype=np.uint64) * fs; sizes = np.full(nf, fs, dtype=np.uint32); foffs = np.arange(nf, dtype=np.uint64) * stride
+    bc.compress_device(d_src.data_ptr(), offs, sizes, d_frames.data_ptr(), foffs, d_fsz.data_ptr(), 3)
+    torch.cuda.synchronize()
+    fsz = d_fsz.cpu().numpy().astype(np.uint32)
+    assert (fsz < 0xFFFFFF88).all()
+    d_out = torch.empty(nf * fs, dtype=torch.uint8, device="cuda"); d_osz = torch.zeros(nf, dtype=torch.int32, device="cuda")
+
+    def step():
+        bc.decompress_device(d_frames.data_ptr(), foffs, fsz, d_out.data_ptr(), offs, sizes, d_osz.data_ptr())
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    bc.enable_timing(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    kt = bc.kernel_times()
+    bc.enable_timing(False)
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert (d_osz.cpu().numpy() == fs).all(), "a frame failed to decode"
+    assert torch.equal(d_out, d_src), "decoded bytes differ from the input"
+    if rank != 0:
+        return None
+    comp = int(fsz.astype(np.uint64).sum())
+    name, (secs, launches) = max(kt.items(), key=lambda kv: kv[1][0])
+    per_launch = (nf * fs + comp) * args.steps / launches
+    roof = {"bound": "hbm", "kernel": name, "achieved": round(per_launch / (secs / launches) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(per_launch / (secs / launches) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(per_launch),
+            "avg_launch_ms": round(secs / launches * 1e3, 4), "kernels_ms_per_step": {k: round(v[0] / args.steps * 1e3, 4) for k, v in kt.items()}}
+    out = {"metric": f"GiB/s decompress (output bytes), frames of {fs} B", "value": round(nf * fs * world * args.steps / elapsed / (1 << 30), 3), "unit": "GiB/s",
+           "frames_per_gpu_per_step": nf, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "verified": "whole output equals the input (torch.equal) after the timed region",
+           "roofline": roof}
+    if not args.no_cpu_baseline:
+        cores = usable_cores(); m = min(nf, 4096)
+        fr = d_frames[:m * stride].cpu().numpy(); L = O.lib(); vp = ctypes.c_void_p
+        dst = np.empty(m * fs, dtype=np.uint8); dsz = np.zeros(m, dtype=np.uint32)
+        best = None
+        for _ in range(2):
+            t1 = time.perf_counter()
+            L.zso_decompressBatch(dst.ctypes.data_as(vp), offs[:m].ctypes.data_as(vp), sizes[:m].ctypes.data_as(vp), dsz.ctypes.data_as(vp), fr.ctypes.data_as(vp),
+                                  foffs[:m].ctypes.data_as(vp), fsz[:m].ctypes.data_as(vp), m, cores)
+            d = time.perf_counter() - t1; best = d if best is None else min(best, d)
+        assert (dst == host[:m * fs]).all()
+        out["cpu_baseline"] = {"value": round(m * fs / best / (1 << 30), 3), "unit": "GiB/s", "cores": cores, "kind": "port",
+                               "sample": f"{m} of the same frames, oracle D (C restatement of the reference's C# decoder), one thread per core"}
+        Z = O.libzstd()
+        if Z and not args.no_extras:
+            t1 = time.perf_counter()
+            rc = L.zso_libzstdDecompressBatch(dst.ctypes.data_as(vp), offs[:m].ctypes.data_as(vp), sizes[:m].ctypes.data_as(vp), dsz.ctypes.data_as(vp), fr.ctypes.data_as(vp),
+                                              foffs[:m].ctypes.data_as(vp), fsz[:m].ctypes.data_as(vp), m, cores)
+            d = time.perf_counter() - t1
+            assert rc == 0 and (dst == host[:m * fs]).all()
+            out["libzstd_yardstick"] = {"value": round(m * fs / d / (1 << 30), 3), "unit": "GiB/s", "cores": cores,
+                                        "label": "upstream libzstd %d ZSTD_decompress on the same frames, NOT the reference" % Z.ZSTD_versionNumber()}
+    return out
 
 
 def main():
@@ -57,11 +161,29 @@ def main():
     ap.add_argument("--with-io", action="store_true", help="also time the job that starts and ends on rank 0: scatter shards, compress, pack, gather frames "
                     "(SURVEY 8e steps 1-4); reported as io_inclusive, never as value")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank: exercises the N > 1 code path on a 1-GPU box")
+    ap.add_argument("--decode-frames", type=int, default=57344, help="frames of --decode-frame-size bytes decoded per step of the decode leg (0: no decode leg)")
+    ap.add_argument("--decode-frame-size", type=int, default=32768)
+    ap.add_argument("--no-extras", action="store_true", help="skip ratio_by_class and libzstd_yardstick")
+    ap.add_argument("--dry-run-gloo", action="store_true", help="CPU rehearsal of the launch path: gloo process group, no GPU work; prints the ranks that ran")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
 
     import torch
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus or (args.gpus == 1 and args.force_dist), f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU"
     distributed = world > 1 or args.force_dist
+    if args.dry_run_gloo:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", str(rank)); os.environ.setdefault("WORLD_SIZE", str(world))
+        dist.init_process_group(backend="gloo")
+        ranks = [None] * world
+        dist.all_gather_object(ranks, {"rank": rank, "pid": os.getpid()})
+        if rank == 0:
+            print(json.dumps({"dry_run": "gloo", "n_gpus": world, "ranks": ranks}))
+        dist.destroy_process_group()
+        return
     torch.cuda.set_device(local_rank)
     if distributed:
         import torch.distributed as dist
@@ -147,6 +269,8 @@ def main():
         io_inclusive = {"value": round(n * world * cs / best / (1 << 30), 3), "unit": "GiB/s", "ms": round(best * 1e3, 3), "frames_decode": ok,
                         "note": "rank 0 input -> scatter (grouped send/recv) -> compress -> pack -> all-gather sizes -> gather frames to rank 0; device memory only"}
 
+    decode = decode_leg(bc, args, rank, world, distributed, barrier, torch, dist if distributed else None) if args.decode_frames else None
+
     csz = d_sizes.cpu().numpy().astype(np.uint32)
     assert (csz < 0xFFFFFF88).all(), "a chunk failed to compress"
     comp_bytes = int(csz.astype(np.uint64).sum())
@@ -166,18 +290,25 @@ def main():
             per_launch_bytes = (nbytes + comp_bytes) * args.steps / launches
             avg = secs / launches
             achieved = per_launch_bytes / avg / 1e9
-            # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE), scaled to this launch size
-            traffic = None
+            # HBM bytes per launch of that kernel from the committed PMC passes (FETCH_SIZE + WRITE_SIZE), scaled to this launch size.
+            # The file names the kernel sources it was measured at: other sources -> null.
+            traffic = None; traffic_note = None
             try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r1_traffic.json")))["kernels"].get(name)
-                if tj:
-                    traffic = int(tj["hbm_bytes"] * (n * args.steps / launches) / tj["blocks_per_launch"])
-            except Exception:
-                traffic = None
+                tjf = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
+                if tjf.get("kernel_source_sha256") != source_fingerprint():
+                    traffic_note = "profiles/r2_traffic.json was measured at other kernel sources (%s): not reported" % tjf.get("kernel_source_sha256")
+                else:
+                    tj = tjf["kernels"].get(name)
+                    if tj:
+                        traffic = int(tj["hbm_bytes"] * (n * args.steps / launches) / tj["blocks_per_launch"])
+            except Exception as e:
+                traffic_note = "no traffic file: %s" % type(e).__name__
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch_bytes),
                         "avg_launch_ms": round(avg * 1e3, 4),
                         "kernels_ms_per_step": {k: round(v[0] / args.steps * 1e3, 4) for k, v in ktimes.items()}}
+            if traffic_note:
+                roofline["traffic_note"] = traffic_note
         # exactness spot check of the timed output + ratio yardstick
         import _oracle as O
         sample = list(range(0, n, max(1, n // 16)))[:16]
@@ -208,13 +339,38 @@ def main():
         metric = "GiB/s compress @ level 3, 64 KiB chunks" if (args.level == 3 and cs == 65536) else f"GiB/s compress @ level {args.level}, {cs // 1024} KiB chunks"
         out = {"metric": metric, "value": round(value, 3), "unit": "GiB/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True,
-               "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": data_label,
+               "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": data_label, "ranks": world,
                "config": {"workload": f"{n} independent {cs} B chunks per GPU per step, level {args.level}, BASELINE config[1] shape "
                                       f"(Silesia unavailable offline -> Zipf-token log stream, SURVEY 8d)", "chunks_per_gpu": n,
                           "chunk_bytes": cs, "level": args.level, "parallelism": f"chunks sharded over {world} GPU(s), no collective in the data path"},
                "ratio": round(ratio, 4), "ratio_vs_libzstd_same_level": ratio_vs_zstd,
                "hbm_read_roofline_frac": round(total_in * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
                "roofline": roofline, "cpu_baseline": cpu, "datagen_s": round(gen_s, 2)}
+        if decode:
+            out["decode"] = decode
+        Z = O.libzstd()
+        if Z and not args.no_extras:
+            # the ratio contract per data class (tests/_corpus.py), HIP encoder vs upstream libzstd at this level and chunk size
+            import _corpus as C
+            rb = {}
+            for cname, cdata in C.corpus(1 << 20).items():
+                buf = np.frombuffer(cdata, dtype=np.uint8)
+                co = np.arange(0, len(cdata), cs, dtype=np.uint64); csizes = np.minimum(len(cdata) - co, cs).astype(np.uint32)
+                _, _, cz = bc.compress_host(buf, co, csizes, args.level)
+                zz = sum(len(O.zstd_compress(cdata[int(o):int(o) + int(k)], args.level)) for o, k in zip(co, csizes))
+                rb[cname] = round(int(cz.astype(np.uint64).sum()) / zz, 4)
+            out["ratio_by_class"] = {"ours_over_libzstd_compressed_size": rb, "worst": max(rb.values()), "tolerance": 1.01,
+                                     "note": "1 MiB per class, %d B chunks, level %d; < 1: smaller than libzstd" % (cs, args.level)}
+            if not args.no_cpu_baseline:
+                cores = usable_cores(); m = min(n, max(256, 32 * cores))
+                zb = np.empty(m * stride, dtype=np.uint8); zs = np.zeros(m, dtype=np.uint32); vp = ctypes.c_void_p
+                t1 = time.perf_counter()
+                rc = O.lib().zso_libzstdCompressBatch(zb.ctypes.data_as(vp), doffs[:m].ctypes.data_as(vp), zs.ctypes.data_as(vp), host.ctypes.data_as(vp),
+                                                      offs[:m].ctypes.data_as(vp), sizes[:m].ctypes.data_as(vp), m, args.level, cores)
+                d = time.perf_counter() - t1
+                assert rc == 0
+                out["libzstd_yardstick"] = {"value": round(m * cs / d / (1 << 30), 3), "unit": "GiB/s", "cores": cores,
+                                            "label": "upstream libzstd %d ZSTD_compress level %d on %d chunks of the same batch, NOT the reference (which has no encoder)" % (Z.ZSTD_versionNumber(), args.level, m)}
         if io_inclusive:
             out["io_inclusive"] = io_inclusive
         print(json.dumps(out))

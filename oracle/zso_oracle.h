@@ -43,6 +43,13 @@ int zso_compressBatch(void *dst, const uint64_t *dstOffsets, uint32_t *dstSizes,
 int zso_decompressBatch(void *dst, const uint64_t *dstOffsets, const uint32_t *dstCaps, uint32_t *dstSizes,
                         const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
                         uint32_t n, int nThreads);
+/* the same drivers over upstream libzstd loaded with dlopen (a labelled yardstick, NOT the reference); -2: no libzstd.so.1 */
+int zso_libzstdCompressBatch(void *dst, const uint64_t *dstOffsets, uint32_t *dstSizes,
+                             const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                             uint32_t n, int level, int nThreads);
+int zso_libzstdDecompressBatch(void *dst, const uint64_t *dstOffsets, const uint32_t *dstCaps, uint32_t *dstSizes,
+                               const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
+                               uint32_t n, int nThreads);
 #ifdef __cplusplus
 }
 #endif
