@@ -37,7 +37,7 @@ typedef uint64_t U64;
 /* [0..3] literals type basic/rle/compressed/repeat ; [4] 1-stream huf ; [5] 4-stream huf ; [6] direct weights ; [7] FSE weights
  * [8..11] LL mode basic/rle/compressed/repeat ; [12..15] OF ; [16..19] ML ; [20..22] block raw/rle/compressed
  * [23] frames ; [24] skippable ; [25] checksum ; [26] blocks with nbSeq==0 ; [27] long nbSeq (>=0x7F00) ; [28] repcode used ; [29] multi-block frame */
-static uint32_t g_stats[40];   /* [30] sequences [31] literals [32] literal-section bytes [33] sequence-section bytes */
+static uint32_t g_stats[40];   /* [30] sequences [31] literals [32] literal-section bytes [33] sequence-section bytes [34] literal sections decoded by the double-symbol (X4) Huffman decoder */
 void zso_statsReset(void) { memset(g_stats, 0, sizeof g_stats); }
 void zso_statsGet(uint32_t *out) { memcpy(out, g_stats, 32 * sizeof(uint32_t)); }
 void zso_statsGet40(uint32_t *out) { memcpy(out, g_stats, sizeof g_stats); }
@@ -410,13 +410,15 @@ static size_t HUF_readStats(BYTE *huffWeight, size_t hwSize, U32 *rankStats, U32
 }
 
 /* ======================================================================= *
- *  HufDecompress.cs : single-symbol table + 1/4-stream decode.
- *  The reference may pick its double-symbol decoder for speed
- *  (SelectDecoder, HufDecompress.cs:1082-1095); both produce the same bytes
- *  from a well-formed stream, so only the single-symbol form is restated.
+ *  HufDecompress.cs : single-symbol ("X2") and double-symbol ("X4") tables, 1/4-stream decoders, and the choice between
+ *  them (SelectDecoder, HufDecompress.cs:1082-1095).  Both decoders produce the same bytes from a well-formed stream;
+ *  they differ in where a damaged stream is caught, so the reference's dispatch is kept: a new table with 4 streams goes
+ *  through SelectDecoder, a new table with 1 stream is always X2 (ZStdDecompress.cs:737), a repeated table is decoded
+ *  by the decoder that built it (tableType, HufDecompress.cs:1179-1205), a dictionary's table is X4 (LoadEntropy :2391).
  * ======================================================================= */
 typedef struct { BYTE byte; BYTE nbBits; } HUF_DElt;                          /* HufDecompress.cs:109-113 */
-typedef struct { U32 tableLog; int valid; HUF_DElt dt[1 << HUF_TABLELOG_MAX]; } HUF_DTable;
+typedef struct { U16 sequence; BYTE nbBits; BYTE length; } HUF_DEltX4;        /* HufDecompress.cs:190-195 */
+typedef struct { U32 tableLog; int valid; int tableType; HUF_DElt dt[1 << HUF_TABLELOG_MAX]; HUF_DEltX4 dx[1 << HUF_TABLELOG_MAX]; } HUF_DTable;
 
 /* HufDecompress.cs:117-180 */
 static size_t HUF_readDTable(HUF_DTable *D, const void *src, size_t srcSize)
@@ -427,7 +429,7 @@ static size_t HUF_readDTable(HUF_DTable *D, const void *src, size_t srcSize)
     size_t const iSize = HUF_readStats(huffWeight, HUF_SYMBOLVALUE_MAX + 1, rankVal, &nbSymbols, &tableLog, src, srcSize);
     if (zso_isError(iSize)) return iSize;
     if (tableLog > HUF_TABLELOG_MAX + 1) return ERR(ZSO_tableLog_tooLarge);
-    D->tableLog = tableLog;
+    D->tableLog = tableLog; D->tableType = 0;
     { U32 n, nextRankStart = 0;
       for (n = 1; n < tableLog + 1; n++) { U32 const cur = nextRankStart; nextRankStart += rankVal[n] << (n - 1); rankVal[n] = cur; } }
     { U32 n;
@@ -517,6 +519,227 @@ static size_t HUF_decompress4X(BYTE *dst, size_t dstSize, const void *cSrc, size
         if (!(BIT_end(&b1) & BIT_end(&b2) & BIT_end(&b3) & BIT_end(&b4))) return ERR(ZSO_corruption_detected);
         return dstSize;
     }
+}
+
+/* ---- double-symbol decoder ---- */
+typedef struct { BYTE symbol; BYTE weight; } sortedSymbol_t;                   /* HufDecompress.cs:687-691 */
+
+/* HufDecompress.cs:695-741 */
+static void HUF_fillDTableX4Level2(HUF_DEltX4 *DTable, U32 sizeLog, U32 consumed, const U32 *rankValOrigin, int minWeight,
+                                   const sortedSymbol_t *sortedSymbols, U32 sortedListSize, U32 nbBitsBaseline, U16 baseSeq)
+{
+    HUF_DEltX4 DElt;
+    U32 rankVal[HUF_TABLELOG_MAX + 1];
+    memcpy(rankVal, rankValOrigin, sizeof rankVal);
+    if (minWeight > 1) {
+        U32 i, skipSize = rankVal[minWeight];
+        DElt.sequence = baseSeq; DElt.nbBits = (BYTE)consumed; DElt.length = 1;
+        for (i = 0; i < skipSize; i++) DTable[i] = DElt;
+    }
+    {
+        U32 s2;
+        for (s2 = 0; s2 < sortedListSize; s2++) {
+            U32 const symbol = sortedSymbols[s2].symbol, weight = sortedSymbols[s2].weight;
+            U32 const nbBits = nbBitsBaseline - weight;
+            U32 const length = 1u << (sizeLog - nbBits);
+            U32 const start = rankVal[weight];
+            U32 i = start;
+            U32 const end = start + length;
+            DElt.sequence = (U16)(baseSeq + (symbol << 8)); DElt.nbBits = (BYTE)(nbBits + consumed); DElt.length = 2;
+            do { DTable[i++] = DElt; } while (i < end);
+            rankVal[weight] += length;
+        }
+    }
+}
+
+/* HufDecompress.cs:761-808 */
+static void HUF_fillDTableX4(HUF_DEltX4 *DTable, U32 targetLog, const sortedSymbol_t *sortedList, U32 sortedListSize,
+                             const U32 *rankStart, const U32 *rankValOrigin, U32 maxWeight, U32 nbBitsBaseline)
+{
+    U32 rankVal[HUF_TABLELOG_MAX + 1];
+    int const scaleLog = (int)(nbBitsBaseline - targetLog);
+    U32 const minBits = nbBitsBaseline - maxWeight;
+    U32 s2;
+    memcpy(rankVal, rankValOrigin, sizeof rankVal);
+    for (s2 = 0; s2 < sortedListSize; s2++) {
+        U16 const symbol = sortedList[s2].symbol;
+        U32 const weight = sortedList[s2].weight;
+        U32 const nbBits = nbBitsBaseline - weight;
+        U32 const start = rankVal[weight];
+        U32 const length = 1u << (targetLog - nbBits);
+        if (targetLog - nbBits >= minBits) {
+            U32 sortedRank;
+            int minWeight = (int)nbBits + scaleLog;
+            if (minWeight < 1) minWeight = 1;
+            sortedRank = rankStart[minWeight];
+            HUF_fillDTableX4Level2(DTable + start, targetLog - nbBits, nbBits, rankValOrigin + nbBits * (HUF_TABLELOG_MAX + 1), minWeight,
+                                   sortedList + sortedRank, sortedListSize - sortedRank, nbBitsBaseline, symbol);
+        } else {
+            HUF_DEltX4 DElt; U32 u; U32 const end = start + length;
+            DElt.sequence = symbol; DElt.nbBits = (BYTE)nbBits; DElt.length = 1;
+            for (u = start; u < end; u++) DTable[u] = DElt;
+        }
+        rankVal[weight] += length;
+    }
+}
+
+/* HufDecompress.cs:813-925 ; the table is always laid out for maxTableLog = HUF_TABLELOG_MAX (hufTable[0] = 12 * 0x1000001, ZStdDecompress.cs:2488) */
+static size_t HUF_readDTableX4(HUF_DTable *D, const void *src, size_t srcSize)
+{
+    U32 const maxTableLog = HUF_TABLELOG_MAX;
+    U32 rankVal[HUF_TABLELOG_MAX][HUF_TABLELOG_MAX + 1];
+    U32 rankStats[HUF_TABLELOG_MAX + 1 + 3];
+    U32 rankStart0[HUF_TABLELOG_MAX + 2];
+    U32 *const rankStart = rankStart0 + 1;
+    sortedSymbol_t sortedSymbol[HUF_SYMBOLVALUE_MAX + 1];
+    BYTE weightList[HUF_SYMBOLVALUE_MAX + 1];
+    U32 tableLog = 0, maxW, sizeOfSort, nbSymbols = 0;
+    size_t iSize;
+    memset(rankVal, 0, sizeof rankVal); memset(rankStats, 0, sizeof rankStats); memset(rankStart0, 0, sizeof rankStart0);
+    iSize = HUF_readStats(weightList, HUF_SYMBOLVALUE_MAX + 1, rankStats, &nbSymbols, &tableLog, src, srcSize);
+    if (zso_isError(iSize)) return iSize;
+    if (tableLog > maxTableLog) return ERR(ZSO_tableLog_tooLarge);
+    for (maxW = tableLog; rankStats[maxW] == 0; maxW--) {}
+    {
+        U32 w, nextRankStart = 0;
+        for (w = 1; w < maxW + 1; w++) { U32 const cur = nextRankStart; nextRankStart += rankStats[w]; rankStart[w] = cur; }
+        rankStart[0] = nextRankStart;
+        sizeOfSort = nextRankStart;
+    }
+    {
+        U32 s2;
+        for (s2 = 0; s2 < nbSymbols; s2++) {
+            U32 const w = weightList[s2];
+            U32 const r = rankStart[w]++;
+            sortedSymbol[r].symbol = (BYTE)s2; sortedSymbol[r].weight = (BYTE)w;
+        }
+        rankStart[0] = 0;
+    }
+    {
+        U32 *const rankVal0 = rankVal[0];
+        {
+            int const rescale = (int)(maxTableLog - tableLog) - 1;
+            U32 nextRankVal = 0, w;
+            for (w = 1; w < maxW + 1; w++) { U32 const cur = nextRankVal; nextRankVal += rankStats[w] << (w + rescale); rankVal0[w] = cur; }
+        }
+        {
+            U32 const minBits = tableLog + 1 - maxW;
+            U32 consumed;
+            for (consumed = minBits; consumed < maxTableLog - minBits + 1; consumed++) {
+                U32 *const rankValPtr = rankVal[consumed];
+                U32 w;
+                for (w = 1; w < maxW + 1; w++) rankValPtr[w] = rankVal0[w] >> consumed;
+            }
+        }
+    }
+    HUF_fillDTableX4(D->dx, maxTableLog, sortedSymbol, sizeOfSort, rankStart0, &rankVal[0][0], maxW, tableLog + 1);
+    D->tableLog = maxTableLog; D->tableType = 1;
+    return iSize;
+}
+
+/* HufDecompress.cs:361-367 ; the reference copies two bytes whatever the length */
+static U32 HUF_decodeSymbolX4(BYTE *op, BIT_D *b, const HUF_DEltX4 *dt, U32 dtLog)
+{
+    U32 const val = BIT_lookFast(b, dtLog);
+    op[0] = (BYTE)dt[val].sequence; op[1] = (BYTE)(dt[val].sequence >> 8);
+    BIT_skip(b, dt[val].nbBits);
+    return dt[val].length;
+}
+/* HufDecompress.cs:369-385 */
+static U32 HUF_decodeLastSymbolX4(BYTE *op, BIT_D *b, const HUF_DEltX4 *dt, U32 dtLog)
+{
+    U32 const val = BIT_lookFast(b, dtLog);
+    op[0] = (BYTE)dt[val].sequence;
+    if (dt[val].length == 1) BIT_skip(b, dt[val].nbBits);
+    else if (b->bitsConsumed < CONTAINER_BYTES * 8) {
+        BIT_skip(b, dt[val].nbBits);
+        if (b->bitsConsumed > CONTAINER_BYTES * 8) b->bitsConsumed = CONTAINER_BYTES * 8;
+    }
+    return 1;
+}
+/* HufDecompress.cs:405-428 ; 32-bit mode: SYMBOLX4_2 is a no-op, SYMBOLX4_1 active (HUF_TABLELOG_MAX <= 12) */
+static void HUF_decodeStreamX4(BYTE *p, BIT_D *b, BYTE *pEnd, const HUF_DEltX4 *dt, U32 dtLog)
+{
+    while ((BIT_reload(b) == BIT_unfinished) & (p + (CONTAINER_BYTES - 1) < pEnd)) {
+        p += HUF_decodeSymbolX4(p, b, dt, dtLog);   /* _1 */
+        p += HUF_decodeSymbolX4(p, b, dt, dtLog);   /* _0 */
+    }
+    while ((BIT_reload(b) == BIT_unfinished) & (p + 2 <= pEnd)) p += HUF_decodeSymbolX4(p, b, dt, dtLog);
+    while (p + 2 <= pEnd) p += HUF_decodeSymbolX4(p, b, dt, dtLog);
+    if (p < pEnd) p += HUF_decodeLastSymbolX4(p, b, dt, dtLog);
+}
+/* HufDecompress.cs:430-453 */
+static size_t HUF_decompress1X4(BYTE *dst, size_t dstSize, const void *cSrc, size_t cSrcSize, const HUF_DTable *D)
+{
+    BIT_D bitD;
+    { size_t const e = BIT_init(&bitD, cSrc, cSrcSize); if (zso_isError(e)) return e; }
+    HUF_decodeStreamX4(dst, &bitD, dst + dstSize, D->dx, D->tableLog);
+    if (!BIT_end(&bitD)) return ERR(ZSO_corruption_detected);
+    return dstSize;
+}
+/* HufDecompress.cs:455-542.  Unlike the X2 body, this loop refreshes endSignal (:513). */
+static size_t HUF_decompress4X4(BYTE *dst, size_t dstSize, const void *cSrc, size_t cSrcSize, const HUF_DTable *D)
+{
+    if (cSrcSize < 10) return ERR(ZSO_corruption_detected);
+    {
+        const BYTE *const istart = (const BYTE *)cSrc;
+        BYTE *const ostart = dst;
+        BYTE *const oend = ostart + dstSize;
+        const HUF_DEltX4 *const dt = D->dx;
+        U32 const dtLog = D->tableLog;
+        BIT_D b1, b2, b3, b4;
+        size_t const length1 = rdLE16(istart), length2 = rdLE16(istart + 2), length3 = rdLE16(istart + 4);
+        size_t const length4 = cSrcSize - (length1 + length2 + length3 + 6);
+        const BYTE *const istart1 = istart + 6;
+        const BYTE *const istart2 = istart1 + length1;
+        const BYTE *const istart3 = istart2 + length2;
+        const BYTE *const istart4 = istart3 + length3;
+        size_t const segmentSize = (dstSize + 3) / 4;
+        BYTE *const opStart2 = ostart + segmentSize;
+        BYTE *const opStart3 = opStart2 + segmentSize;
+        BYTE *const opStart4 = opStart3 + segmentSize;
+        BYTE *op1 = ostart, *op2 = opStart2, *op3 = opStart3, *op4 = opStart4;
+        U32 endSignal;
+        if (length4 > cSrcSize) return ERR(ZSO_corruption_detected);
+        { size_t const e = BIT_init(&b1, istart1, length1); if (zso_isError(e)) return e; }
+        { size_t const e = BIT_init(&b2, istart2, length2); if (zso_isError(e)) return e; }
+        { size_t const e = BIT_init(&b3, istart3, length3); if (zso_isError(e)) return e; }
+        { size_t const e = BIT_init(&b4, istart4, length4); if (zso_isError(e)) return e; }
+        if (opStart4 > oend) return ERR(ZSO_corruption_detected);   /* oracle safety: the reference would write out of bounds */
+        endSignal = (U32)BIT_reload(&b1) | (U32)BIT_reload(&b2) | (U32)BIT_reload(&b3) | (U32)BIT_reload(&b4);
+        /* streams 1-3 may run past their segment here (caught right after the loop): the literal buffer has the room */
+        while ((endSignal == BIT_unfinished) && ((size_t)(op4 - ostart) + (CONTAINER_BYTES - 1) < dstSize)) {
+            op1 += HUF_decodeSymbolX4(op1, &b1, dt, dtLog); op2 += HUF_decodeSymbolX4(op2, &b2, dt, dtLog);
+            op3 += HUF_decodeSymbolX4(op3, &b3, dt, dtLog); op4 += HUF_decodeSymbolX4(op4, &b4, dt, dtLog);
+            op1 += HUF_decodeSymbolX4(op1, &b1, dt, dtLog); op2 += HUF_decodeSymbolX4(op2, &b2, dt, dtLog);
+            op3 += HUF_decodeSymbolX4(op3, &b3, dt, dtLog); op4 += HUF_decodeSymbolX4(op4, &b4, dt, dtLog);
+            endSignal = (U32)BIT_reload(&b1) | (U32)BIT_reload(&b2) | (U32)BIT_reload(&b3) | (U32)BIT_reload(&b4);
+        }
+        if (op1 > opStart2) return ERR(ZSO_corruption_detected);
+        if (op2 > opStart3) return ERR(ZSO_corruption_detected);
+        if (op3 > opStart4) return ERR(ZSO_corruption_detected);
+        HUF_decodeStreamX4(op1, &b1, opStart2, dt, dtLog);
+        HUF_decodeStreamX4(op2, &b2, opStart3, dt, dtLog);
+        HUF_decodeStreamX4(op3, &b3, opStart4, dt, dtLog);
+        HUF_decodeStreamX4(op4, &b4, oend, dt, dtLog);
+        if (!(BIT_end(&b1) & BIT_end(&b2) & BIT_end(&b3) & BIT_end(&b4))) return ERR(ZSO_corruption_detected);
+        return dstSize;
+    }
+}
+
+/* HufDecompress.cs:1056-1095 : algoTime[Q][single, double] and SelectDecoder (0 = X2, 1 = X4) */
+static U32 HUF_selectDecoder(size_t dstSize, size_t cSrcSize)
+{
+    static const U32 algoTime[16][2][2] = {
+        {{0,0},{1,1}}, {{0,0},{1,1}}, {{38,130},{1313,74}}, {{448,128},{1353,74}}, {{556,128},{1353,74}}, {{714,128},{1418,74}},
+        {{883,128},{1437,74}}, {{897,128},{1515,75}}, {{926,128},{1613,75}}, {{947,128},{1729,77}}, {{1107,128},{2083,81}},
+        {{1177,128},{2379,87}}, {{1242,128},{2415,93}}, {{1349,128},{2644,106}}, {{1455,128},{2422,124}}, {{722,128},{1891,145}} };
+    U32 const Q = (cSrcSize >= dstSize) ? 15 : (U32)(cSrcSize * 16 / dstSize);
+    U32 const D256 = (U32)(dstSize >> 8);
+    U32 const DTime0 = algoTime[Q][0][0] + algoTime[Q][0][1] * D256;
+    U32 DTime1 = algoTime[Q][1][0] + algoTime[Q][1][1] * D256;
+    DTime1 += DTime1 >> 3;
+    return DTime1 < DTime0 ? 1u : 0u;
 }
 
 /* ======================================================================= *
@@ -677,18 +900,26 @@ static size_t decodeLiteralsBlock(DCtx *d, const void *src, size_t srcSize)
                 if (litSize > ZSTD_BLOCKSIZE_MAX) return ERR(ZSO_corruption_detected);
                 if (litCSize + lhSize > srcSize) return ERR(ZSO_corruption_detected);
                 STAT(singleStream ? 4 : 5);
-                if (litEncType == 3) {
-                    r = singleStream ? HUF_decompress1X(d->litBuffer, litSize, istart + lhSize, litCSize, &d->huf)
-                                     : HUF_decompress4X(d->litBuffer, litSize, istart + lhSize, litCSize, &d->huf);
+                if (litEncType == 3) {               /* HufDecompress.cs:1179-1205: the decoder that built the table */
+                    if (d->huf.tableType) r = singleStream ? HUF_decompress1X4(d->litBuffer, litSize, istart + lhSize, litCSize, &d->huf)
+                                                           : HUF_decompress4X4(d->litBuffer, litSize, istart + lhSize, litCSize, &d->huf);
+                    else r = singleStream ? HUF_decompress1X(d->litBuffer, litSize, istart + lhSize, litCSize, &d->huf)
+                                          : HUF_decompress4X(d->litBuffer, litSize, istart + lhSize, litCSize, &d->huf);
                 } else if (singleStream) {           /* HufDecompress.cs:1186-1197 */
                     size_t const hSize = HUF_readDTable(&d->huf, istart + lhSize, litCSize);
                     if (zso_isError(hSize)) r = hSize;
                     else if (hSize >= litCSize) r = ERR(ZSO_srcSize_wrong);
                     else r = HUF_decompress1X(d->litBuffer, litSize, istart + lhSize + hSize, litCSize - hSize, &d->huf);
-                } else {                             /* HufDecompress.cs:1208-1220 + :647-660 */
+                } else {                             /* HufDecompress.cs:1208-1220 (SelectDecoder) + :647-660 / :984-997 */
                     if (litSize == 0) r = ERR(ZSO_dstSize_tooSmall);
                     else if (litCSize == 0) r = ERR(ZSO_corruption_detected);
-                    else {
+                    else if (HUF_selectDecoder(litSize, litCSize)) {
+                        size_t const hSize = HUF_readDTableX4(&d->huf, istart + lhSize, litCSize);
+                        STAT(34);
+                        if (zso_isError(hSize)) r = hSize;
+                        else if (hSize >= litCSize) r = ERR(ZSO_srcSize_wrong);
+                        else r = HUF_decompress4X4(d->litBuffer, litSize, istart + lhSize + hSize, litCSize - hSize, &d->huf);
+                    } else {
                         size_t const hSize = HUF_readDTable(&d->huf, istart + lhSize, litCSize);
                         if (zso_isError(hSize)) r = hSize;
                         else if (hSize >= litCSize) r = ERR(ZSO_srcSize_wrong);
@@ -1084,9 +1315,8 @@ static size_t decompressFrame(DCtx *d, void *dst, size_t dstCapacity, const void
     return (size_t)(op - ostart);
 }
 
-/* LoadEntropy :2378-2450.  The reference reads the dictionary's Huffman table in the double-symbol layout (HUF_readDTableX4);
- * the symbols a table decodes do not depend on the layout, so the single-symbol table of this file is built from the same
- * description.  @return bytes read (magic and dictID included) or an error */
+/* LoadEntropy :2378-2450.  The dictionary's Huffman table is read in the double-symbol layout (HUF_readDTableX4_wksp, :2391): a block
+ * that repeats it is decoded by the X4 decoder.  @return bytes read (magic and dictID included) or an error */
 static size_t loadEntropy(DCtx *d, const void *dict, size_t dictSize)
 {
     const BYTE *dictPtr = (const BYTE *)dict;
@@ -1094,7 +1324,7 @@ static size_t loadEntropy(DCtx *d, const void *dict, size_t dictSize)
     S16 norm[MaxSeq + 1];
     if (dictSize <= 8) return ERR(ZSO_dictionary_corrupted);
     dictPtr += 8;
-    { size_t const hSize = HUF_readDTable(&d->huf, dictPtr, (size_t)(dictEnd - dictPtr));
+    { size_t const hSize = HUF_readDTableX4(&d->huf, dictPtr, (size_t)(dictEnd - dictPtr));
       if (zso_isError(hSize)) return ERR(ZSO_dictionary_corrupted);
       d->huf.valid = 1; dictPtr += hSize; }
     { U32 max = MaxOff, log; size_t const h = readNCount(norm, &max, &log, dictPtr, (size_t)(dictEnd - dictPtr));

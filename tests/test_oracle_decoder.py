@@ -3,7 +3,7 @@
      java/src/test/java/com/epam/deltix/zstd/TestDecompress.java:8-10), and
  (2) frames made by upstream libzstd 1.4.8 (tests/golden/gen_fixtures.py) for the constructs
      the reference's tests never reach.  CPU only."""
-import hashlib, os, struct
+import ctypes, hashlib, os, struct
 import numpy as np
 import pytest
 import _oracle as O
@@ -56,6 +56,27 @@ def test_fixture_coverage():
             26: "nbSeq==0", 27: ">= 0x7F00 sequences", 28: "repcode", 29: "multi-block"}
     missing = [v for k, v in must.items() if tot[k] == 0]
     assert not missing, missing
+
+
+def test_both_huffman_decoders_are_reached():
+    """the reference picks its single- or double-symbol Huffman decoder per literal section (SelectDecoder,
+    HufDecompress.cs:1082-1095); oracle D restates both and the dispatch.  The fixtures and this repo's own frames reach both."""
+    L = O.lib()
+    L.zso_statsGet40.argtypes = [ctypes.c_void_p]
+    def x4_and_huff(frames):
+        x4 = huf = 0
+        for frame, want in frames:
+            L.zso_statsReset()
+            assert O.decompress(frame, len(want)) == want
+            st = np.zeros(40, dtype=np.uint32); L.zso_statsGet40(st.ctypes.data_as(ctypes.c_void_p))
+            x4 += int(st[34]); huf += int(st[5])
+        return x4, huf
+    x4, huf = x4_and_huff(D.fixtures().values())
+    assert 0 < x4 < huf, (x4, huf)                       # some 4-stream sections by the X4 decoder, some by the X2 one
+    data = D.zipf_log(1 << 20).tobytes()
+    own = [(O.compress(data[i:i + 65536], 3), data[i:i + 65536]) for i in range(0, len(data), 65536)]
+    x4o, hufo = x4_and_huff(own)
+    assert hufo > 0
 
 
 def test_get_decompressed_size_semantics():

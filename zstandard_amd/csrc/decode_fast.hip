@@ -153,7 +153,7 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
         if (litCSizeTot > cSize) break;
         // ---- sequence headers + tables (:1110-1180), then the tables leave for the sequences kernel ----
         const uint8_t *ip = bs + litCSizeTot; uint32_t remaining = cSize - litCSizeTot, nbSeq = 0;
-        DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = 0; st.llRepeatOk = 0;
+        DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = 0; st.llRepeatOk = 0; st.hufX4 = 0;
         uint16_t *stab = reinterpret_cast<uint16_t *>(seqTabs + (size_t)item * ZS_FAST_SEQTAB_BYTES);
         if (lane < 3) L.misc[8 + lane] = 0;
         if (seqHeadersT<true>(L, st, ip, remaining, nbSeq, stab, &L.misc[8])) break;

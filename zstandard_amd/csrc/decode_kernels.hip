@@ -542,7 +542,70 @@ __device__ __forceinline__ uint32_t bc_take(BitC &b, uint32_t n)
 
 // the Huffman streams of one block (HufDecompress.cs:222-358): stream k on lane k (nStreams = 1 or 4), in rounds of
 // "stage ZS_LITWIN bytes of every stream, decode until a stream needs more".  8 decoded bytes go out per store.
-__device__ __forceinline__ bool hufDecodeStreams(DLds &L, uint32_t nStreams, uint8_t *out, uint32_t n, const uint8_t *src, uint32_t size, uint64_t *g_prof)
+// SelectDecoder (HufDecompress.cs:1056-1095): 1 = the reference takes its double-symbol decoder for a 4-stream section with a new table
+__device__ __forceinline__ uint32_t hufSelectDecoder(uint32_t dstSize, uint32_t cSrcSize)
+{
+    // algoTime[Q][single, double] = {tableTime, decode256Time}
+    const uint32_t t0[16] = { 0, 0, 38, 448, 556, 714, 883, 897, 926, 947, 1107, 1177, 1242, 1349, 1455, 722 };
+    const uint32_t d0[16] = { 0, 0, 130, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128, 128 };
+    const uint32_t t1[16] = { 1, 1, 1313, 1353, 1353, 1418, 1437, 1515, 1613, 1729, 2083, 2379, 2415, 2644, 2422, 1891 };
+    const uint32_t d1[16] = { 1, 1, 74, 74, 74, 74, 74, 75, 75, 77, 81, 87, 93, 106, 124, 145 };
+    const uint32_t Q = (cSrcSize >= dstSize) ? 15u : (uint32_t)((uint64_t)cSrcSize * 16 / dstSize);
+    const uint32_t D256 = dstSize >> 8;
+    uint32_t a0 = 0, b0 = 0, a1 = 0, b1 = 0;
+    #pragma unroll
+    for (uint32_t q = 0; q < 16; q++) if (q == Q) { a0 = t0[q]; b0 = d0[q]; a1 = t1[q]; b1 = d1[q]; }
+    const uint32_t DTime0 = a0 + b0 * D256;
+    uint32_t DTime1 = a1 + b1 * D256;
+    DTime1 += DTime1 >> 3;
+    return DTime1 < DTime0 ? 1u : 0u;
+}
+
+// The reference decodes a literal section with its single-symbol (X2) or its double-symbol (X4) Huffman decoder (SelectDecoder,
+// HufDecompress.cs:1082-1095; a repeated table: the decoder that built it; a dictionary's table: X4).  Both read the same symbols
+// from the same bits; they differ in one place: a stream's LAST symbol, when the X4 table entry found for it holds two symbols
+// (HUF_decodeLastSymbolX4, HufDecompress.cs:369-385): the entry's bits (both symbols') are skipped only if bits were left, and the
+// count is clamped at the stream's end -- so up to l1 + l2 unread bits pass where the X2 decoder asks for exactly l1; with no bit
+// left the lookup wraps to the top of the stream's first word and nothing is skipped.  The streams are decoded the X2 way here;
+// a stream of an X4 section that fails the strict end check is walked again (rare: damaged input only) with the X4 decoder's
+// grouping (a lookup takes two symbols when their lengths sum to <= 12 = its table log) to see whether its last symbol is taken
+// alone and what the entry holds.  Oracle: HUF_decodeStreamX4 / HUF_decodeLastSymbolX4 in oracle/zso_decoder.c.
+__device__ static bool hufX4TailAccepts(const uint16_t *huf, uint32_t dtLog, const uint8_t *src, uint32_t size, uint32_t n, uint8_t *out)
+{
+    if (size == 0 || src[size - 1] == 0 || n == 0) return false;
+    auto peek12 = [&](int32_t bp) -> uint32_t {                        // the 12 bits below unread-bit count bp; bits below the stream start read 0
+        const int32_t bh = (bp - 1) >> 3;
+        uint32_t w = 0;
+        for (int k = 0; k < 4; k++) { const int32_t q = bh - k; w |= (q >= 0 ? (uint32_t)src[q] : 0u) << (24 - 8 * k); }
+        return (w << (7u - (uint32_t)((bp - 1) & 7))) >> 20;
+    };
+    auto info = [&](uint32_t v, uint32_t &l1, uint32_t &both, uint32_t &sym) -> bool {   // the X4 entry at 12-bit index v
+        const uint32_t e1 = huf[v >> (12u - dtLog)]; l1 = e1 >> 8; sym = e1 & 0xFFu;
+        const uint32_t rest = (v << l1) & 0xFFFu;
+        const uint32_t e2 = huf[rest >> (12u - dtLog)];
+        both = l1 + (e2 >> 8);
+        return both <= 12u;
+    };
+    int32_t bp = (int32_t)(size * 8 - (8 - zs_highbit(src[size - 1])));
+    uint32_t i = 0, l1, both, sym;
+    while (i + 2 <= n) {
+        if (bp <= 0) return false;                                      // more than one symbol to go and no bit left: the count passes the end
+        if (info(peek12(bp), l1, both, sym)) { bp -= (int32_t)both; i += 2; } else { bp -= (int32_t)l1; i += 1; }
+    }
+    if (i == n) return bp == 0;
+    if (bp < 0) return false;
+    if (bp == 0) {                                                      // the lookup wraps: the top 12 bits of the stream's first word (BitStream.cs:412, shift & 31)
+        uint32_t c = 0;
+        for (uint32_t k = 0; k < 4 && k < size; k++) c |= (uint32_t)src[k] << (8 * k);
+        if (!info(c >> 20, l1, both, sym)) return false;                // a one-symbol entry is skipped: past the end
+        out[n - 1] = (uint8_t)sym;
+        return true;
+    }
+    if (info(peek12(bp), l1, both, sym)) return (uint32_t)bp <= both;
+    return (uint32_t)bp == l1;
+}
+
+__device__ __forceinline__ bool hufDecodeStreams(DLds &L, uint32_t nStreams, uint8_t *out, uint32_t n, const uint8_t *src, uint32_t size, bool useX4, uint64_t *g_prof)
 {
     (void)g_prof;
     const uint32_t lane = (uint32_t)zs_lane();
@@ -602,7 +665,9 @@ __device__ __forceinline__ bool hufDecodeStreams(DLds &L, uint32_t nStreams, uin
 #endif
         if (!__ballot(!done)) break;
     }
-    return !__ballot(mine && b.bitPos != 0);          // EndOfDStream (BitStream.cs:494): every bit consumed, none over-read
+    bool bad = mine && b.bitPos != 0;                  // EndOfDStream (BitStream.cs:494): every bit consumed, none over-read
+    if (useX4 && __ballot(bad)) { if (bad) bad = !hufX4TailAccepts(L.huf, dtLog, src, size, n, out); }
+    return !__ballot(bad);
 }
 
 // XXH64 seed 0 (XxHash.cs:896-1161), single lane
@@ -630,7 +695,7 @@ __device__ static uint64_t xxh64(const uint8_t *p, uint64_t len)
     return h64;
 }
 
-struct DState { uint32_t rep[3]; uint32_t litEntropy, fseEntropy; uint32_t llRepeatOk; };
+struct DState { uint32_t rep[3]; uint32_t litEntropy, fseEntropy; uint32_t llRepeatOk; uint32_t hufX4; };   // hufX4: the reference built the current Huffman table for its double-symbol decoder
 
 // ---- one tile of <= 64 decoded sequences (L.u.sq.tile*) -> output bytes.  Returns 0 or an error; advances op / litPos. ----
 #ifdef ZS_EXEC_PROFILE          // development aid (tools/exec_profile.py): s_memtime per phase of execTile, summed per item
@@ -909,6 +974,7 @@ __device__ __forceinline__ uint32_t decodeBlock(DLds &L, DState &st, uint8_t *ds
             if (type == 2) {
                 if (!single && litSize == 0) return ZE(E_corruption_detected);
                 if (!single && litCSize == 0) return ZE(E_corruption_detected);
+                st.hufX4 = single ? 0u : hufSelectDecoder(litSize, litCSize);      // ZStdDecompress.cs:737 (1 stream: X2) / HufDecompress.cs:1208-1220
                 const uint32_t h = readHufTable(L, cs, csz);
 #ifdef ZS_DEC_PROFILE
                 { const uint64_t now_ = __builtin_readcyclecounter(); if (g_prof) g_prof[6] += now_ - prof_t_; }
@@ -937,7 +1003,7 @@ __device__ __forceinline__ uint32_t decodeBlock(DLds &L, DState &st, uint8_t *ds
                 sCnt = sl < 3 ? seg : litSize - 3 * seg;
                 sOut = sl * seg;
             }
-            const bool ok = hufDecodeStreams(L, nStreams, litBuf + sOut, sCnt, cs + sOff, sLen, g_prof);
+            const bool ok = hufDecodeStreams(L, nStreams, litBuf + sOut, sCnt, cs + sOff, sLen, st.hufX4 != 0, g_prof);
             if (__ballot(!ok)) return ZE(E_corruption_detected);
             wave_mem_sync();
             litPtr = litBuf; st.litEntropy = 1; litCSizeTot = litCSize + lhSize;
@@ -1121,7 +1187,7 @@ k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
         if (fcsID == 0) { if (singleSegment) fcs = ip[pos]; } else if (fcsID == 1) fcs = rd16(ip + pos) + 256; else if (fcsID == 2) fcs = rd32(ip + pos); else fcs = zs_load64(ip + pos);
         if (singleSegment) windowSize = fcs;
         ipos += fhs;
-        DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = 0; st.llRepeatOk = 0;   // DecompressBegin :2478-2499
+        DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = 0; st.llRepeatOk = 0; st.hufX4 = 0;   // DecompressBegin :2478-2499
         const uint8_t *dictEnd = nullptr; uint32_t dictSize = 0, dictIDLoaded = 0;
         if (DICT && dict && dictBytes) {                             // ZSTD_decompress_insertDictionary :2452-2475
             const uint8_t *content = dict; uint32_t contentSize = dictBytes;
@@ -1129,7 +1195,7 @@ k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
                 dictIDLoaded = rd32(dict + 4);
                 const uint8_t *p = dict + 8; const uint8_t *const pend = dict + dictBytes;
                 if (dictBytes <= 8) DONE(ZE(E_dictionary_corrupted));
-                { const uint32_t h = readHufTable(L, p, (uint32_t)(pend - p)); if (isErr(h)) DONE(ZE(E_dictionary_corrupted)); p += h; }
+                { const uint32_t h = readHufTable(L, p, (uint32_t)(pend - p)); if (isErr(h)) DONE(ZE(E_dictionary_corrupted)); p += h; st.hufX4 = 1; }   // HUF_readDTableX4_wksp (:2391)
                 for (int t = 0; t < 3; t++) {                         // offset codes, match lengths, literal lengths (:2395-2435)
                     const uint32_t maxS = t == 0 ? 31 : (t == 1 ? 52 : 35), maxLog = t == 0 ? 8 : 9;
                     SeqSym *cells = t == 0 ? L.OF.cells : (t == 1 ? L.ML.cells : L.LL.cells);
