@@ -569,7 +569,7 @@ static U32 matchLen(const BYTE *src, U32 a, U32 b, U32 limit)   /* common prefix
  * counts at most FCAP bytes), backward extension into the pending literals (at most BCAP bytes), offset cost (none
  * for a recent offset), literals skipped.  The best one becomes a sequence with its full forward length. */
 #define WINDOW 64u
-#define REPWIN 16u
+#define REPWIN 8u
 #define FCAP 8u
 #define BCAP 8u
 #define REPMIN 4u
@@ -674,8 +674,10 @@ static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32
 }
 
 /* stages 3b-6 for one block whose sequences (w->seqs) and literals (w->lits) are in place */
+U32 g_lastNseq;   /* development aid (tools/lab): sequences of the last block encoded */
 static size_t encodeParsed(Work *w, BYTE *dst, size_t cap, U32 nseq, U32 nlit, int firstBlock)
 {
+    g_lastNseq = nseq;
     {
         /* stage 3b: offsets -> offset field values through the 3-entry recent-offset list
          * (inverse of ZStdDecompress.cs:1509-1530).  Blocks after the first start from an unknown

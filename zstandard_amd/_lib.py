@@ -6,7 +6,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 # development tools (tools/gpu_debug.py, tools/time_kernels.py) set ZSMI_DEBUG_LIB=1: a second library built with
 # -DZSMI_DEBUG_HOOKS (scratch read-back, stage-stop timing aids); the product library has neither
 DEBUG = os.environ.get("ZSMI_DEBUG_LIB", "") == "1"
-LIB_PATH = os.path.join(_HERE, "lib", "libzsmi_debug.so" if DEBUG else "libzsmi.so")
+LIB_PATH = os.environ.get("ZSMI_LIB_FILE") or os.path.join(_HERE, "lib", "libzsmi_debug.so" if DEBUG else "libzsmi.so")   # ZSMI_LIB_FILE: kernel-shape experiments
 CSRC = os.path.join(_HERE, "csrc")
 
 

@@ -192,8 +192,8 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
 // The unit's source bytes are staged in LDS once (NW KiB + pads), so every compare of the walk is an LDS read and
 // the unit is fetched from HBM once.  The lanes are NW independent walkers of 8 lanes; walker g walks the walk
 // range g (1 KiB).  A walker step looks at the 64 positions from ip: the candidate bits of stage 1 (LDS copy of the
-// bit plane), plus, for the first ZS_REPWIN positions, the positions where one of the walker's two recent offsets repeats
-// 4 bytes (lane sub tries ip + sub and ip + sub + 8).  The first LOOK positions holding a candidate go one per lane; a lane
+// bit plane), plus, for the first ZS_REPWIN = 8 positions, the positions where one of the walker's two recent offsets repeats
+// 4 bytes (lane sub tries ip + sub).  The first LOOK positions holding a candidate go one per lane; a lane
 // takes the recent offset or fetches the stage-1 distance (global), compares 16 bytes forward (the score counts ZS_FCAP of
 // them) and 8 bytes backward (into the pending literals) and scores; the best one of the walker becomes a sequence
 // (extended by the walker's 8 lanes if it hit the 16-byte cap).  A match may run past the range end, ZS_CROSS_MAX bytes at most.
@@ -220,14 +220,6 @@ __device__ __forceinline__ void lds_span(const uint8_t *ldsBase, uint32_t byteOf
     for (int k = 0; k < K; k++) out[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
 }
 __device__ __forceinline__ uint64_t zs_u64(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
-// the 4 bytes at byteOff and the 4 bytes at byteOff + 8 of the LDS copy
-__device__ __forceinline__ void lds_two(const uint8_t *ldsBase, uint32_t byteOff, uint32_t &a, uint32_t &b)
-{
-    const uint32_t *d = reinterpret_cast<const uint32_t *>(ldsBase + (byteOff & ~3u));
-    const uint32_t w0 = d[0], w1 = d[1], w2 = d[2], w3 = d[3], sh = byteOff & 3u;
-    a = __builtin_amdgcn_alignbyte(w1, w0, sh); b = __builtin_amdgcn_alignbyte(w3, w2, sh);
-}
-
 template <int NW>
 __global__ void __launch_bounds__(NW * 8)
 k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units, uint32_t block0,
@@ -305,33 +297,35 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
         const bool run = ip < scanEnd;
         if (!__any(run)) break;
         const uint32_t wend = min(ip + ZS_WINDOW, scanEnd);
-        // ---- recent offsets: lane sub tries positions ip + sub and ip + sub + 8 ----
+        // ---- recent offsets: lane sub tries position ip + sub (ZS_REPWIN = 8 = the walker's lanes) ----
         uint32_t rm0 = 0, rm1 = 0;                                               // bit i: rep0 / rep1 repeats 4 bytes at ip + i
         {
             const uint32_t q = ip + sub;
-            const bool t0 = run && rep0 != 0, t1 = run && rep1 != 0;
-            uint32_t a0, a8, b0, b8, c0, c8;
-            lds_two(walkLds, ZS_WALK_FRONT + q, a0, a8);
-            lds_two(walkLds, ZS_WALK_FRONT + ((t0 && q >= rep0) ? q - rep0 : q), b0, b8);
-            lds_two(walkLds, ZS_WALK_FRONT + ((t1 && q >= rep1) ? q - rep1 : q), c0, c8);
-            const bool in0 = q < wend && q + 4 <= limit, in8 = q + 8 < wend && q + 12 <= limit;
-            const uint64_t m00 = __ballot(t0 && in0 && q >= rep0 && a0 == b0), m08 = __ballot(t0 && in8 && q + 8 >= rep0 && a8 == b8);
-            const uint64_t m10 = __ballot(t1 && in0 && q >= rep1 && a0 == c0), m18 = __ballot(t1 && in8 && q + 8 >= rep1 && a8 == c8);
-            const uint32_t sh = 8u * grp;
-            rm0 = ((uint32_t)(m00 >> sh) & 0xFFu) | (((uint32_t)(m08 >> sh) & 0xFFu) << 8);
-            rm1 = ((uint32_t)(m10 >> sh) & 0xFFu) | (((uint32_t)(m18 >> sh) & 0xFFu) << 8);
+            const bool in0 = run && q < wend && q + 4 <= limit;
+            const bool t0 = in0 && rep0 != 0 && q >= rep0, t1 = in0 && rep1 != 0 && q >= rep1;
+            uint32_t a[1], b[1], c[1];
+            lds_span<1>(walkLds, ZS_WALK_FRONT + q, a);
+            lds_span<1>(walkLds, ZS_WALK_FRONT + (t0 ? q - rep0 : q), b);
+            lds_span<1>(walkLds, ZS_WALK_FRONT + (t1 ? q - rep1 : q), c);
+            const uint64_t m0 = __ballot(t0 && a[0] == b[0]), m1 = __ballot(t1 && a[0] == c[0]);
+            // the walker's byte of a ballot: its 32-bit half, then a bit-field extract (no 64-bit shifts)
+            const uint32_t bsh = 8u * (grp & 3u);
+            rm0 = __builtin_amdgcn_ubfe((grp & 4u) ? (uint32_t)(m0 >> 32) : (uint32_t)m0, bsh, 8u);
+            rm1 = __builtin_amdgcn_ubfe((grp & 4u) ? (uint32_t)(m1 >> 32) : (uint32_t)m1, bsh, 8u);
         }
         // ---- window: candidate bits of [ip, ip + 64) from LDS (the same for the walker's 8 lanes) or'ed with the recent-offset
-        //      bits; lane sub takes the sub-th candidate position ----
-        uint64_t m64 = 0;
+        //      bits; lane sub takes the sub-th candidate position.  32-bit words: two funnel shifts give the window ----
+        uint32_t mlo = 0, mhi = 0;
         if (run) {
-            const uint32_t wi = ip >> 6, sh = ip & 63u, wlen = wend - ip;
-            const uint64_t lo = lm[wi], hi = lm[wi + 1];
-            m64 = (lo >> sh) | ((hi << 1) << (63u - sh));
-            if (wlen < 64u) m64 &= (1ull << wlen) - 1ull;
-            m64 |= (uint64_t)(rm0 | rm1);
+            const uint32_t *lw = reinterpret_cast<const uint32_t *>(lm) + (ip >> 5);
+            const uint32_t w0 = lw[0], w1 = lw[1], w2 = lw[2], sh = ip & 31u, wlen = wend - ip;
+            mlo = __builtin_amdgcn_alignbit(w1, w0, sh); mhi = __builtin_amdgcn_alignbit(w2, w1, sh);
+            if (wlen < 64u) {
+                mlo = (wlen >= 32u) ? mlo : __builtin_amdgcn_ubfe(mlo, 0u, wlen);           // width 0 gives 0
+                mhi = (wlen > 32u) ? __builtin_amdgcn_ubfe(mhi, 0u, wlen - 32u) : 0u;
+            }
+            mlo |= rm0 | rm1;
         }
-        const uint32_t mlo = (uint32_t)m64, mhi = (uint32_t)(m64 >> 32);
         const uint32_t clo = (uint32_t)__popc(mlo);
         const uint32_t ncand = min(clo + (uint32_t)__popc(mhi), (uint32_t)look);
         const bool active = run && sub < ncand;
@@ -346,7 +340,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
             idx = mm ? (uint32_t)__builtin_ctz(mm) + (upper ? 32u : 0u) : 0u;
         }
         const uint32_t q = ip + idx;
-        const bool isR0 = active && idx < 16u && ((rm0 >> (idx & 15u)) & 1u) != 0, isR1 = active && !isR0 && idx < 16u && ((rm1 >> (idx & 15u)) & 1u) != 0;
+        const bool isR0 = active && idx < 8u && ((rm0 >> (idx & 7u)) & 1u) != 0, isR1 = active && !isR0 && idx < 8u && ((rm1 >> (idx & 7u)) & 1u) != 0;
         const bool isRep = isR0 || isR1;
         uint32_t off = isR0 ? rep0 : (isR1 ? rep1 : 0u);
         if (active && !isRep) {
@@ -405,7 +399,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
                 }
             }
             const uint64_t stopm = __ballot(nb < 16u);
-            const uint32_t g8 = (uint32_t)((stopm >> (8 * grp)) & 0xFFu);
+            const uint32_t g8 = __builtin_amdgcn_ubfe((grp & 4u) ? (uint32_t)(stopm >> 32) : (uint32_t)stopm, 8u * (grp & 3u), 8u);
             const uint32_t f = g8 ? (uint32_t)__builtin_ctz(g8) : 0u;
             const uint32_t part = (uint32_t)__shfl((int)nb, (int)((lane & ~7u) + f));
             if (need) {

@@ -14,7 +14,7 @@
 #define ZS_CROSS_MAX   16384u     // a match may pass its walk range's end by this much (never the block's end)
 #define ZS_MINMATCH    5u         // shortest match kept
 #define ZS_REPMIN      4u         // shortest match at one of the walker's two recent offsets
-#define ZS_REPWIN      16u        // positions of a walk step's window tried for recent-offset matches
+#define ZS_REPWIN      8u         // positions of a walk step's window tried for recent-offset matches (one per lane of a walker)
 #define ZS_WINDOW      64u        // positions looked at per walk step
 #define ZS_FCAP        8u         // forward bytes compared when scoring a candidate
 #define ZS_BCAP        8u         // backward bytes compared when scoring a candidate
