@@ -2,7 +2,7 @@
 # development aid: PMC passes (separate runs, kernel-trace only) over a short bench; summaries via tools/pmc_summary.py
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=$1
-run() { rocprofv3 --pmc $2 --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$1 -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/pmc_${tag}_$1.log 2>&1; }
+run() { rocprofv3 --pmc $2 --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$1 -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --decode-frames 0 > gpurun_out/pmc_${tag}_$1.log 2>&1; }
 run a "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM_RD"
 run b "TCC_HIT_sum TCC_MISS_sum TCP_TCC_READ_REQ_sum SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_WR SQ_WAVES SQ_WAIT_INST_LDS"
 run c "FETCH_SIZE"
