@@ -401,3 +401,33 @@ def test_in_flight_limits_cross_both_ways():
     env = dict(os.environ, ZSMI_BLOCKS_IN_FLIGHT="64", ZSMI_ITEMS_IN_FLIGHT="64")
     r = subprocess.run([sys.executable, "-c", _CHILD, ROOT], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "CHILD-OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_decode_two_block_frames_fast_path_and_its_fallbacks(codec):
+    """frames of two compressed blocks take the decoder's fast kernels (block slot 1); shapes next to them must still decode:
+    three blocks, a raw or RLE second block, one-block frames in the same batch, a damaged second block (oracle's error code)"""
+    data = D.zipf_log(4 << 20, seed_lo=515)
+    rng = np.random.default_rng(8)
+    noise = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    chunks = [data[0:131072].tobytes(), data[131072:131072 + 100000].tobytes(), data[300000:300000 + 65537].tobytes(), data[400000:400000 + 65536].tobytes(),
+              data[500000:500000 + 196608].tobytes(),                                   # three blocks: general kernel
+              data[700000:700000 + 65536].tobytes() + noise[:65536],                    # second block raw
+              data[800000:800000 + 65536].tobytes() + bytes(40000),                     # second block RLE
+              noise[:65536] + data[900000:900000 + 65536].tobytes(),                    # first block raw
+              data[1000000:1000000 + 70000].tobytes(), data[1100000:1100000 + 131071].tobytes()]
+    frames = [O.compress(c, 3) for c in chunks]
+    bad = bytearray(frames[0]); bad[len(bad) - 200] ^= 0x41                              # inside the second block of a two-block frame
+    frames.append(bytes(bad)); chunks.append(chunks[0])
+    res = _decompress_many(codec, frames, [len(c) for c in chunks])
+    for i, (f, c, (sz, got)) in enumerate(zip(frames, chunks, res)):
+        try:
+            want = O.decompress(f, len(c))
+        except O.OracleError as e:
+            assert sz == (1 << 32) - e.code, (i, hex(sz), e.code)
+            continue
+        assert sz == len(want) and got == want, i
+    # libzstd's own two-block frames (tables may repeat in the second block: the general kernel takes those)
+    if O.libzstd():
+        zf = [O.zstd_compress(c, 3) for c in chunks[:4]]
+        for (sz, got), c in zip(_decompress_many(codec, zf, [len(c) for c in chunks[:4]]), chunks[:4]):
+            assert sz == len(c) and got == c

@@ -1,5 +1,9 @@
-// Fast decode path for the shape the batch codec itself produces and BASELINE config 4 names: an item that is exactly
-// one frame with one compressed block, no checksum.  The serial entropy decoders run lane-parallel ACROSS frames:
+// Fast decode path for the shapes the batch codec itself produces and BASELINE config 4 names: an item that is exactly
+// one frame with one or two compressed blocks (chunks of <= 64 KiB / <= 128 KiB), with or without a content checksum.
+// Everything per block (descriptor, tables, literals, decoded sequences) lives in slot blk * cap + item: the Huffman and
+// sequences kernels are launched once per block index; the execute kernel walks an item's blocks in order, carrying the
+// output position and the recent offsets (ZStdDecompress.cs:1596).  A second block that repeats tables (literals type 3,
+// sequence mode 3: ZStdDecompress.cs:696-697, 1062-1064) leaves the item to the general kernel.  The serial entropy decoders run lane-parallel ACROSS frames:
 //
 //   k_dec_prep      one wavefront per item : headers, Huffman table, sequence tables (all lanes, same code as the general
 //                                            decoder) -> tables + a descriptor in global memory; decides fast / general
@@ -62,10 +66,13 @@ __device__ __forceinline__ uint32_t zs_mlExtraBits(uint32_t s) { return s < 32 ?
 // ---------------------------------------------------------------------------------------------------------------------
 // k_dec_prep
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef ZS_PREP_MINWG
+#define ZS_PREP_MINWG 6                 // wavefronts per SIMD the prep kernel is compiled for (<= 80 VGPRs)
+#endif
 template <int F>
-__global__ void __launch_bounds__(64 * F)
+__global__ void __launch_bounds__(64 * F, ZS_PREP_MINWG)
 k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems,
-           ZsFastDesc *__restrict__ descs, uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ seqTabs)
+           ZsFastDesc *__restrict__ descs, uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ seqTabs, uint32_t cap)
 {
     // the general decoder's LDS image without its Huffman table and with one sequence table instead of three (4.4 of 15.5 KiB)
     __shared__ __attribute__((aligned(16))) unsigned char LSraw[F][(ZS_DLDS_PREP + 15) & ~15u];
@@ -76,20 +83,20 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
     const uint32_t lane = (uint32_t)zs_lane();
     const uint8_t *src = srcAll + it.srcOff;
     const uint32_t srcSize = it.srcSize;
-    ZsFastDesc d;
-    d.fast = 0; d.litType = 0; d.litSize = 0; d.litSrc = 0; d.hufLog = 0; d.nStreams = 0;
-    for (int k = 0; k < 4; k++) { d.sOff[k] = d.sLen[k] = d.sCnt[k] = d.sOut[k] = 0; }
-    d.nbSeq = d.seqOff = d.seqSize = 0; d.llLog = d.ofLog = d.mlLog = 0; d.contentSize = 0; d.hasContentSize = 0; d.hasChecksum = 0; d.checksum = 0;
+    // descriptor fields go to global memory as they become known (lane 0), the fast flags last: nothing of a descriptor is kept in
+    // registers (27 of them otherwise: the kernel's occupancy)
+    #define DSET(field, value) do { if (lane == 0) dp->field = (value); } while (0)
     if (lane < 36) L.llTab[lane] = d_LL_base[lane] | ((uint32_t)d_LL_bits[lane] << 24);
     if (lane < 53) L.mlTab[lane] = d_ML_base[lane] | ((uint32_t)d_ML_bits[lane] << 24);
     wave_sync();
+    bool ok = false; uint32_t nBlocks = 0;
     do {
         // ---- frame header (:389-499): one frame, no dictionary ----
         if (srcSize < 5 + 1 + 3 || rd32(src) != 0xFD2FB528u) break;
         const uint32_t fhd = src[4];
         const uint32_t dictIDCode = fhd & 3, checksumFlag = (fhd >> 2) & 1, singleSegment = (fhd >> 5) & 1, fcsID = fhd >> 6;
         if (dictIDCode || (fhd & 0x08)) break;
-        const uint32_t tail = checksumFlag ? 4u : 0u;              // the checksum behind the block
+        const uint32_t tail = checksumFlag ? 4u : 0u;              // the checksum behind the last block
         const uint32_t fcsSize = fcsID == 0 ? 0 : (fcsID == 1 ? 2 : (fcsID == 2 ? 4 : 8));
         const uint32_t fhs = 5 + !singleSegment + fcsSize + (singleSegment && !fcsID);
         if (srcSize < fhs + 3 + tail) break;
@@ -98,73 +105,98 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
         uint64_t fcs = ~0ull;
         if (fcsID == 0) { if (singleSegment) fcs = src[pos]; } else if (fcsID == 1) fcs = rd16(src + pos) + 256; else if (fcsID == 2) fcs = rd32(src + pos); else fcs = zs_load64(src + pos);
         if (fcs != ~0ull && fcs > 0xFFFFFFFFull) break;
-        d.hasContentSize = fcs != ~0ull; d.contentSize = (uint32_t)fcs;
-        // ---- the one block (:646-659): last, compressed, filling the rest of the item ----
-        const uint32_t bh = rd24(src + fhs);
-        const uint32_t lastBlock = bh & 1, btype = (bh >> 1) & 3, cSize = bh >> 3;
-        if (!lastBlock || btype != 2 || cSize >= (1u << 17) || cSize < 3) break;
-        if ((uint64_t)fhs + 3 + cSize + tail != srcSize) break;
-        if (checksumFlag) { d.hasChecksum = 1; d.checksum = rd32(src + srcSize - 4); }
-        const uint32_t b0 = fhs + 3;                               // block payload offset in the item
-        const uint8_t *bs = src + b0;
-        // ---- literals section header (:683-821) ----
-        uint32_t litCSizeTot;
-        {
-            const uint32_t type = bs[0] & 3, lhl = (bs[0] >> 2) & 3;
-            if (type == 3) break;                                   // treeless: not in a first block
-            if (type == 2) {
-                if (cSize < 5) break;
-                const uint32_t lhc = rd32(bs);
-                uint32_t lhSize, litSize, litCSize; bool single = false;
-                if (lhl < 2) { single = !lhl; lhSize = 3; litSize = (lhc >> 4) & 0x3FF; litCSize = (lhc >> 14) & 0x3FF; }
-                else if (lhl == 2) { lhSize = 4; litSize = (lhc >> 4) & 0x3FFF; litCSize = lhc >> 18; }
-                else { lhSize = 5; litSize = (lhc >> 4) & 0x3FFFF; litCSize = (lhc >> 22) + ((uint32_t)bs[4] << 10); }
-                if (litSize > (1u << 17) || litCSize + lhSize > cSize) break;
-                if (!single && (litSize == 0 || litCSize == 0)) break;
-                uint16_t *ht = reinterpret_cast<uint16_t *>(hufTabs + (size_t)item * ZS_FAST_HUFTAB_BYTES);
-                const uint32_t h = readHufTableT<true>(L, bs + lhSize, litCSize, ht, ZS_FAST_HUFLOG);
-                if (isErr(h) || h >= litCSize || L.hufLog > ZS_FAST_HUFLOG) break;
-                const uint32_t cs0 = b0 + lhSize + h, csz = litCSize - h;
-                d.litType = 2; d.litSize = litSize; d.hufLog = L.hufLog;
-                if (single) { d.nStreams = 1; d.sOff[0] = cs0; d.sLen[0] = csz; d.sCnt[0] = litSize; d.sOut[0] = 0; }
-                else {
-                    if (csz < 10) break;
-                    const uint8_t *cs = src + cs0;
-                    const uint32_t l1 = rd16(cs), l2 = rd16(cs + 2), l3 = rd16(cs + 4);
-                    if (l1 + l2 + l3 + 6 > csz) break;
-                    const uint32_t seg = (litSize + 3) / 4;
-                    if (3 * seg > litSize) break;
-                    d.nStreams = 4;
-                    d.sOff[0] = cs0 + 6; d.sOff[1] = d.sOff[0] + l1; d.sOff[2] = d.sOff[1] + l2; d.sOff[3] = d.sOff[2] + l3;
-                    d.sLen[0] = l1; d.sLen[1] = l2; d.sLen[2] = l3; d.sLen[3] = csz - (l1 + l2 + l3 + 6);
-                    for (uint32_t k = 0; k < 4; k++) { d.sCnt[k] = k < 3 ? seg : litSize - 3 * seg; d.sOut[k] = k * seg; }
+        const uint32_t hasContentSize = fcs != ~0ull, contentSize = (uint32_t)fcs;
+        uint32_t b0 = fhs;                                          // offset of the next block header in the item
+        bool fail = false;
+        #pragma unroll 1
+        for (uint32_t blk = 0; blk < 2 && !fail; blk++) {
+            fail = true;
+            const size_t slot = (size_t)blk * cap + item;
+            ZsFastDesc *dp = descs + slot;
+            if (blk == 0) { DSET(hasContentSize, hasContentSize); DSET(contentSize, contentSize); DSET(hasChecksum, checksumFlag); DSET(checksum, checksumFlag ? rd32(src + srcSize - 4) : 0u); }
+            // ---- a block (:646-659): compressed; the last one fills the rest of the item ----
+            if ((uint64_t)b0 + 3 + tail > srcSize) break;
+            const uint32_t bh = rd24(src + b0);
+            const uint32_t lastBlock = bh & 1, btype = (bh >> 1) & 3, cSize = bh >> 3;
+            if (btype != 2 || cSize >= (1u << 17) || cSize < 3) break;
+            if ((uint64_t)b0 + 3 + cSize + tail > srcSize) break;
+            if (lastBlock && (uint64_t)b0 + 3 + cSize + tail != srcSize) break;
+            if (!lastBlock && blk == 1) break;                       // more than two blocks: general kernel
+            b0 += 3;                                                // block payload offset in the item
+            const uint8_t *bs = src + b0;
+            // ---- literals section header (:683-821) ----
+            uint32_t litCSizeTot;
+            {
+                const uint32_t type = bs[0] & 3, lhl = (bs[0] >> 2) & 3;
+                if (type == 3) break;                               // a repeated Huffman table: general kernel
+                if (type == 2) {
+                    if (cSize < 5) break;
+                    const uint32_t lhc = rd32(bs);
+                    uint32_t lhSize, litSize, litCSize; bool single = false;
+                    if (lhl < 2) { single = !lhl; lhSize = 3; litSize = (lhc >> 4) & 0x3FF; litCSize = (lhc >> 14) & 0x3FF; }
+                    else if (lhl == 2) { lhSize = 4; litSize = (lhc >> 4) & 0x3FFF; litCSize = lhc >> 18; }
+                    else { lhSize = 5; litSize = (lhc >> 4) & 0x3FFFF; litCSize = (lhc >> 22) + ((uint32_t)bs[4] << 10); }
+                    if (litSize > (1u << 17) || litCSize + lhSize > cSize) break;
+                    if (!single && (litSize == 0 || litCSize == 0)) break;
+                    uint16_t *ht = reinterpret_cast<uint16_t *>(hufTabs + slot * ZS_FAST_HUFTAB_BYTES);
+                    const uint32_t h = readHufTableT<true>(L, bs + lhSize, litCSize, ht, ZS_FAST_HUFLOG);
+                    if (isErr(h) || h >= litCSize || L.hufLog > ZS_FAST_HUFLOG) break;
+                    const uint32_t cs0 = b0 + lhSize + h, csz = litCSize - h;
+                    DSET(litType, 2u); DSET(litSize, litSize); DSET(hufLog, L.hufLog);
+                    if (single) { DSET(nStreams, 1u); DSET(sOff[0], cs0); DSET(sLen[0], csz); DSET(sCnt[0], litSize); DSET(sOut[0], 0u); }
+                    else {
+                        if (csz < 10) break;
+                        const uint8_t *cs = src + cs0;
+                        const uint32_t l1 = rd16(cs), l2 = rd16(cs + 2), l3 = rd16(cs + 4);
+                        if (l1 + l2 + l3 + 6 > csz) break;
+                        const uint32_t seg = (litSize + 3) / 4;
+                        if (3 * seg > litSize) break;
+                        if (lane == 0) {
+                            dp->nStreams = 4;
+                            dp->sOff[0] = cs0 + 6; dp->sOff[1] = cs0 + 6 + l1; dp->sOff[2] = cs0 + 6 + l1 + l2; dp->sOff[3] = cs0 + 6 + l1 + l2 + l3;
+                            dp->sLen[0] = l1; dp->sLen[1] = l2; dp->sLen[2] = l3; dp->sLen[3] = csz - (l1 + l2 + l3 + 6);
+                            for (uint32_t k = 0; k < 4; k++) { dp->sCnt[k] = k < 3 ? seg : litSize - 3 * seg; dp->sOut[k] = k * seg; }
+                        }
+                    }
+                    litCSizeTot = litCSize + lhSize;
+                } else {
+                    uint32_t lhSize, litSize;
+                    if (lhl == 1) { lhSize = 2; litSize = rd16(bs) >> 4; }
+                    else if (lhl == 3) { lhSize = 3; litSize = rd24(bs) >> 4; }
+                    else { lhSize = 1; litSize = bs[0] >> 3; }
+                    if (type == 0) { if (litSize + lhSize > cSize) break; DSET(litType, 0u); DSET(litSrc, b0 + lhSize); litCSizeTot = lhSize + litSize; }
+                    else { if (lhSize + 1 > cSize || litSize > (1u << 17)) break; DSET(litType, 1u); DSET(litSrc, (uint32_t)bs[lhSize]); litCSizeTot = lhSize + 1; }
+                    DSET(litSize, litSize); DSET(nStreams, 0u);
                 }
-                litCSizeTot = litCSize + lhSize;
-            } else {
-                uint32_t lhSize, litSize;
-                if (lhl == 1) { lhSize = 2; litSize = rd16(bs) >> 4; }
-                else if (lhl == 3) { lhSize = 3; litSize = rd24(bs) >> 4; }
-                else { lhSize = 1; litSize = bs[0] >> 3; }
-                if (type == 0) { if (litSize + lhSize > cSize) break; d.litType = 0; d.litSrc = b0 + lhSize; litCSizeTot = lhSize + litSize; }
-                else { if (lhSize + 1 > cSize || litSize > (1u << 17)) break; d.litType = 1; d.litSrc = bs[lhSize]; litCSizeTot = lhSize + 1; }
-                d.litSize = litSize;
             }
+            if (litCSizeTot > cSize) break;
+            // ---- sequence headers + tables (:1110-1180), then the tables leave for the sequences kernel.  st.fseEntropy stays 0: a
+            //      table repeated from the block before (mode 3) is an error here and sends the item to the general kernel ----
+            const uint8_t *ip = bs + litCSizeTot; uint32_t remaining = cSize - litCSizeTot, nbSeq = 0;
+            DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = 0; st.llRepeatOk = 0; st.hufX4 = 0;
+            uint16_t *stab = reinterpret_cast<uint16_t *>(seqTabs + slot * ZS_FAST_SEQTAB_BYTES);
+            if (lane < 3) L.misc[8 + lane] = 0;
+            if (seqHeadersT<true>(L, st, ip, remaining, nbSeq, stab, &L.misc[8])) break;
+            if (nbSeq > ZS_FAST_MAXSEQ) break;
+            if (nbSeq == 0 && remaining != 0) break;
+            DSET(nbSeq, nbSeq); DSET(seqOff, (uint32_t)(ip - src)); DSET(seqSize, remaining);
+            DSET(llLog, nbSeq ? L.misc[8] : 0u); DSET(ofLog, nbSeq ? L.misc[9] : 0u); DSET(mlLog, nbSeq ? L.misc[10] : 0u);
+            DSET(fast, 1u);
+            nBlocks = blk + 1;
+            b0 += cSize;
+            fail = false;
+            if (lastBlock) break;
         }
-        if (litCSizeTot > cSize) break;
-        // ---- sequence headers + tables (:1110-1180), then the tables leave for the sequences kernel ----
-        const uint8_t *ip = bs + litCSizeTot; uint32_t remaining = cSize - litCSizeTot, nbSeq = 0;
-        DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = 0; st.llRepeatOk = 0; st.hufX4 = 0;
-        uint16_t *stab = reinterpret_cast<uint16_t *>(seqTabs + (size_t)item * ZS_FAST_SEQTAB_BYTES);
-        if (lane < 3) L.misc[8 + lane] = 0;
-        if (seqHeadersT<true>(L, st, ip, remaining, nbSeq, stab, &L.misc[8])) break;
-        if (nbSeq > ZS_FAST_MAXSEQ) break;
-        if (nbSeq == 0 && remaining != 0) break;
-        d.nbSeq = nbSeq; d.seqOff = (uint32_t)(ip - src); d.seqSize = remaining;
-        if (nbSeq) { d.llLog = L.misc[8]; d.ofLog = L.misc[9]; d.mlLog = L.misc[10]; }
-        d.fast = 1;
+        ok = !fail;
     } while (0);
-    if (lane == 0) descs[item] = d;
+    // an item is fast only as a whole; a block index it does not use reads as absent
+    if (lane == 0) {
+        if (!ok) { descs[item].fast = 0; descs[(size_t)cap + item].fast = 0; }
+        else if (nBlocks < 2) descs[(size_t)cap + item].fast = 0;
+    }
+    #undef DSET
 }
+
 
 // A lane stages the window of ITS OWN stream: win[] <- stream bytes [base - 8, base + W), zero outside [0, size).
 // All the loads of a window are independent, so they overlap (a loop over streams with one load each serialises a memory
@@ -216,7 +248,7 @@ struct HufLds { uint16_t huf[ZS_FAST_GROUP][ZS_HUF2_ENTRIES]; uint32_t win[64][(
 
 __global__ void __launch_bounds__(64)
 k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-              const uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ litScratchAll)
+              const uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ litScratchAll, uint32_t blk, uint32_t cap)
 {
     __shared__ HufLds H;
     const uint32_t lane = (uint32_t)zs_lane();
@@ -224,12 +256,13 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     const uint32_t item = blockIdx.x * ZS_FAST_GROUP + g;
     bool mine = false; uint32_t dtLog = 1, n = 0, size = 0;
     const uint8_t *src = srcAll; uint8_t *out = litScratchAll;
+    const size_t slot0 = (size_t)blk * cap;                          // this block index's descriptors, tables, literal scratch
     if (item < nItems) {
-        const ZsFastDesc *d = descs + item;
-        if (d->fast && d->litType == 2 && k < d->nStreams) {
+        const ZsFastDesc *d = descs + slot0 + item;
+        if (descs[item].fast && d->fast && d->litType == 2 && k < d->nStreams) {
             mine = true; dtLog = d->hufLog; n = d->sCnt[k]; size = d->sLen[k];
             src = srcAll + items[item].srcOff + d->sOff[k];
-            out = litScratchAll + (size_t)item * ((1u << 17) + 64) + d->sOut[k];
+            out = litScratchAll + (slot0 + item) * ((1u << 17) + 64) + d->sOut[k];
         }
     }
     if (!__ballot(mine)) return;
@@ -238,7 +271,7 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
         const uint32_t it2 = blockIdx.x * ZS_FAST_GROUP + gg;
         const uint32_t log2 = wave_get(mine ? dtLog : 0u, (int)(gg * 4));        // stream 0 of the item exists whenever any does
         if (!log2) continue;
-        const uint32_t *ht = reinterpret_cast<const uint32_t *>(hufTabs + (size_t)it2 * ZS_FAST_HUFTAB_BYTES);
+        const uint32_t *ht = reinterpret_cast<const uint32_t *>(hufTabs + (slot0 + it2) * ZS_FAST_HUFTAB_BYTES);
         uint32_t *dstw = reinterpret_cast<uint32_t *>(H.huf[gg]);
         {   // 5 dwords per lane, the loads issued together
             constexpr uint32_t words = ZS_HUF2_ENTRIES / 2, per = (words + 63) / 64;
@@ -316,7 +349,7 @@ struct SeqDecLds { uint16_t cells[G][(LOG9 ? 1280 : 768) + ZS_FAST_CELLPAD]; uin
 template <bool LOG9, uint32_t G>
 __global__ void __launch_bounds__(64)
 k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-                const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll)
+                const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t blk, uint32_t cap)
 {
     __shared__ SeqDecLds<LOG9, G> S;
     constexpr uint32_t LLC = LOG9 ? 512 : 256, OFB = LLC, MLB = LLC + 256;        // cells of the LL table; where OF and ML start
@@ -324,14 +357,15 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
     const uint32_t item = blockIdx.x * G + lane;
     bool mine = false; uint32_t nbSeq = 0, size = 0, llLog = 0, ofLog = 0, mlLog = 0;
     const uint8_t *src = srcAll;
+    const size_t slot0 = (size_t)blk * cap;
     if (lane < G && item < nItems) {
-        const ZsFastDesc *d = descs + item;
-        if (d->fast && d->nbSeq && ((d->llLog > 8 || d->mlLog > 8) == LOG9)) { mine = true; nbSeq = d->nbSeq; size = d->seqSize; llLog = d->llLog; ofLog = d->ofLog; mlLog = d->mlLog; src = srcAll + items[item].srcOff + d->seqOff; }
+        const ZsFastDesc *d = descs + slot0 + item;
+        if (descs[item].fast && d->fast && d->nbSeq && ((d->llLog > 8 || d->mlLog > 8) == LOG9)) { mine = true; nbSeq = d->nbSeq; size = d->seqSize; llLog = d->llLog; ofLog = d->ofLog; mlLog = d->mlLog; src = srcAll + items[item].srcOff + d->seqOff; }
     }
     if (!__ballot(mine)) return;
     for (uint32_t gg = 0; gg < G; gg++) {
         if (!wave_get(mine ? 1u : 0u, (int)gg)) continue;
-        const uint32_t *st = reinterpret_cast<const uint32_t *>(seqTabs + (size_t)(blockIdx.x * G + gg) * ZS_FAST_SEQTAB_BYTES);
+        const uint32_t *st = reinterpret_cast<const uint32_t *>(seqTabs + (slot0 + blockIdx.x * G + gg) * ZS_FAST_SEQTAB_BYTES);
         const uint32_t a = 1u << wave_get(llLog, (int)gg), o = 1u << wave_get(ofLog, (int)gg), m = 1u << wave_get(mlLog, (int)gg);
         {   // the three tables, two cells a dword: every load issued before the first LDS store (up to 4 + 2 + 4 dwords per lane)
             uint32_t va[4], vo[2], vm[4];
@@ -354,7 +388,7 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
     bool ok = !mine || bc_init(b, src, size);
     const uint16_t *cells = S.cells[lane & (G - 1)];
     const uint32_t *win = S.win[lane & (G - 1)];
-    ZsFastSeq *outp = seqOutAll + (size_t)item * ZS_FAST_MAXSEQ;
+    ZsFastSeq *outp = seqOutAll + (slot0 + item) * ZS_FAST_MAXSEQ;
     uint32_t sLL = 0, sOF = 0, sML = 0, t = 0;
     bool started = false, done = !mine || !ok;
     #define FSEQ_NEED(nbits) do { if (b.avail < (nbits)) bc_refill(b, win, base); } while (0)
@@ -399,7 +433,7 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
 template <int F>
 __global__ void __launch_bounds__(64 * F, ZS_EXEC_MINWG)
 k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-              const ZsFastSeq *__restrict__ seqAll, uint8_t *__restrict__ litScratchAll, uint8_t *dstAll, uint32_t *__restrict__ dstSizes)
+              const ZsFastSeq *__restrict__ seqAll, uint8_t *__restrict__ litScratchAll, uint8_t *dstAll, uint32_t *__restrict__ dstSizes, uint32_t cap)
 {
     __shared__ uint32_t tiles[F][3][64];
     __shared__ uint32_t codeTabs[36 + 53];                                      // base | extra bits << 24 of the LL / ML codes
@@ -409,16 +443,31 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     else if (threadIdx.x >= 64 && threadIdx.x < 64 + 53) codeTabs[36 + threadIdx.x - 64] = d_ML_base[threadIdx.x - 64] | ((uint32_t)d_ML_bits[threadIdx.x - 64] << 24);
     __syncthreads();                                                            // the only workgroup barrier: before any wavefront leaves
     if (item >= nItems) return;
-    const ZsFastDesc d = descs[item];
-    if (!d.fast) return;
-    const ZsDecItem it = items[item];
+    // the item index is the same in every lane: said so, its descriptor and item record are scalar loads (27 + 6 registers that
+    // would otherwise sit in every lane; the kernel lives at its 80-VGPR cap)
+    const uint32_t itemU = (uint32_t)__builtin_amdgcn_readfirstlane((int)item);
+    if (!descs[itemU].fast) return;
+    const uint32_t hasContentSize = descs[itemU].hasContentSize, contentSize = descs[itemU].contentSize;
+    const ZsDecItem it = items[itemU];
     uint8_t *dstBase = dstAll + it.dstOff;
     const uint64_t oend = it.dstCap;
-    uint8_t *litBuf = litScratchAll + (size_t)item * ((1u << 17) + 64);
+    uint64_t op = 0; bool bad = false;
+    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                                      // the list carried from tile to tile and block to block (lane 0 holds it)
+#ifdef ZS_EXEC_PROFILE
+    uint64_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const uint64_t pfStart = __builtin_amdgcn_s_memtime(); uint64_t pfMark = pfStart;
+#endif
+    #pragma unroll 1
+    for (uint32_t blk = 0; blk < 2 && !bad; blk++) {
+    const size_t slot = (size_t)blk * cap + itemU;
+    const ZsFastDesc *dp = descs + slot;
+    if (blk && !dp->fast) break;                                                // a one-block frame
+    struct { uint32_t litType, litSize, litSrc, nbSeq, seqOff; } d;            // what this kernel needs of the block's descriptor (scalars)
+    d.litType = dp->litType; d.litSize = dp->litSize; d.litSrc = dp->litSrc; d.nbSeq = dp->nbSeq; d.seqOff = dp->seqOff;
+    uint8_t *litBuf = litScratchAll + slot * ((1u << 17) + 64);
     const uint8_t *litPtr = litBuf;
     if (d.litType == 0) litPtr = srcAll + it.srcOff + d.litSrc;
     else if (d.litType == 1) { for (uint32_t j = lane; j < d.litSize; j += 64) litBuf[j] = (uint8_t)d.litSrc; wave_mem_sync(); }
-    const ZsFastSeq *seqs = seqAll + (size_t)item * ZS_FAST_MAXSEQ;
+    const ZsFastSeq *seqs = seqAll + slot * ZS_FAST_MAXSEQ;
     const uint8_t *bits = srcAll + it.srcOff + d.seqOff;                        // the sequence bitstream, d.seqSize bytes
     // the 64 stream bits below bit position p, top aligned (bit p - 1 at bit 63); bits below the stream start read as 0
     auto bitsBelow = [&](int32_t p) -> uint64_t {
@@ -429,11 +478,7 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
         else { wv = 0; for (int32_t k = 0; k <= bh; k++) wv |= (uint64_t)bits[k] << (8 * (k + 7 - bh)); }
         return wv << (7u - (uint32_t)((p - 1) & 7));
     };
-    uint64_t op = 0; uint32_t litPos = 0; bool bad = false;
-    uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                                      // the list carried from tile to tile (lane 0 holds it)
-#ifdef ZS_EXEC_PROFILE
-    uint64_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const uint64_t pfStart = __builtin_amdgcn_s_memtime(); uint64_t pfMark = pfStart;
-#endif
+    uint32_t litPos = 0;
     for (uint32_t t0 = 0; t0 < d.nbSeq; t0 += 64) {
         const uint32_t T = min(64u, d.nbSeq - t0);
         // lane t: the extra bits of sequence t0 + t (:1487-1545) -> lengths, offset value and its recent-offset class
@@ -526,14 +571,16 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
         wave_sync();
     }
 #ifdef ZS_EXEC_PROFILE
-    if (lane == 0) { uint64_t *o = reinterpret_cast<uint64_t *>(litBuf + (1u << 17)); pf[4] = __builtin_amdgcn_s_memtime() - pfStart; pf[5] = d.nbSeq; for (int k = 0; k < 8; k++) o[k] = pf[k]; }
+    if (lane == 0 && blk == 0) { uint64_t *o = reinterpret_cast<uint64_t *>(litBuf + (1u << 17)); pf[4] = __builtin_amdgcn_s_memtime() - pfStart; pf[5] = d.nbSeq; for (int k = 0; k < 8; k++) o[k] = pf[k]; }
 #endif
     if (!bad) {
         const uint32_t lastLL = d.litSize - litPos;
         if (lastLL > oend - op) bad = true;
         else { for (uint32_t j = lane; j < lastLL; j += 64) dstBase[op + j] = litPtr[litPos + j]; op += lastLL; }
+        wave_mem_sync();                                                        // the next block's matches read these bytes
     }
-    if (!bad && d.hasContentSize && op != d.contentSize) bad = true;
+    }   // blocks of the item
+    if (!bad && hasContentSize && op != contentSize) bad = true;
     if (lane == 0) { if (bad) descs[item].fast = 0; else dstSizes[item] = (uint32_t)op; }
 }
 

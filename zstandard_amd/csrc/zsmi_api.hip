@@ -382,11 +382,12 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
     for (uint32_t i = 0; i < n; i++) { hi[i].srcOff = srcOffsets[i]; hi[i].dstOff = dstOffsets[i]; hi[i].srcSize = srcSizes[i]; hi[i].dstCap = dstCaps[i]; }
     if (hipMemcpyAsync(c->dItems.p, hi, sizeof(ZsDecItem) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
     const uint32_t cap = std::min<uint32_t>(n, c->maxItemsInFlight);
-    if (!c->dLitScratch.reserve((size_t)cap * ((1u << 17) + 64))) return ZSMI_error_memory_allocation;
     const bool useDict = dDict != nullptr && dictSize != 0;
     const bool fast = c->decodeFast && !useDict;                  // frames that name a dictionary go to the general kernel
-    if (fast && (!c->dFastDesc.reserve((size_t)cap * sizeof(ZsFastDesc)) || !c->dHufTabs.reserve((size_t)cap * ZS_FAST_HUFTAB_BYTES) ||
-                 !c->dSeqTabs.reserve((size_t)cap * ZS_FAST_SEQTAB_BYTES) || !c->dSeqOut.reserve((size_t)cap * ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)))) return ZSMI_error_memory_allocation;
+    // the fast path keeps two block slots per item (frames of one or two blocks): slot = block index * cap + item
+    if (!c->dLitScratch.reserve((size_t)cap * (fast ? 2 : 1) * ((1u << 17) + 64))) return ZSMI_error_memory_allocation;
+    if (fast && (!c->dFastDesc.reserve((size_t)cap * 2 * sizeof(ZsFastDesc)) || !c->dHufTabs.reserve((size_t)cap * 2 * ZS_FAST_HUFTAB_BYTES) ||
+                 !c->dSeqTabs.reserve((size_t)cap * 2 * ZS_FAST_SEQTAB_BYTES) || !c->dSeqOut.reserve((size_t)cap * 2 * ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)))) return ZSMI_error_memory_allocation;
     for (uint32_t i0 = 0; i0 < n; i0 += cap) {
         const uint32_t cnt = std::min(cap, n - i0);
         const ZsDecItem *dI = (const ZsDecItem *)c->dItems.p + i0;
@@ -397,12 +398,14 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
             ZsFastDesc *dD = (ZsFastDesc *)c->dFastDesc.p;
             const uint32_t groups = (cnt + ZS_FAST_GROUP - 1) / ZS_FAST_GROUP;
             LAUNCH(c, "k_dec_prep", (k_dec_prep<ZS_DEC_GROUP>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc, dI, cnt, dD,
-                   (uint8_t *)c->dHufTabs.p, (uint8_t *)c->dSeqTabs.p);
-            LAUNCH(c, "k_dec_huffman", k_dec_huffman, dim3(groups), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p);
-            LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p);
-            LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, ZS_FAST_SEQGROUP>), dim3((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p);
+                   (uint8_t *)c->dHufTabs.p, (uint8_t *)c->dSeqTabs.p, cap);
+            for (uint32_t blk = 0; blk < 2; blk++) {                  // block index 1: the second block of two-block frames (a wavefront without one leaves at once)
+                LAUNCH(c, "k_dec_huffman", k_dec_huffman, dim3(groups), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, blk, cap);
+                LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, blk, cap);
+                LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, ZS_FAST_SEQGROUP>), dim3((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, blk, cap);
+            }
             LAUNCH(c, "k_dec_execute", (k_dec_execute<4>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const ZsFastSeq *)c->dSeqOut.p,
-                   (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0);
+                   (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap);
             LAUNCH(c, "k_dec_checksum", k_dec_checksum, dim3((cnt + 63) / 64), dim3(64), 0, dI, cnt, (const ZsFastDesc *)dD, (const uint8_t *)dDst, dDstSizes + i0);
             doneFlags = &dD->fast;
         }
