@@ -524,9 +524,11 @@ typedef struct {
  * the LDS resolves lanes that hit the same slot in ascending lane order (probed: tools/probe/lds_xchg.hip), which
  * is exactly this loop. */
 #define SLOT_EMPTY 0xFFFFFFFFu
-static U32 hashShort(const BYTE *p) { return rd32(p) * 0x9E3779B1u + (U32)p[4] * 0x9E3779u; }
-static U32 rotl32(U32 v, int r) { return (v << r) | (v >> (32 - r)); }
-static U32 hashLong(const BYTE *p) { return (rd32(p + 4) ^ rotl32(rd32(p) * 0x9E3779B1u, 15)) * 0x85EBCA77u; }
+/* hashes made of 24 x 24 -> 32 bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 run at full rate on CDNA, v_mul_lo_u32 at a quarter):
+ * short: bytes 0-2 and 2-4; long: bytes 0-2, 3-5, 6-7 */
+static U32 mul24(U32 a, U32 b) { return (a & 0xFFFFFFu) * (b & 0xFFFFFFu); }
+static U32 hashShort(const BYTE *p) { U32 const lo = rd32(p), hi = rd32(p + 4); return mul24(lo, 0x9E3779u) + mul24((lo >> 16) | (hi << 16), 0x85EBCBu); }
+static U32 hashLong(const BYTE *p) { U32 const lo = rd32(p), hi = rd32(p + 4); return mul24(lo, 0x9E3779u) + mul24((lo >> 24) | (hi << 8), 0x85EBCBu) + mul24(hi >> 16, 0xC2B2AFu); }
 static U32 tableLogFor(U32 unitN) { return unitN > BLOCK_MAX ? MAX_TABLE_LOG : MAX_TABLE_LOG - 1; }
 static void findCandidates(Work *w, const BYTE *src, U32 n, const EParams *prm)
 {

@@ -32,8 +32,12 @@
 #define ZS_CAND_RING (4u * ZS_CAND_G * 64u + 16u)                 // source bytes of 4 groups + the mirror of the first 16
 #define ZS_CAND_LDS(TLOG, NT) ((size_t)(NT) * (4u << (TLOG)) + ((NT) > 1 ? 2u * (NT) * ZS_CAND_G * 64u * 4u : 0u) + ZS_CAND_RING + (NT) * 256u)   // tables, exchange buffers, source ring, a dummy word per lane
 #define ZS_SLOT_EMPTY 0xFFFFFFFFu
-__device__ __forceinline__ uint32_t zs_hash_short(uint32_t lo, uint32_t hi) { return lo * 0x9E3779B1u + (hi & 0xFFu) * 0x9E3779u; }
-__device__ __forceinline__ uint32_t zs_hash_long(uint32_t lo, uint32_t hi) { return (hi ^ __builtin_amdgcn_alignbit(lo * 0x9E3779B1u, lo * 0x9E3779B1u, 17)) * 0x85EBCA77u; }   // rotl 15
+// hashes made of 24 x 24 -> 32 bit multiplies (v_mul_u32_u24 / v_mad_u32_u24: full rate; a v_mul_lo_u32 is quarter rate and the first
+// version's two per long hash were a quarter of the kernel's issue slots).  short: bytes 0-2 and 2-4; long: bytes 0-2, 3-5, 6-7
+// (the multiplies read only the low 24 bits of their operands).  Same functions in oracle/zso_encoder.c.
+__device__ __forceinline__ uint32_t zs_hash_short(uint32_t lo, uint32_t hi) { return __umul24(lo, 0x9E3779u) + __umul24(__builtin_amdgcn_alignbit(hi, lo, 16), 0x85EBCBu); }
+__device__ __forceinline__ uint32_t zs_hash_long(uint32_t lo, uint32_t hi)
+{ return __umul24(lo, 0x9E3779u) + __umul24(__builtin_amdgcn_alignbit(hi, lo, 24), 0x85EBCBu) + __umul24(hi >> 16, 0xC2B2AFu); }
 
 template <int TLOG, int NT>
 __global__ void __launch_bounds__(64 * NT)
