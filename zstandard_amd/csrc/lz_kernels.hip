@@ -93,9 +93,10 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     };
     // Software pipeline over the groups (a wavefront is alone on its SIMD: nothing else hides its latencies).  Iteration g:
     //   1. distances of group g - 1 from the exchange results that came back during the last iteration -> LDS exchange buffer
-    //   2. stage this wavefront's part of group g + 1 (loaded M .. 2 M iterations earlier); 3. barrier
-    //   4. issue the reads of this wavefront's half of both tables' distances of group g - 1 and of the source bytes of group g
-    //   5. hash group g and issue its G exchanges (they run while 6 is done and until the next iteration's step 1)
+    //   2. stage this wavefront's part of group g + 2 (loaded M .. 2 M iterations earlier); 3. barrier
+    //   4. issue the reads of this wavefront's half of both tables' distances of group g - 1
+    //   5. hash group g (its ring words were read during the last iteration) and issue its G exchanges (they run while 6 is done and
+    //      until the next iteration's step 1); issue the ring reads of group g + 1
     //   6. merge, candidate bits, stores of group g - 1
     // Loads in flight live in two register sets A and B of M groups each, addressed statically; the loop body is
     // [load B | M iterations on A | load A | M iterations on B].  The compiler puts a full s_waitcnt vmcnt(0) at the loop head (it
@@ -110,6 +111,12 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
         uint32_t entry[G], old[G];
         #pragma unroll
         for (uint32_t u = 0; u < G; u++) { entry[u] = 0; old[u] = ZS_SLOT_EMPTY; }
+        uint32_t w0[G], w1[G], w2[G];                                        // the three dwords around each of the lane's G positions of the next group to hash
+        auto readRing = [&](uint32_t g) {
+            const uint32_t *rp = reinterpret_cast<const uint32_t *>(ring + (g & 3u) * GP + (lane & ~3u));
+            #pragma unroll
+            for (uint32_t u = 0; u < G; u++) { w0[u] = rp[u * 16]; w1[u] = rp[u * 16 + 1]; w2[u] = rp[u * 16 + 2]; }
+        };
         auto iter = [&](auto wholeTag, uint32_t g, const uint32_t (&wNext)[PW]) {
             constexpr bool WHOLE = decltype(wholeTag)::value;                // group g lies wholly inside the hashable positions
             const uint32_t pbase = (g - 1) * GP;                             // group g - 1 (nothing of it is kept when g == 0)
@@ -126,17 +133,13 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
                 uint32_t *xb = xbuf + (size_t)(g & 1u) * NT * GP;
                 #pragma unroll
                 for (uint32_t u = 0; u < G; u++) xb[wave * GP + u * 64 + lane] = d[u];
-                stagePart(g + 1, wNext);
+                stagePart(g + 2, wNext);
                 __syncthreads();
                 #pragma unroll
                 for (uint32_t uu = 0; uu < H; uu++) { const uint32_t u = wave * H + uu; mS[uu] = xb[u * 64 + lane]; mL[uu] = xb[GP + u * 64 + lane]; }
-            } else stagePart(g + 1, wNext);
+            } else stagePart(g + 2, wNext);
             {
                 const uint32_t base = g * GP;                                // group g (behind the last group: dummy exchanges)
-                const uint32_t *rp = reinterpret_cast<const uint32_t *>(ring + (g & 3u) * GP + (lane & ~3u));
-                uint32_t w0[G], w1[G], w2[G];
-                #pragma unroll
-                for (uint32_t u = 0; u < G; u++) { w0[u] = rp[u * 16]; w1[u] = rp[u * 16 + 1]; w2[u] = rp[u * 16 + 2]; }
                 #pragma unroll
                 for (uint32_t u = 0; u < G; u++) {                           // the G exchanges go to the LDS back to back
                     const uint32_t p = base + u * 64 + lane;
@@ -147,6 +150,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
                     const uint32_t idx = h >> (32 - TLOG);
                     old[u] = atomicExch(&T[(WHOLE || p < hashable) ? idx : dummy], entry[u]);
                 }
+                readRing(g + 1);                                             // group g + 1 is in the ring since this iteration's barrier: its words travel under the stores below
             }
             if (g > 0) {
                 // candidate bits (and bit 16 of the distances) of this wavefront's H steps of group g - 1: lane uu keeps step uu's
@@ -172,18 +176,20 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
             if (g > nGroups) return;
             if ((g + 1) * GP <= hashable) iter(std::true_type{}, g, wNext); else iter(std::false_type{}, g, wNext);
         };
-        {   // group 0 into the ring; register set A = the parts of groups 1 .. M (staged by iterations 0 .. M - 1)
-            uint32_t w[PW];
-            loadPart(0, w);
-            stagePart(0, w);
-            loadM(1, bufA);
+        {   // groups 0 and 1 into the ring; register set A = the parts of groups 2 .. M + 1 (staged by iterations 0 .. M - 1: a group's words
+            // are read an iteration before it is hashed, and its last positions need the first bytes of the group behind it)
+            uint32_t wa[PW], wb[PW];
+            loadPart(0, wa); loadPart(min(1u, nGroups), wb);
+            stagePart(0, wa); stagePart(1, wb);
+            loadM(2, bufA);
             if (NT > 1) __syncthreads();
+            readRing(0);
         }
         for (uint32_t g0 = 0; g0 <= nGroups; g0 += 2 * M) {
-            loadM(g0 + M + 1, bufB);
+            loadM(g0 + M + 2, bufB);
             #pragma unroll
             for (uint32_t k = 0; k < M; k++) step(g0 + k, bufA[k]);
-            loadM(g0 + 2 * M + 1, bufA);
+            loadM(g0 + 2 * M + 2, bufA);
             #pragma unroll
             for (uint32_t k = 0; k < M; k++) step(g0 + M + k, bufB[k]);
         }
