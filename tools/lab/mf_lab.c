@@ -96,7 +96,6 @@ static void labCandidates(Work *w, const BYTE *src, U32 n, const EParams *prm)
     }
 }
 
-typedef struct { U32 start, ml, off; } ASeq;   /* absolute match start (after backward extension) */
 
 /* one walk range [start, end); matches may extend to limit (= end without cross, else block end) */
 static U32 labWalk(const BYTE *src, U32 n, U32 start, U32 end, U32 limit, ASeq *out, U32 *lastAnchor)
