@@ -21,10 +21,11 @@
 // Candidates are not compared with the source bytes here (index + tag = 28 hash bits agree; the walk measures every match).
 // The two wavefronts work in groups of G steps: each writes its G x 64 distances to an LDS exchange buffer, a barrier, then
 // each merges and stores half of the group:  dist[] (low 16 bits), distHi (bit 16, big units), distMask ("has a candidate").
-// HBM traffic per unit: reads n (both wavefronts, the second from cache), writes 2 n + n / 8 (+ n / 8).
+// The source bytes of a group reach the hashing lanes through a 4-group ring in LDS (one coalesced dword load per lane: each
+// wavefront stages its share two groups ahead).  HBM traffic per unit: reads n, writes 2 n + n / 8 (+ n / 8).
 // ---------------------------------------------------------------------------------------------
 #ifndef ZS_CAND_G
-#define ZS_CAND_G 8                // steps of 64 positions per group (loads in flight per lane)
+#define ZS_CAND_G 8                // steps of 64 positions per group: exchanges issued back to back, one barrier per group (16: 85 KiB of LDS, one workgroup per CU)
 #endif
 #ifndef ZS_CAND_DEPTH
 #define ZS_CAND_DEPTH 4            // a register set holds the source loads of this many groups (two sets: 4 .. 8 groups in flight)
