@@ -41,13 +41,10 @@ def usable_cores():
 
 
 def source_fingerprint():
-    """sha256 over the kernel sources: profiles/*_traffic.json carries the one it was measured at"""
-    import hashlib
-    h = hashlib.sha256()
-    d = os.path.join(ROOT, "zstandard_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        h.update(f.encode()); h.update(open(os.path.join(d, f), "rb").read())
-    return h.hexdigest()[:16]
+    """fingerprint of the kernel sources (comments and white space do not count): profiles/*_traffic.json carries the one it was measured at"""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from src_fingerprint import fingerprint
+    return fingerprint(ROOT)
 
 
 def self_launch(args):
