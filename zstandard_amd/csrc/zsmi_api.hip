@@ -138,7 +138,8 @@ struct zsmi_ctx {
                                          // last round is mostly tail, so big launches pay (16384 frames of 32 KiB: 82 GiB/s, 57344: 104 GiB/s)
     PinBuf hItems;
     // staging for host-buffer calls
-    DevBuf sSrc, sDst, sSizes, sDict;
+    DevBuf sSrc, sDst, sSizes, sDict, sPack, sPackOff;
+    PinBuf hPack;
     // timing
     bool timing = false;
     std::vector<TimedLaunch> launches;
@@ -200,7 +201,7 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
 {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dUnits, &c->dItems, &c->dLitScratch, &c->dFastDesc, &c->dHufTabs, &c->dSeqTabs, &c->dSeqOut, &c->sSrc, &c->sDst, &c->sSizes, &c->sDict }) b->release();
+    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dUnits, &c->dItems, &c->dLitScratch, &c->dFastDesc, &c->dHufTabs, &c->dSeqTabs, &c->dSeqOut, &c->sSrc, &c->sDst, &c->sSizes, &c->sDict, &c->sPack, &c->sPackOff }) b->release();
     for (int i = 0; i < zsmi_ctx::kMaxLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
         if (L.stream) (void)hipStreamSynchronize(L.stream);
@@ -481,6 +482,48 @@ static bool spanOf(const uint64_t *off, const uint32_t *sz, const uint32_t *caps
     if (lo == ~0ull) { lo = 0; hi = 0; }
     return true;
 }
+// Results of a host-buffer call go back to the caller's buffer: items that sit back to back are one transfer; a scattered batch (compressed
+// frames in bound-sized slots) is packed on the device, crosses PCIe once into pinned memory and is placed from there (a transfer per item costs
+// ~10 us each: 4096 frames took longer to return than to compress)
+__global__ void k_pack_items(const uint8_t *base, const uint64_t *offs /* [0..n): where, [n..2n): packed position */, const uint32_t *sizes, uint32_t n, uint8_t *packed)
+{
+    const uint32_t i = blockIdx.x;
+    const uint32_t sz = sizes[i] > 0xFFFFFF88u ? 0 : sizes[i];
+    zs_block_copy(packed + offs[n + i], base + offs[i], sz, threadIdx.x, blockDim.x);
+}
+static int copyBack(zsmi_ctx *c, const uint8_t *dBase, const uint64_t *dof, uint8_t *dst, const uint64_t *dstOffsets, const uint32_t *sizes /* host, synchronised */, uint32_t n)
+{
+    struct Run { uint64_t host, dev, len; };
+    std::vector<Run> runs;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (sizes[i] > 0xFFFFFF88u || sizes[i] == 0) continue;
+        total += sizes[i];
+        if (!runs.empty() && runs.back().host + runs.back().len == dstOffsets[i] && runs.back().dev + runs.back().len == dof[i]) runs.back().len += sizes[i];
+        else runs.push_back({ dstOffsets[i], dof[i], sizes[i] });
+    }
+    if (runs.size() <= 16) {
+        for (const Run &r : runs)
+            if (hipMemcpyAsync(dst + r.host, dBase + r.dev, r.len, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+        return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : ZSMI_error_GENERIC;
+    }
+    if (!c->sPack.reserve(total + 64) || !c->sPackOff.reserve(sizeof(uint64_t) * 2 * n + sizeof(uint32_t) * n) || !c->hPack.reserve(std::max<uint64_t>(total, sizeof(uint64_t) * 2 * n + sizeof(uint32_t) * n))) return ZSMI_error_memory_allocation;
+    uint64_t *ho = (uint64_t *)c->hPack.p; uint32_t *hs = (uint32_t *)(ho + 2 * n);
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < n; i++) { ho[i] = dof[i]; ho[n + i] = run; hs[i] = sizes[i]; run += (sizes[i] > 0xFFFFFF88u) ? 0 : sizes[i]; }
+    if (hipMemcpyAsync(c->sPackOff.p, ho, sizeof(uint64_t) * 2 * n + sizeof(uint32_t) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return ZSMI_error_GENERIC;      // hPack is reused for the payload below
+    LAUNCH(c, "k_pack_items", k_pack_items, dim3(n), dim3(256), 0, dBase, (const uint64_t *)c->sPackOff.p, (const uint32_t *)((const uint64_t *)c->sPackOff.p + 2 * n), n, (uint8_t *)c->sPack.p);
+    if (hipMemcpyAsync(c->hPack.p, c->sPack.p, total, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    const uint8_t *hp = (const uint8_t *)c->hPack.p;
+    run = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (sizes[i] > 0xFFFFFF88u) continue;
+        memcpy(dst + dstOffsets[i], hp + run, sizes[i]); run += sizes[i];
+    }
+    return 0;
+}
 extern "C" int zsmi_compressBatchHost(zsmi_ctx *c, const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
                                       uint32_t n, void *dst, const uint64_t *dstOffsets, uint32_t *dstSizes, int level)
 {
@@ -500,15 +543,7 @@ extern "C" int zsmi_compressBatchHost(zsmi_ctx *c, const void *src, const uint64
     if (rc) return rc;
     if (hipMemcpyAsync(dstSizes, dSizes, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return ZSMI_error_GENERIC;
-    // copy back only what was produced
-    bool contiguous = true;
-    for (uint32_t i = 0; i < n; i++) if (dstSizes[i] > 0xFFFFFF88u) contiguous = false;
-    (void)contiguous;
-    for (uint32_t i = 0; i < n; i++) {
-        if (dstSizes[i] > 0xFFFFFF88u) continue;
-        if (hipMemcpyAsync((uint8_t *)dst + dstOffsets[i], (const uint8_t *)c->sDst.p + dof[i], dstSizes[i], hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
-    }
-    return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : ZSMI_error_GENERIC;
+    return copyBack(c, (const uint8_t *)c->sDst.p, dof.data(), (uint8_t *)dst, dstOffsets, dstSizes, n);
 }
 static int decompressBatchHostImpl(zsmi_ctx *c, const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
                                    uint32_t n, void *dst, const uint64_t *dstOffsets, const uint32_t *dstCaps, uint32_t *dstSizes,
@@ -534,11 +569,7 @@ static int decompressBatchHostImpl(zsmi_ctx *c, const void *src, const uint64_t 
     if (rc) return rc;
     if (hipMemcpyAsync(dstSizes, c->sSizes.p, sizeof(uint32_t) * n, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
     if (hipStreamSynchronize(c->stream) != hipSuccess) return ZSMI_error_GENERIC;
-    for (uint32_t i = 0; i < n; i++) {
-        if (dstSizes[i] > 0xFFFFFF88u || dstSizes[i] == 0) continue;
-        if (hipMemcpyAsync((uint8_t *)dst + dstOffsets[i], (const uint8_t *)c->sDst.p + dof[i], dstSizes[i], hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
-    }
-    return hipStreamSynchronize(c->stream) == hipSuccess ? 0 : ZSMI_error_GENERIC;
+    return copyBack(c, (const uint8_t *)c->sDst.p, dof.data(), (uint8_t *)dst, dstOffsets, dstSizes, n);
 }
 
 extern "C" int zsmi_decompressBatchHost(zsmi_ctx *c, const void *src, const uint64_t *srcOffsets, const uint32_t *srcSizes,
