@@ -9,29 +9,39 @@
 #include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
-// k_lz_candidates<TLOG, NT> : one workgroup of NT wavefronts per LZ unit; wavefront t owns table t in LDS.
+// k_lz_candidates<TLOG, NT> : one workgroup of 2 NT wavefronts per LZ unit: an OWNER and a HASHER wavefront per table.
 //   table 0 "short": hash of the 5 bytes at p, table 1 "long" (NT == 2: level >= 3): hash of the 8 bytes at p;
 //   2^TLOG 32-bit slots each (TLOG 13: units <= 64 KiB, 64 KiB of LDS for both; TLOG 14: units <= 128 KiB, 128 KiB).
 //   slot = tag (the 15 hash bits below the index bits) << 17 | position; 0xFFFFFFFF = empty.
-// A wavefront takes 64 consecutive positions per LDS exchange (ds_wrxchg_rtn_b32): every lane leaves its entry and gets the
+// The owner takes 64 consecutive positions per LDS exchange (ds_wrxchg_rtn_b32): every lane leaves its entry and gets the
 // slot's previous content back.  Lanes of one instruction that hit the same slot are served in ascending lane order
 // (tools/probe/lds_xchg.hip: 0 violations in 2e9 same-slot pairs on MI355X), and a wavefront's LDS instructions execute in
 // order: so position p receives exactly the last earlier position inserted with the same slot -- the sequential loop of
 // findCandidates in oracle/zso_encoder.c.  Same tag -> distance p - that position; the long table's distance wins.
 // Candidates are not compared with the source bytes here (index + tag = 28 hash bits agree; the walk measures every match).
-// The two wavefronts work in groups of G steps: each writes its G x 64 distances to an LDS exchange buffer, a barrier, then
-// each merges and stores half of the group:  dist[] (low 16 bits), distHi (bit 16, big units), distMask ("has a candidate").
-// The source bytes of a group reach the hashing lanes through a 4-group ring in LDS (one coalesced dword load per lane: each
-// wavefront stages its share two groups ahead).  HBM traffic per unit: reads n, writes 2 n + n / 8 (+ n / 8).
+//
+// Only the exchanges have to be made in order by one wavefront; everything around them is data parallel, and a wavefront that did
+// all of it was alone on its SIMD waiting out every latency (round 2, first shape: 1875 cycles per group of 512 positions, a third of
+// them issuing).  So the work of a table is cut in two roles that run side by side, a group (G = 8 steps of 64 positions) apart:
+//   hasher, interval i: hashes group i -- lane l takes the 8 positions 8 l .. 8 l + 7 of the group from two coalesced 8-byte loads
+//           (prefetched 4 .. 8 groups ahead) -- and leaves an operand word per position (tag << 17 | slot index) in an LDS ring;
+//           then merges group i - 2: long distance, else short; dist[] (low 16 bits), distHi (bit 16, big units), distMask.
+//   owner,  interval i: group i - 1: operand -> entry, exchange, distance (same tag and an earlier position) written over the operand.
+// One barrier per interval.  The operand ring holds 3 groups per table; a position's word sits at step * 64 + ((lane + step) & 63),
+// which spreads both the hashers' writes (8 consecutive positions a lane) and the owners' reads (64 consecutive) over all banks.
+// HBM traffic per unit: reads n (twice through L2: both hashers), writes 2 n + n / 8 (+ n / 8).
 // ---------------------------------------------------------------------------------------------
 #ifndef ZS_CAND_G
-#define ZS_CAND_G 8                // steps of 64 positions per group: exchanges issued back to back, one barrier per group (16: 85 KiB of LDS, one workgroup per CU)
+#define ZS_CAND_G 8                // steps of 64 positions per group
 #endif
 #ifndef ZS_CAND_DEPTH
-#define ZS_CAND_DEPTH 4            // a register set holds the source loads of this many groups (two sets: 4 .. 8 groups in flight)
+#define ZS_CAND_DEPTH 2            // a register set holds the source loads of this many groups (two sets: 4 .. 8 groups in flight)
 #endif
-#define ZS_CAND_RING (4u * ZS_CAND_G * 64u + 16u)                 // source bytes of 4 groups + the mirror of the first 16
-#define ZS_CAND_LDS(TLOG, NT) ((size_t)(NT) * (4u << (TLOG)) + ((NT) > 1 ? 2u * (NT) * ZS_CAND_G * 64u * 4u : 0u) + ZS_CAND_RING + (NT) * 256u)   // tables, exchange buffers, source ring, a dummy word per lane
+#ifndef ZS_CAND_MERGERS
+#define ZS_CAND_MERGERS 1            // 1: a third wavefront per table merges and stores (0: the hashers do)
+#endif
+#define ZS_CAND_WAVES(NT) ((2 + ZS_CAND_MERGERS) * (NT))
+#define ZS_CAND_LDS(TLOG, NT) ((size_t)(NT) * (4u << (TLOG)) + 3u * (NT) * ZS_CAND_G * 64u * 4u + (NT) * 256u)   // tables, operand ring, a dummy word per owner lane
 #define ZS_SLOT_EMPTY 0xFFFFFFFFu
 // hashes made of 24 x 24 -> 32 bit multiplies (v_mul_u32_u24 / v_mad_u32_u24: full rate; a v_mul_lo_u32 is quarter rate and the first
 // version's two per long hash were a quarter of the kernel's issue slots).  short: bytes 0-2 and 2-4; long: bytes 0-2, 3-5, 6-7
@@ -41,20 +51,20 @@ __device__ __forceinline__ uint32_t zs_hash_long(uint32_t lo, uint32_t hi)
 { return __umul24(lo, 0x9E3779u) + __umul24(__builtin_amdgcn_alignbit(hi, lo, 24), 0x85EBCBu) + __umul24(hi >> 16, 0xC2B2AFu); }
 
 template <int TLOG, int NT>
-__global__ void __launch_bounds__(64 * NT)
+__global__ void __launch_bounds__(64 * ZS_CAND_WAVES(NT))
 k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units, uint32_t block0,
                 uint16_t *__restrict__ distAll, uint8_t *__restrict__ distHiAll, uint8_t *__restrict__ distMaskAll)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t candLds[];
     constexpr bool BIG = TLOG > ZS_TABLE_LOG_SMALL;
-    constexpr uint32_t G = ZS_CAND_G, GP = G * 64u, H = (NT > 1) ? G / 2 : G;     // H: steps of a group a wavefront stores
+    constexpr uint32_t G = ZS_CAND_G, GP = G * 64u, H = G / NT;         // H: steps of a group a hasher merges and stores
     constexpr uint32_t M = ZS_CAND_DEPTH;
-    constexpr uint32_t PART = GP / NT, PW = PART / 256;               // source bytes of a group a wavefront stages; dwords per lane
+    static_assert(G == 8, "a hasher lane takes 8 consecutive positions of a group");
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
-    uint32_t *T = candLds + ((size_t)wave << TLOG);
-    uint32_t *xbuf = candLds + ((size_t)NT << TLOG);                  // [group parity][table][GP]
-    uint8_t *ring = reinterpret_cast<uint8_t *>(xbuf + ((NT > 1) ? 2u * NT * GP : 0u));       // source bytes of 4 groups + 16
-    const uint32_t dummy = (uint32_t)((reinterpret_cast<uint32_t *>(ring) + ZS_CAND_RING / 4 + threadIdx.x) - T);   // a word of this lane's own behind everything
+    const uint32_t tab = (wave < NT) ? wave : ((wave < 2 * NT) ? wave - NT : wave - 2 * NT);   // wavefronts [0, NT): owners, [NT, 2 NT): hashers, [2 NT, 3 NT): mergers
+    uint32_t *T = candLds + ((size_t)tab << TLOG);
+    uint32_t *opnd = candLds + ((size_t)NT << TLOG);                     // [3][NT][GP]
+    constexpr uint32_t RING = 3u * NT * GP;
     const ZsUnitDesc ud = units[blockIdx.x];
     const uint8_t *s = src + ud.srcOff;
     const uint32_t n = ud.size;
@@ -62,140 +72,157 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     uint16_t *dist = distAll + slot * ZS_BLOCK_MAX;
     uint8_t *distHi = distHiAll + slot * (ZS_BLOCK_MAX / 8);
     uint8_t *distMask = distMaskAll + slot * (ZS_BLOCK_MAX / 8);     // bit p: position p has a candidate
-
-    {   // each wavefront clears its own table (its LDS instructions execute in order: no barrier needed before it uses it)
-        uint4 *t4 = reinterpret_cast<uint4 *>(T);
-        const uint4 e = make_uint4(ZS_SLOT_EMPTY, ZS_SLOT_EMPTY, ZS_SLOT_EMPTY, ZS_SLOT_EMPTY);
-        #pragma unroll 8
-        for (uint32_t i = lane; i < (1u << TLOG) / 4; i += 64) t4[i] = e;
-    }
     const uint32_t hashable = (n >= 8) ? n - 7 : 0;                   // positions [0, hashable) have 8 bytes
     const uint32_t nGroups = (hashable + GP - 1) / GP;
     if (nGroups == 0) return;
-    const uint32_t lastWord = n - 4;                                  // loads are clamped, never branched around
-
-    // The source bytes reach the hashing lanes through a ring in LDS: group g lies at ring[(g & 3) * GP ...), staged by the NT
-    // wavefronts a part each with one coalesced load per lane (a lane fetching its own 8 bytes at p, p + 1, ... is an unaligned
-    // access per lane: the texture addresser serialised them and bound the kernel).  A lane reads the three dwords around its
-    // position and shifts (lane & 3 is its byte offset in every step).  The ring's first 16 bytes are mirrored behind its end.
-    auto loadPart = [&](uint32_t g, uint32_t (&w)[PW]) {
+    // a position that is not inserted (behind the hashable ones) exchanges with a word of its owner lane's own behind the ring;
+    // index relative to the owner's table, < 2^16
+    const uint32_t dummyBase = ((uint32_t)(NT - tab) << TLOG) + RING + tab * 64u;
+    // merge of a group (both tables' distances -> dist / distMask / distHi): this wavefront's H steps of it
+    uint32_t mrot[H];                                                    // the word of step tab * H + uu, lane
+    #pragma unroll
+    for (uint32_t uu = 0; uu < H; uu++) { const uint32_t u = (NT > 1 ? tab * H : 0u) + uu; mrot[uu] = u * 64u + ((lane + u) & 63u); }
+    auto mergeRead = [&](uint32_t g, uint32_t (&mS)[H], uint32_t (&mL)[H]) {
+        const uint32_t *xb = opnd + (size_t)(g % 3u) * NT * GP;
         #pragma unroll
-        for (uint32_t k = 0; k < PW; k++) {
-            // a word that would pass the unit's end is read at the last whole word and shifted down: the bytes below the end stay right
-            const uint32_t o = g * GP + wave * PART + k * 256u + lane * 4u, oc = min(o, lastWord);
-            w[k] = zs_load32(s + oc) >> (8u * min(o - oc, 3u));
+        for (uint32_t uu = 0; uu < H; uu++) { mS[uu] = xb[mrot[uu]]; mL[uu] = (NT > 1) ? xb[GP + mrot[uu]] : 0u; }
+    };
+    auto mergeStore = [&](uint32_t g, const uint32_t (&mS)[H], const uint32_t (&mL)[H]) {
+        // candidate bits (and bit 16 of the distances): lane uu keeps step uu's word, so each plane takes one store of H * 8
+        // contiguous bytes.  (What is stored for positions behind the hashable ones is never read: the walk stops at them.)
+        const uint32_t sbase = g * GP + ((NT > 1) ? tab * H * 64u : 0u);
+        uint64_t pmMine = 0, hiMine = 0;
+        #pragma unroll
+        for (uint32_t uu = 0; uu < H; uu++) {
+            const uint32_t dm = (NT > 1) ? (mL[uu] ? mL[uu] : mS[uu]) : mS[uu];
+            if (BIG) { const uint64_t hi = __ballot((dm >> 16) != 0); if (lane == uu) hiMine = hi; }
+            const uint64_t pm = __ballot(dm != 0);
+            if (lane == uu) pmMine = pm;
+            dist[sbase + uu * 64 + lane] = (uint16_t)dm;
+        }
+        if (lane < H) {
+            *reinterpret_cast<uint64_t *>(distMask + ((sbase + lane * 64) >> 3)) = pmMine;
+            if (BIG) *reinterpret_cast<uint64_t *>(distHi + ((sbase + lane * 64) >> 3)) = hiMine;
         }
     };
-    auto stagePart = [&](uint32_t g, const uint32_t (&w)[PW]) {
-        uint8_t *dst = ring + (g & 3u) * GP + wave * PART + lane * 4u;
+    if (ZS_CAND_MERGERS && wave >= 2 * NT) {
+        // ---------------- merger: interval i merges group i - 2 ----------------
+        __syncthreads(); __syncthreads();
+        for (uint32_t i = 2; i <= nGroups + 1; i++) {
+            uint32_t mS[H], mL[H];
+            mergeRead(i - 2, mS, mL);
+            mergeStore(i - 2, mS, mL);
+            __syncthreads();
+        }
+        return;
+    }
+
+    if (wave < NT) {
+        // ---------------- owner ----------------
+        {   // clears its own table (its LDS instructions execute in order: no barrier needed before it uses it)
+            uint4 *t4 = reinterpret_cast<uint4 *>(T);
+            const uint4 e = make_uint4(ZS_SLOT_EMPTY, ZS_SLOT_EMPTY, ZS_SLOT_EMPTY, ZS_SLOT_EMPTY);
+            #pragma unroll 8
+            for (uint32_t i = lane; i < (1u << TLOG) / 4; i += 64) t4[i] = e;
+        }
+        uint32_t rot[G];                                                 // where the lane's word of step u sits
         #pragma unroll
-        for (uint32_t k = 0; k < PW; k++) *reinterpret_cast<uint32_t *>(dst + k * 256u) = w[k];
-        if ((g & 3u) == 0 && wave == 0 && lane < 4) *reinterpret_cast<uint32_t *>(ring + 4u * GP + lane * 4u) = w[0];
-    };
-    // Software pipeline over the groups (a wavefront is alone on its SIMD: nothing else hides its latencies).  Iteration g:
-    //   1. distances of group g - 1 from the exchange results that came back during the last iteration -> LDS exchange buffer
-    //   2. stage this wavefront's part of group g + 2 (loaded M .. 2 M iterations earlier); 3. barrier
-    //   4. issue the reads of this wavefront's half of both tables' distances of group g - 1
-    //   5. hash group g (its ring words were read during the last iteration) and issue its G exchanges (they run while 6 is done and
-    //      until the next iteration's step 1); issue the ring reads of group g + 1
-    //   6. merge, candidate bits, stores of group g - 1
-    // Loads in flight live in two register sets A and B of M groups each, addressed statically; the loop body is
-    // [load B | M iterations on A | load A | M iterations on B].  The compiler puts a full s_waitcnt vmcnt(0) at the loop head (it
-    // cannot count loads across the back edge): there it only meets the loads of A issued M iterations earlier.
-    auto run = [&](auto roleTag) {
-        constexpr bool LONG = decltype(roleTag)::value;
-        uint32_t bufA[M][PW], bufB[M][PW];
-        auto loadM = [&](uint32_t g0, uint32_t (&buf)[M][PW]) {
+        for (uint32_t u = 0; u < G; u++) rot[u] = u * 64u + ((lane + u) & 63u);
+        uint32_t ringSlot = 0;                                           // (i - 1) % 3
+        __syncthreads();                                                 // interval 0: the hashers fill group 0
+        for (uint32_t i = 1; i <= nGroups; i++) {
+            uint32_t *ob = opnd + ((size_t)ringSlot * NT + tab) * GP;
+            const uint32_t base = (i - 1) * GP + lane;
+            uint32_t op[G], entry[G], old[G];
             #pragma unroll
-            for (uint32_t k = 0; k < M; k++) loadPart(min(g0 + k, nGroups), buf[k]);
-        };
-        uint32_t entry[G], old[G];
-        #pragma unroll
-        for (uint32_t u = 0; u < G; u++) { entry[u] = 0; old[u] = ZS_SLOT_EMPTY; }
-        uint32_t w0[G], w1[G], w2[G];                                        // the three dwords around each of the lane's G positions of the next group to hash
-        auto readRing = [&](uint32_t g) {
-            const uint32_t *rp = reinterpret_cast<const uint32_t *>(ring + (g & 3u) * GP + (lane & ~3u));
+            for (uint32_t u = 0; u < G; u++) op[u] = ob[rot[u]];
             #pragma unroll
-            for (uint32_t u = 0; u < G; u++) { w0[u] = rp[u * 16]; w1[u] = rp[u * 16 + 1]; w2[u] = rp[u * 16 + 2]; }
-        };
-        auto iter = [&](auto wholeTag, uint32_t g, const uint32_t (&wNext)[PW]) {
-            constexpr bool WHOLE = decltype(wholeTag)::value;                // group g lies wholly inside the hashable positions
-            const uint32_t pbase = (g - 1) * GP;                             // group g - 1 (nothing of it is kept when g == 0)
-            uint32_t d[G];
+            for (uint32_t u = 0; u < G; u++) {                           // the G exchanges go to the LDS back to back
+                entry[u] = (op[u] & 0xFFFE0000u) | (base + u * 64u);
+                old[u] = atomicExch(&T[op[u] & 0xFFFFu], entry[u]);
+            }
             #pragma unroll
             for (uint32_t u = 0; u < G; u++) {
                 // same tag: entry - old is the distance (the tags cancel).  It counts if it is positive: an empty slot reads as
                 // position 131071, behind every position; both conditions in one compare: max(old ^ entry, entry - old) < 2^17.
                 const uint32_t x = old[u] ^ entry[u], dd = entry[u] - old[u];
-                d[u] = (max(x, dd) < (1u << 17)) ? dd : 0u;
+                ob[rot[u]] = (max(x, dd) < (1u << 17)) ? dd : 0u;
             }
-            uint32_t mS[H], mL[H];
-            if (NT > 1) {
-                uint32_t *xb = xbuf + (size_t)(g & 1u) * NT * GP;
-                #pragma unroll
-                for (uint32_t u = 0; u < G; u++) xb[wave * GP + u * 64 + lane] = d[u];
-                stagePart(g + 2, wNext);
-                __syncthreads();
-                #pragma unroll
-                for (uint32_t uu = 0; uu < H; uu++) { const uint32_t u = wave * H + uu; mS[uu] = xb[u * 64 + lane]; mL[uu] = xb[GP + u * 64 + lane]; }
-            } else stagePart(g + 2, wNext);
-            {
-                const uint32_t base = g * GP;                                // group g (behind the last group: dummy exchanges)
-                #pragma unroll
-                for (uint32_t u = 0; u < G; u++) {                           // the G exchanges go to the LDS back to back
-                    const uint32_t p = base + u * 64 + lane;
-                    const uint32_t lo = __builtin_amdgcn_alignbyte(w1[u], w0[u], lane & 3u), hi = __builtin_amdgcn_alignbyte(w2[u], w1[u], lane & 3u);
-                    uint32_t h = LONG ? zs_hash_long(lo, hi) : zs_hash_short(lo, hi);
-                    asm volatile("" : "+v"(h));                              // (keeps the compiler from folding the shifts below into two more multiplies)
-                    entry[u] = ((h << TLOG) & 0xFFFE0000u) | (p & 0x1FFFFu);
-                    const uint32_t idx = h >> (32 - TLOG);
-                    old[u] = atomicExch(&T[(WHOLE || p < hashable) ? idx : dummy], entry[u]);
-                }
-                readRing(g + 1);                                             // group g + 1 is in the ring since this iteration's barrier: its words travel under the stores below
-            }
-            if (g > 0) {
-                // candidate bits (and bit 16 of the distances) of this wavefront's H steps of group g - 1: lane uu keeps step uu's
-                // word, so each plane takes one store of H * 8 contiguous bytes.  (What is stored for positions behind the
-                // hashable ones is never read: the walk stops at them.)
-                const uint32_t sbase = pbase + ((NT > 1) ? wave * H * 64u : 0u);
-                uint64_t pmMine = 0, hiMine = 0;
-                #pragma unroll
-                for (uint32_t uu = 0; uu < H; uu++) {
-                    const uint32_t dm = (NT > 1) ? (mL[uu] ? mL[uu] : mS[uu]) : d[uu];
-                    if (BIG) { const uint64_t hi = __ballot((dm >> 16) != 0); if (lane == uu) hiMine = hi; }
-                    const uint64_t pm = __ballot(dm != 0);
-                    if (lane == uu) pmMine = pm;
-                    dist[sbase + uu * 64 + lane] = (uint16_t)dm;
-                }
-                if (lane < H) {
-                    *reinterpret_cast<uint64_t *>(distMask + ((sbase + lane * 64) >> 3)) = pmMine;
-                    if (BIG) *reinterpret_cast<uint64_t *>(distHi + ((sbase + lane * 64) >> 3)) = hiMine;
-                }
-            }
-        };
-        auto step = [&](uint32_t g, const uint32_t (&wNext)[PW]) {
-            if (g > nGroups) return;
-            if ((g + 1) * GP <= hashable) iter(std::true_type{}, g, wNext); else iter(std::false_type{}, g, wNext);
-        };
-        {   // groups 0 and 1 into the ring; register set A = the parts of groups 2 .. M + 1 (staged by iterations 0 .. M - 1: a group's words
-            // are read an iteration before it is hashed, and its last positions need the first bytes of the group behind it)
-            uint32_t wa[PW], wb[PW];
-            loadPart(0, wa); loadPart(min(1u, nGroups), wb);
-            stagePart(0, wa); stagePart(1, wb);
-            loadM(2, bufA);
-            if (NT > 1) __syncthreads();
-            readRing(0);
+            ringSlot = (ringSlot == 2u) ? 0u : ringSlot + 1u;
+            __syncthreads();
         }
-        for (uint32_t g0 = 0; g0 <= nGroups; g0 += 2 * M) {
-            loadM(g0 + M + 2, bufB);
+        __syncthreads();                                                 // interval nGroups + 1: the hashers merge the last group
+        return;
+    }
+
+    // ---------------- hasher ----------------
+    // Loads in flight live in two register sets A and B of M groups each, addressed statically; the loop body is
+    // [load B | M intervals on A | load A | M intervals on B].  The compiler puts a full s_waitcnt vmcnt(0) at the loop head (it
+    // cannot count loads across the back edge): there it only meets the loads of A issued M intervals earlier.
+    auto run = [&](auto roleTag) {
+        constexpr bool LONG = decltype(roleTag)::value;
+        const uint32_t stepOfLane = lane >> 3, l0 = (lane & 7u) * 8u;    // the lane's positions 8 lane + u = step (lane >> 3), owner lane l0 + u
+        uint32_t widx[G];
+        #pragma unroll
+        for (uint32_t u = 0; u < G; u++) widx[u] = stepOfLane * 64u + ((l0 + u + stepOfLane) & 63u);
+        const uint32_t last8 = n - 8;                                    // loads are clamped, never branched around
+        auto loadGroup = [&](uint32_t g, uint32_t (&w)[4]) {
+            // bytes [o, o + 16) of the unit; a piece that would pass the unit's end is read at the last whole 8 bytes and shifted down
+            // (the bytes below the end stay right, nothing behind the end is touched)
+            const uint32_t o = g * GP + lane * 8u;
+            const uint32_t oa = min(o, last8), ob = min(o + 8u, last8);
+            const uint64_t a = zs_load64(s + oa) >> (8u * min(o - oa, 7u));
+            const uint64_t b = zs_load64(s + ob) >> (8u * min(o + 8u - ob, 7u));
+            w[0] = (uint32_t)a; w[1] = (uint32_t)(a >> 32); w[2] = (uint32_t)b; w[3] = (uint32_t)(b >> 32);
+        };
+        uint32_t bufA[M][4], bufB[M][4];
+        auto loadM = [&](uint32_t g0, uint32_t (&buf)[M][4]) {
+            #pragma unroll
+            for (uint32_t k = 0; k < M; k++) loadGroup(min(g0 + k, nGroups), buf[k]);
+        };
+        auto iter = [&](auto wholeTag, uint32_t i, const uint32_t (&w)[4]) {
+            constexpr bool WHOLE = decltype(wholeTag)::value;            // group i lies wholly inside the hashable positions
+            const uint32_t ringSlot = i % 3u;
+            // distances of group i - 2 (both tables): reads issued first, they travel under the hashing
+            uint32_t mS[H], mL[H];
+            if (!ZS_CAND_MERGERS && i >= 2) mergeRead(i - 2, mS, mL);
+            if (i < nGroups) {
+                uint32_t *ob = opnd + ((size_t)ringSlot * NT + tab) * GP;
+                const uint32_t pbase = i * GP + lane * 8u;
+                #pragma unroll
+                for (uint32_t u = 0; u < G; u++) {
+                    const uint32_t k = u >> 2, sh = u & 3u;
+                    const uint32_t lo = sh ? __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh) : w[k];
+                    const uint32_t hi = sh ? __builtin_amdgcn_alignbyte(w[(k + 2) & 3], w[k + 1], sh) : w[k + 1];   // u == 4 needs no fourth dword beyond w[3]
+                    uint32_t h = LONG ? zs_hash_long(lo, hi) : zs_hash_short(lo, hi);
+                    asm volatile("" : "+v"(h));                          // (keeps the compiler from folding the shifts below into two more multiplies)
+                    // tag << 17 | index: the hash rotated left by TLOG holds both (bits 31..17 and TLOG-1..0)
+                    const uint32_t r = __builtin_amdgcn_alignbit(h, h, 32 - TLOG);
+                    ob[widx[u]] = (WHOLE || pbase + u < hashable) ? (r & (0xFFFE0000u | ((1u << TLOG) - 1u))) : ((r & 0xFFFE0000u) | (dummyBase + l0 + u));
+                }
+            }
+            if (!ZS_CAND_MERGERS && i >= 2) mergeStore(i - 2, mS, mL);
+            __syncthreads();
+        };
+        auto step = [&](uint32_t i, const uint32_t (&w)[4]) {
+            if (i > nGroups + 1) return;
+#ifdef ZS_CAND_NOWHOLE
+            iter(std::false_type{}, i, w);
+#else
+            if ((i + 1) * GP + 8u <= n) iter(std::true_type{}, i, w); else iter(std::false_type{}, i, w);
+#endif
+        };
+        loadM(0, bufA);
+        for (uint32_t g0 = 0; g0 <= nGroups + 1; g0 += 2 * M) {
+            loadM(g0 + M, bufB);
             #pragma unroll
             for (uint32_t k = 0; k < M; k++) step(g0 + k, bufA[k]);
-            loadM(g0 + 2 * M + 2, bufA);
+            loadM(g0 + 2 * M, bufA);
             #pragma unroll
             for (uint32_t k = 0; k < M; k++) step(g0 + M + k, bufB[k]);
         }
     };
-    if (wave == 0) run(std::false_type{}); else run(std::true_type{});
+    if (tab == 0) run(std::false_type{}); else run(std::true_type{});
 }
 
 // ---------------------------------------------------------------------------------------------

@@ -338,7 +338,7 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         // match search per LZ unit: small units (one block) and big units (two blocks) have their own kernel shapes
         const uint32_t s0 = c->smallBefore[chunk0], ns = c->smallBefore[chunk1] - s0, b0 = c->bigBefore[chunk0], nbig = c->bigBefore[chunk1] - b0;
         const ZsUnitDesc *dUS = (const ZsUnitDesc *)c->dUnits.p + s0, *dUB = (const ZsUnitDesc *)c->dUnits.p + c->planSmall + b0;
-        #define CAND_LAUNCH(name, TL, NT, cnt, du) LAUNCH_ON(c, st, name, (k_lz_candidates<TL, NT>), dim3(cnt), dim3(64 * NT), ZS_CAND_LDS(TL, NT), (const uint8_t *)dSrc, du, block0, \
+        #define CAND_LAUNCH(name, TL, NT, cnt, du) LAUNCH_ON(c, st, name, (k_lz_candidates<TL, NT>), dim3(cnt), dim3(64 * ZS_CAND_WAVES(NT)), ZS_CAND_LDS(TL, NT), (const uint8_t *)dSrc, du, block0, \
                           (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, (uint8_t *)L.dDistMask.p)
         if (ns) { if (useLong) CAND_LAUNCH("k_lz_candidates", ZS_TABLE_LOG_SMALL, 2, ns, dUS); else CAND_LAUNCH("k_lz_candidates", ZS_TABLE_LOG_SMALL, 1, ns, dUS); }
         if (nbig) { if (useLong) CAND_LAUNCH("k_lz_candidates_big", ZS_TABLE_LOG_BIG, 2, nbig, dUB); else CAND_LAUNCH("k_lz_candidates_big", ZS_TABLE_LOG_BIG, 1, nbig, dUB); }
