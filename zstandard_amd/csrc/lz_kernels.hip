@@ -27,8 +27,9 @@
 //           (prefetched 4 .. 8 groups ahead) -- and leaves an operand word per position (tag << 17 | slot index) in an LDS ring;
 //           then merges group i - 2: long distance, else short; dist[] (low 16 bits), distHi (bit 16, big units), distMask.
 //   owner,  interval i: group i - 1: operand -> entry, exchange, distance (same tag and an earlier position) written over the operand.
-// One barrier per interval.  The operand ring holds 3 groups per table; a position's word sits at step * 64 + ((lane + step) & 63),
-// which spreads both the hashers' writes (8 consecutive positions a lane) and the owners' reads (64 consecutive) over all banks.
+// One barrier per interval.  The operand ring holds 3 groups per table; a step's 64 words are ZS_CAND_ROW = 65 words apart, which
+// spreads both the hashers' writes (8 consecutive positions a lane) and the owners' reads (64 consecutive) over all banks and keeps
+// every address of the form base + constant.
 // HBM traffic per unit: reads n (twice through L2: both hashers), writes 2 n + n / 8 (+ n / 8).
 // ---------------------------------------------------------------------------------------------
 #ifndef ZS_CAND_G
@@ -41,7 +42,8 @@
 #define ZS_CAND_MERGERS 1            // 1: a third wavefront per table merges and stores (0: the hashers do)
 #endif
 #define ZS_CAND_WAVES(NT) ((2 + ZS_CAND_MERGERS) * (NT))
-#define ZS_CAND_LDS(TLOG, NT) ((size_t)(NT) * (4u << (TLOG)) + 3u * (NT) * ZS_CAND_G * 64u * 4u + (NT) * 256u)   // tables, operand ring, a dummy word per owner lane
+#define ZS_CAND_ROW 65u            // words per step in the operand ring (64 + 1 of padding)
+#define ZS_CAND_LDS(TLOG, NT) ((size_t)(NT) * (4u << (TLOG)) + 3u * (NT) * ZS_CAND_G * ZS_CAND_ROW * 4u + (NT) * 256u)   // tables, operand ring, a dummy word per owner lane
 #define ZS_SLOT_EMPTY 0xFFFFFFFFu
 // hashes made of 24 x 24 -> 32 bit multiplies (v_mul_u32_u24 / v_mad_u32_u24: full rate; a v_mul_lo_u32 is quarter rate and the first
 // version's two per long hash were a quarter of the kernel's issue slots).  short: bytes 0-2 and 2-4; long: bytes 0-2, 3-5, 6-7
@@ -64,7 +66,8 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     const uint32_t tab = (wave < NT) ? wave : ((wave < 2 * NT) ? wave - NT : wave - 2 * NT);   // wavefronts [0, NT): owners, [NT, 2 NT): hashers, [2 NT, 3 NT): mergers
     uint32_t *T = candLds + ((size_t)tab << TLOG);
     uint32_t *opnd = candLds + ((size_t)NT << TLOG);                     // [3][NT][GP]
-    constexpr uint32_t RING = 3u * NT * GP;
+    constexpr uint32_t ROW = ZS_CAND_ROW, GR = G * ROW;                  // words of a group in the ring, per table
+    constexpr uint32_t RING = 3u * NT * GR;
     const ZsUnitDesc ud = units[blockIdx.x];
     const uint8_t *s = src + ud.srcOff;
     const uint32_t n = ud.size;
@@ -79,13 +82,10 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     // index relative to the owner's table, < 2^16
     const uint32_t dummyBase = ((uint32_t)(NT - tab) << TLOG) + RING + tab * 64u;
     // merge of a group (both tables' distances -> dist / distMask / distHi): this wavefront's H steps of it
-    uint32_t mrot[H];                                                    // the word of step tab * H + uu, lane
-    #pragma unroll
-    for (uint32_t uu = 0; uu < H; uu++) { const uint32_t u = (NT > 1 ? tab * H : 0u) + uu; mrot[uu] = u * 64u + ((lane + u) & 63u); }
     auto mergeRead = [&](uint32_t g, uint32_t (&mS)[H], uint32_t (&mL)[H]) {
-        const uint32_t *xb = opnd + (size_t)(g % 3u) * NT * GP;
+        const uint32_t *xb = opnd + (size_t)(g % 3u) * NT * GR + (NT > 1 ? tab * H : 0u) * ROW + lane;
         #pragma unroll
-        for (uint32_t uu = 0; uu < H; uu++) { mS[uu] = xb[mrot[uu]]; mL[uu] = (NT > 1) ? xb[GP + mrot[uu]] : 0u; }
+        for (uint32_t uu = 0; uu < H; uu++) { mS[uu] = xb[uu * ROW]; mL[uu] = (NT > 1) ? xb[GR + uu * ROW] : 0u; }
     };
     auto mergeStore = [&](uint32_t g, const uint32_t (&mS)[H], const uint32_t (&mL)[H]) {
         // candidate bits (and bit 16 of the distances): lane uu keeps step uu's word, so each plane takes one store of H * 8
@@ -125,20 +125,19 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
             #pragma unroll 8
             for (uint32_t i = lane; i < (1u << TLOG) / 4; i += 64) t4[i] = e;
         }
-        uint32_t rot[G];                                                 // where the lane's word of step u sits
-        #pragma unroll
-        for (uint32_t u = 0; u < G; u++) rot[u] = u * 64u + ((lane + u) & 63u);
         uint32_t ringSlot = 0;                                           // (i - 1) % 3
         __syncthreads();                                                 // interval 0: the hashers fill group 0
         for (uint32_t i = 1; i <= nGroups; i++) {
-            uint32_t *ob = opnd + ((size_t)ringSlot * NT + tab) * GP;
+            uint32_t *ob = opnd + ((size_t)ringSlot * NT + tab) * GR + lane;
             const uint32_t base = (i - 1) * GP + lane;
             uint32_t op[G], entry[G], old[G];
             #pragma unroll
-            for (uint32_t u = 0; u < G; u++) op[u] = ob[rot[u]];
+            for (uint32_t u = 0; u < G; u++) op[u] = ob[u * ROW];
             #pragma unroll
             for (uint32_t u = 0; u < G; u++) {                           // the G exchanges go to the LDS back to back
-                entry[u] = (op[u] & 0xFFFE0000u) | (base + u * 64u);
+                uint32_t pu = base + u * 64u;
+                asm volatile("" : "+v"(pu));                             // one add, then v_and_or (split into a scalar and a lane part it takes two ors)
+                entry[u] = (op[u] & 0xFFFE0000u) | pu;
                 old[u] = atomicExch(&T[op[u] & 0xFFFFu], entry[u]);
             }
             #pragma unroll
@@ -146,7 +145,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
                 // same tag: entry - old is the distance (the tags cancel).  It counts if it is positive: an empty slot reads as
                 // position 131071, behind every position; both conditions in one compare: max(old ^ entry, entry - old) < 2^17.
                 const uint32_t x = old[u] ^ entry[u], dd = entry[u] - old[u];
-                ob[rot[u]] = (max(x, dd) < (1u << 17)) ? dd : 0u;
+                ob[u * ROW] = (max(x, dd) < (1u << 17)) ? dd : 0u;
             }
             ringSlot = (ringSlot == 2u) ? 0u : ringSlot + 1u;
             __syncthreads();
@@ -162,9 +161,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     auto run = [&](auto roleTag) {
         constexpr bool LONG = decltype(roleTag)::value;
         const uint32_t stepOfLane = lane >> 3, l0 = (lane & 7u) * 8u;    // the lane's positions 8 lane + u = step (lane >> 3), owner lane l0 + u
-        uint32_t widx[G];
-        #pragma unroll
-        for (uint32_t u = 0; u < G; u++) widx[u] = stepOfLane * 64u + ((l0 + u + stepOfLane) & 63u);
+        const uint32_t wbase = stepOfLane * ROW + l0;
         const uint32_t last8 = n - 8;                                    // loads are clamped, never branched around
         auto loadGroup = [&](uint32_t g, uint32_t (&w)[4]) {
             // bytes [o, o + 16) of the unit; a piece that would pass the unit's end is read at the last whole 8 bytes and shifted down
@@ -187,7 +184,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
             uint32_t mS[H], mL[H];
             if (!ZS_CAND_MERGERS && i >= 2) mergeRead(i - 2, mS, mL);
             if (i < nGroups) {
-                uint32_t *ob = opnd + ((size_t)ringSlot * NT + tab) * GP;
+                uint32_t *ob = opnd + ((size_t)ringSlot * NT + tab) * GR + wbase;
                 const uint32_t pbase = i * GP + lane * 8u;
                 #pragma unroll
                 for (uint32_t u = 0; u < G; u++) {
@@ -198,7 +195,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
                     asm volatile("" : "+v"(h));                          // (keeps the compiler from folding the shifts below into two more multiplies)
                     // tag << 17 | index: the hash rotated left by TLOG holds both (bits 31..17 and TLOG-1..0)
                     const uint32_t r = __builtin_amdgcn_alignbit(h, h, 32 - TLOG);
-                    ob[widx[u]] = (WHOLE || pbase + u < hashable) ? (r & (0xFFFE0000u | ((1u << TLOG) - 1u))) : ((r & 0xFFFE0000u) | (dummyBase + l0 + u));
+                    ob[u] = (WHOLE || pbase + u < hashable) ? (r & (0xFFFE0000u | ((1u << TLOG) - 1u))) : ((r & 0xFFFE0000u) | (dummyBase + l0 + u));
                 }
             }
             if (!ZS_CAND_MERGERS && i >= 2) mergeStore(i - 2, mS, mL);
