@@ -94,7 +94,7 @@ def decode_leg(bc, args, rank, world, distributed, barrier, torch, dist):
     for _ in range(args.warmup):
         step()
     barrier()
-    bc.enable_timing(True)
+    bc.enable_timing(2)                     # events around the dominant kernel only (k_dec_execute)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -102,6 +102,11 @@ def decode_leg(bc, args, rank, world, distributed, barrier, torch, dist):
     barrier()
     elapsed = time.perf_counter() - t0
     kt = bc.kernel_times()
+    bc.enable_timing(True)                  # every kernel: the same steps once more, outside the timed region
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    kt_all = bc.kernel_times()
     bc.enable_timing(False)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -116,7 +121,7 @@ def decode_leg(bc, args, rank, world, distributed, barrier, torch, dist):
     per_launch = (nf * fs + comp) * args.steps / launches
     roof = {"bound": "hbm", "kernel": name, "achieved": round(per_launch / (secs / launches) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(per_launch / (secs / launches) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(per_launch),
-            "avg_launch_ms": round(secs / launches * 1e3, 4), "kernels_ms_per_step": {k: round(v[0] / args.steps * 1e3, 4) for k, v in kt.items()}}
+            "avg_launch_ms": round(secs / launches * 1e3, 4), "kernels_ms_per_step": {k: round(v[0] / args.steps * 1e3, 4) for k, v in kt_all.items()}}
     out = {"metric": f"GiB/s decompress (output bytes), frames of {fs} B", "value": round(nf * fs * world * args.steps / elapsed / (1 << 30), 3), "unit": "GiB/s",
            "frames_per_gpu_per_step": nf, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "verified": "whole output equals the input (torch.equal) after the timed region",
            "roofline": roof}
@@ -221,7 +226,7 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    bc.enable_timing(True)
+    bc.enable_timing(2)                     # HIP events around the dominant kernel only (k_lz_walk): the roofline's launch duration comes from the timed region
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -229,6 +234,12 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     ktimes = bc.kernel_times()
+    # every kernel's time: the same steps once more with events around every launch (ten event records a step cost ~2 % of it: not in the timed region)
+    bc.enable_timing(True)
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    ktimes_all = bc.kernel_times()
     bc.enable_timing(False)
 
     if distributed:
@@ -303,7 +314,8 @@ def main():
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": traffic, "algorithmic_bytes_per_launch": int(per_launch_bytes),
                         "avg_launch_ms": round(avg * 1e3, 4),
-                        "kernels_ms_per_step": {k: round(v[0] / args.steps * 1e3, 4) for k, v in ktimes.items()}}
+                        "kernels_ms_per_step": {k: round(v[0] / args.steps * 1e3, 4) for k, v in ktimes_all.items()},
+                        "kernels_ms_per_step_note": "second pass of the same steps with events around every launch; avg_launch_ms is from the timed region"}
             if traffic_note:
                 roofline["traffic_note"] = traffic_note
         # exactness spot check of the timed output + ratio yardstick

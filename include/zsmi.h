@@ -121,7 +121,9 @@ int zsmi_packFramesDevice(zsmi_ctx *ctx, const void *dFrames, const uint64_t *ds
                           uint32_t n, void *dPacked, uint64_t *dPackedOffsets);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of the kernels launched on the context's stream by the
- *      last batch call; one entry per kernel name, seconds are summed over launches.  Returns entries written. ---- */
+ *      last batch call; one entry per kernel name, seconds are summed over launches.  Returns entries written.
+ *      on = 1: events around every launch; on = 2: only around the dominant kernel of each direction (k_lz_walk*, k_dec_execute):
+ *      ten event records a step between five short kernels are not free, the timed region of bench.py carries two. ---- */
 typedef struct { char name[48]; double seconds; uint32_t launches; } zsmi_kernel_time;
 int zsmi_enableKernelTiming(zsmi_ctx *ctx, int on);
 int zsmi_getKernelTimes(zsmi_ctx *ctx, zsmi_kernel_time *out, int maxEntries);

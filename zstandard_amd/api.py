@@ -193,4 +193,5 @@ class BatchCodec:
         return {out[i].name.decode(): (out[i].seconds, out[i].launches) for i in range(k)}
 
     def enable_timing(self, on=True):
-        self.L.zsmi_enableKernelTiming(self.ctx, 1 if on else 0)
+        """True / 1: events around every launch; 2: only around the dominant kernel (k_lz_walk*, k_dec_execute); False: off"""
+        self.L.zsmi_enableKernelTiming(self.ctx, 2 if on == 2 else (1 if on else 0))

@@ -141,7 +141,7 @@ struct zsmi_ctx {
     DevBuf sSrc, sDst, sSizes, sDict, sPack, sPackOff;
     PinBuf hPack;
     // timing
-    bool timing = false;
+    int timing = 0;                      // 1: events around every launch; 2: only around the dominant kernels (k_lz_walk*, k_dec_execute)
     std::vector<TimedLaunch> launches;
     std::vector<hipEvent_t> eventPool;
 };
@@ -151,11 +151,13 @@ static hipEvent_t getEvent(zsmi_ctx *c)
     if (!c->eventPool.empty()) { hipEvent_t e = c->eventPool.back(); c->eventPool.pop_back(); return e; }
     hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
+static inline bool dominantKernel(const char *name) { return strncmp(name, "k_lz_walk", 9) == 0 || strncmp(name, "k_dec_execute", 13) == 0; }
 #define LAUNCH_ON(ctx, strm, name, kernel, grid, block, lds, ...) do { \
         TimedLaunch tl_{name, nullptr, nullptr}; \
-        if ((ctx)->timing) { tl_.a = getEvent(ctx); tl_.b = getEvent(ctx); (void)hipEventRecord(tl_.a, (strm)); } \
+        const bool timed_ = (ctx)->timing == 1 || ((ctx)->timing == 2 && dominantKernel(name)); \
+        if (timed_) { tl_.a = getEvent(ctx); tl_.b = getEvent(ctx); (void)hipEventRecord(tl_.a, (strm)); } \
         hipLaunchKernelGGL(kernel, grid, block, lds, (strm), __VA_ARGS__); \
-        if ((ctx)->timing) { (void)hipEventRecord(tl_.b, (strm)); (ctx)->launches.push_back(tl_); } \
+        if (timed_) { (void)hipEventRecord(tl_.b, (strm)); (ctx)->launches.push_back(tl_); } \
     } while (0)
 #define LAUNCH(ctx, name, kernel, grid, block, lds, ...) LAUNCH_ON(ctx, (ctx)->stream, name, kernel, grid, block, lds, __VA_ARGS__)
 
@@ -228,7 +230,7 @@ extern "C" int zsmi_sync(zsmi_ctx *c)
 extern "C" int zsmi_enableKernelTiming(zsmi_ctx *c, int on)
 {
     if (!c) return ZSMI_error_init_missing;
-    c->timing = on != 0;
+    c->timing = (on == 2) ? 2 : (on != 0);
     for (auto &tl : c->launches) { c->eventPool.push_back(tl.a); c->eventPool.push_back(tl.b); }
     c->launches.clear();
     return 0;
