@@ -7,7 +7,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 tag=$1
 timeout -k 5 600 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
-timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_stats -- python bench.py --no-cpu-baseline --no-extras > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_rocprof.err || exit 1
+timeout -k 5 400 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_stats -- python bench.py --no-cpu-baseline --no-extras --decode-frames 0 > gpurun_out/${tag}_bench_under_rocprof.json 2> gpurun_out/${tag}_rocprof.err || exit 1
 cp $(ls gpurun_out/prof_${tag}_stats/*/*_kernel_stats.csv | head -1) gpurun_out/${tag}_kernel_stats.csv
 run() { echo "pmc pass $1"; timeout -k 5 200 rocprofv3 --pmc $2 --kernel-trace --output-format csv -d gpurun_out/pmc_${tag}_$1 -- python bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extras --decode-frames 0 > gpurun_out/pmc_${tag}_$1.log 2>&1 || exit 1; }
 run a "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES"
