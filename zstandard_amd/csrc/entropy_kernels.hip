@@ -592,6 +592,47 @@ __device__ __forceinline__ void loadRangesWave(const ZsRangeHdr *hdr, uint32_t *
     if (lane == 63) { if (rngStart) rngStart[ZS_WALK_RANGES] = nsIncl; *lastLits = has ? total - Plast : total; *allLits = lsIncl; }
 }
 
+struct ZsChunkDesc { uint64_t srcOff; uint64_t dstOff; uint32_t size; uint32_t firstBlock; uint32_t nBlocks; uint32_t pad; };
+
+// frame header of a chunk (magic + FHD + FCS, single segment); returns its size.  One thread writes it.
+__device__ __forceinline__ uint32_t zs_frame_header(uint8_t *out, uint32_t size, bool writer)
+{
+    if (writer) {
+        out[0] = 0x28; out[1] = 0xB5; out[2] = 0x2F; out[3] = 0xFD;
+        if (size < 256) { out[4] = 0x20; out[5] = (uint8_t)size; }
+        else if (size < 65536 + 256) { out[4] = 0x60; const uint32_t v = size - 256; out[5] = (uint8_t)v; out[6] = (uint8_t)(v >> 8); }
+        else { out[4] = 0xA0; out[5] = (uint8_t)size; out[6] = (uint8_t)(size >> 8); out[7] = (uint8_t)(size >> 16); out[8] = (uint8_t)(size >> 24); }
+    }
+    return (size < 256) ? 6 : (size < 65536 + 256 ? 7 : 9);
+}
+// one block into its frame at out + pos (all threads of the workgroup); returns the bytes written.  A block is emitted compressed
+// iff both sections exist and literal section + sequence section < block size (else raw; RLE if flagged).
+__device__ __forceinline__ uint32_t zs_emit_block(uint8_t *out, uint32_t pos, const uint8_t *blockSrc, uint32_t n, uint32_t last, const ZsBlockMeta m,
+                                                 const uint8_t *p1, const uint8_t *p2, uint32_t tid, uint32_t nthreads)
+{
+    uint32_t type = m.type;
+    uint32_t total = 0;
+    if (type == 2) {
+        // same decisions as the scalar statement: room left after the literals, section failures, final size test
+        if (m.seqSecSize == 0xFFFFFFFFu || m.litSecSize + 4 > n + 512) type = 0;
+        else { total = m.litSecSize + m.seqSecSize; if (total > n + 512 || total >= n) type = 0; }
+    }
+    if (type == 1) {
+        if (tid == 0) { const uint32_t h = last + (1u << 1) + (n << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); out[pos + 3] = (uint8_t)m.rleByte; }
+        return 4;
+    }
+    if (type == 2) {
+        if (tid == 0) { const uint32_t h = last + (2u << 1) + (total << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); }
+        zs_block_copy(out + pos + 3, p1, m.litSecSize, tid, nthreads);
+        zs_block_copy(out + pos + 3 + m.litSecSize, p2, m.seqHdrSize, tid, nthreads);
+        zs_block_copy(out + pos + 3 + m.litSecSize + m.seqHdrSize, p2 + m.seqHdrSize + m.seqGap, m.seqSecSize - m.seqHdrSize, tid, nthreads);
+        return 3 + total;
+    }
+    if (tid == 0) { const uint32_t h = last + (0u << 1) + (n << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); }
+    zs_block_copy(out + pos + 3, blockSrc, n, tid, nthreads);
+    return 3 + n;
+}
+
 // ---------------------------------------------------------------------------------------------
 // k_encode_literals : one workgroup of 4 wavefronts per block.  Block type (raw for tiny blocks, RLE block),
 // literal gather + histogram (wavefront w takes ranges w and w+4), Huffman lengths by package-merge (256 threads),
@@ -601,7 +642,8 @@ extern "C" __global__ void __launch_bounds__(256, ZS_LIT_MINWG)
 k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict__ blocks,
                   const ZsSeqRec *__restrict__ seqAll, const ZsRangeHdr *__restrict__ hdrAll,
                   uint8_t *__restrict__ litsAll, uint8_t *__restrict__ streamAll, uint8_t *__restrict__ litSecAll,
-                  ZsBlockMeta *__restrict__ metas, int stopAt)
+                  ZsBlockMeta *__restrict__ metas, int stopAt,
+                  const ZsChunkDesc *__restrict__ chunks, const uint8_t *__restrict__ seqSecAll, uint8_t *__restrict__ dst, uint32_t *__restrict__ dstSizes)
 {
     __shared__ K3Lds L;
     const uint32_t blk = blockIdx.x;
@@ -616,7 +658,20 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     uint8_t *payload = litSecAll + (size_t)blk * ZS_LITSEC_STRIDE;
     const uint32_t cap = n + 512;
 
-    #define FINISH(tp, lsz, rb) do { if (tid == 0) { metas[blk].type = (tp); metas[blk].rleByte = (rb); metas[blk].litSecSize = (lsz); } return; } while (0)
+    // The block's literal side is done: its meta goes out; a chunk of ONE block is assembled right here (the sequences kernel ran before this
+    // one on the stream, its section and meta fields are there) - k_assemble_frames is launched only for batches with longer chunks
+    #define FINISH(tp, lsz, rb) do { \
+        if (tid == 0) { metas[blk].type = (tp); metas[blk].rleByte = (rb); metas[blk].litSecSize = (lsz); } \
+        if (bd.firstInChunk && bd.lastInChunk) { \
+            __syncthreads();                         /* the literal section was written by all wavefronts */ \
+            ZsBlockMeta m_ = metas[blk]; m_.type = (tp); m_.rleByte = (rb); m_.litSecSize = (lsz); \
+            const ZsChunkDesc cd_ = chunks[bd.chunk]; \
+            uint8_t *out_ = dst + cd_.dstOff; \
+            uint32_t pos_ = zs_frame_header(out_, cd_.size, tid == 0); \
+            pos_ += zs_emit_block(out_, pos_, s, n, 1u, m_, payload, seqSecAll + (size_t)blk * ZS_SEQSEC_STRIDE, tid, 256); \
+            if (tid == 0) dstSizes[bd.chunk] = pos_; \
+        } \
+        return; } while (0)
 
     if (n == 0) FINISH(0, 0, 0);
     {   // RLE block: every byte equal (ZStdDecompress.cs:1945-1950 on the decode side)
@@ -1215,7 +1270,6 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
 // + blocks  (inverse of ZStdDecompress.cs:421-499, 646-659, 2008-2091).  A block is emitted compressed
 // iff both sections exist and literal section + sequence section < block size (else raw; RLE if flagged).
 // ---------------------------------------------------------------------------------------------
-struct ZsChunkDesc { uint64_t srcOff; uint64_t dstOff; uint32_t size; uint32_t firstBlock; uint32_t nBlocks; uint32_t pad; };
 
 extern "C" __global__ void __launch_bounds__(256)
 k_assemble_frames(const uint8_t *__restrict__ src, const ZsChunkDesc *__restrict__ chunks, const ZsBlockDesc *__restrict__ blocks,
@@ -1223,47 +1277,16 @@ k_assemble_frames(const uint8_t *__restrict__ src, const ZsChunkDesc *__restrict
                   uint32_t blockBase, uint8_t *__restrict__ dst, uint32_t *__restrict__ dstSizes, uint32_t chunkBase)
 {
     const ZsChunkDesc cd = chunks[chunkBase + blockIdx.x];
+    if (cd.nBlocks <= 1) return;                               // one-block chunks were assembled by the literals kernel
     uint8_t *out = dst + cd.dstOff;
     const uint32_t tid = threadIdx.x;
-    uint32_t pos;
-    if (tid == 0) {
-        out[0] = 0x28; out[1] = 0xB5; out[2] = 0x2F; out[3] = 0xFD;
-        if (cd.size < 256) { out[4] = 0x20; out[5] = (uint8_t)cd.size; }
-        else if (cd.size < 65536 + 256) { out[4] = 0x60; const uint32_t v = cd.size - 256; out[5] = (uint8_t)v; out[6] = (uint8_t)(v >> 8); }
-        else { out[4] = 0xA0; out[5] = (uint8_t)cd.size; out[6] = (uint8_t)(cd.size >> 8); out[7] = (uint8_t)(cd.size >> 16); out[8] = (uint8_t)(cd.size >> 24); }
-    }
-    pos = (cd.size < 256) ? 6 : (cd.size < 65536 + 256 ? 7 : 9);
+    uint32_t pos = zs_frame_header(out, cd.size, tid == 0);
     for (uint32_t b = 0; b < cd.nBlocks; b++) {
         const uint32_t gb = cd.firstBlock + b;             // global block index
         const uint32_t lb = gb - blockBase;                // index inside this sub-batch's scratch
         const ZsBlockDesc bd = blocks[gb];
-        const ZsBlockMeta m = metas[lb];
-        const uint32_t last = (b + 1 == cd.nBlocks) ? 1u : 0u;
-        const uint32_t n = bd.size;
-        uint32_t type = m.type;
-        uint32_t total = 0;
-        if (type == 2) {
-            // same decisions as the scalar statement: room left after the literals, section failures, final size test
-            if (m.seqSecSize == 0xFFFFFFFFu || m.litSecSize + 4 > n + 512) type = 0;
-            else { total = m.litSecSize + m.seqSecSize; if (total > n + 512 || total >= n) type = 0; }
-        }
-        if (type == 1) {
-            if (tid == 0) { const uint32_t h = last + (1u << 1) + (n << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); out[pos + 3] = (uint8_t)m.rleByte; }
-            pos += 4;
-        } else if (type == 2) {
-            if (tid == 0) { const uint32_t h = last + (2u << 1) + (total << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); }
-            const uint8_t *p1 = litSecAll + (size_t)lb * ZS_LITSEC_STRIDE;
-            const uint8_t *p2 = seqSecAll + (size_t)lb * ZS_SEQSEC_STRIDE;
-            zs_block_copy(out + pos + 3, p1, m.litSecSize, tid, blockDim.x);
-            zs_block_copy(out + pos + 3 + m.litSecSize, p2, m.seqHdrSize, tid, blockDim.x);
-            zs_block_copy(out + pos + 3 + m.litSecSize + m.seqHdrSize, p2 + m.seqHdrSize + m.seqGap, m.seqSecSize - m.seqHdrSize, tid, blockDim.x);
-            pos += 3 + total;
-        } else {
-            if (tid == 0) { const uint32_t h = last + (0u << 1) + (n << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); }
-            const uint8_t *p = src + bd.srcOff;
-            zs_block_copy(out + pos + 3, p, n, tid, blockDim.x);
-            pos += 3 + n;
-        }
+        pos += zs_emit_block(out, pos, src + bd.srcOff, bd.size, (b + 1 == cd.nBlocks) ? 1u : 0u, metas[lb],
+                             litSecAll + (size_t)lb * ZS_LITSEC_STRIDE, seqSecAll + (size_t)lb * ZS_SEQSEC_STRIDE, tid, blockDim.x);
     }
     if (tid == 0) dstSizes[chunkBase + blockIdx.x] = pos;
 }

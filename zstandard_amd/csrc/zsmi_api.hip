@@ -118,11 +118,10 @@ struct zsmi_ctx {
     uint32_t maxBlocksInFlight = 8192;
     // compress workspace: plan (shared) + one scratch set per internal stream ("lane")
     DevBuf dBlocks, dChunks, dUnits;     // dUnits: small units (<= 64 KiB) first, then big ones, each in chunk order
-    struct Scratch { DevBuf dDist, dDistHi, dDistMask, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr, aux = nullptr; hipEvent_t done = nullptr, evWalk = nullptr, evSeq = nullptr; };
+    struct Scratch { DevBuf dDist, dDistHi, dDistMask, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
     static const int kMaxLanes = 8;
     Scratch lanes[kMaxLanes];
     int nLanes = 1;
-    bool overlapEntropy = false;           // ZSMI_OVERLAP=1: sequences kernel on a side stream beside the literals kernel (measured slower: both want the whole LDS)
     int stopLit = 0, stopSeq = 0;          // timing aids of a -DZSMI_DEBUG_HOOKS build (ZSMI_STOP_LIT / ZSMI_STOP_SEQ): end a kernel after a stage; always 0 in the product
     hipEvent_t evStart = nullptr;
     PinBuf hBlocks, hChunks, hUnits;
@@ -182,7 +181,6 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
         if (!ok) { (void)hipGetLastError(); if (c->ownStream) (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
     }
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
-    if (const char *e = getenv("ZSMI_OVERLAP")) c->overlapEntropy = atoi(e) != 0;
     if (const char *e = getenv("ZSMI_DEC_FAST")) c->decodeFast = atoi(e) != 0;
     if (const char *e = getenv("ZSMI_ITEMS_IN_FLIGHT")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->maxItemsInFlight = (uint32_t)v; }
 #ifdef ZSMI_DEBUG_HOOKS
@@ -192,9 +190,8 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     if (const char *e = getenv("ZSMI_LANES")) { long v = atol(e); if (v >= 1 && v <= zsmi_ctx::kMaxLanes) c->nLanes = (int)v; }
     // sub-batches of one call run on internal streams so that the latency-bound kernels of different sub-batches overlap
     for (int i = 0; i < c->nLanes; i++) {
-        if (hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) != hipSuccess || hipStreamCreateWithFlags(&c->lanes[i].aux, hipStreamNonBlocking) != hipSuccess ||
-            hipEventCreateWithFlags(&c->lanes[i].done, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->lanes[i].evWalk, hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&c->lanes[i].evSeq, hipEventDisableTiming) != hipSuccess) { c->nLanes = i; break; }
+        if (hipStreamCreateWithFlags(&c->lanes[i].stream, hipStreamNonBlocking) != hipSuccess ||
+            hipEventCreateWithFlags(&c->lanes[i].done, hipEventDisableTiming) != hipSuccess) { c->nLanes = i; break; }
     }
     if (c->nLanes == 0 || hipEventCreateWithFlags(&c->evStart, hipEventDisableTiming) != hipSuccess) { zsmi_freeCtx(c); return nullptr; }
     return c;
@@ -209,13 +206,10 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
         if (L.stream) (void)hipStreamSynchronize(L.stream);
         for (DevBuf *b : { &L.dDist, &L.dDistHi, &L.dDistMask, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dLitSec, &L.dSeqSec, &L.dMetas }) b->release();
         if (L.done) (void)hipEventDestroy(L.done);
-        if (L.evWalk) (void)hipEventDestroy(L.evWalk);
-        if (L.evSeq) (void)hipEventDestroy(L.evSeq);
-        if (L.aux) { (void)hipStreamSynchronize(L.aux); (void)hipStreamDestroy(L.aux); }
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     if (c->evStart) (void)hipEventDestroy(c->evStart);
-    for (PinBuf *b : { &c->hBlocks, &c->hChunks, &c->hUnits, &c->hItems }) b->release();
+    for (PinBuf *b : { &c->hBlocks, &c->hChunks, &c->hUnits, &c->hItems, &c->hPack }) b->release();
     for (auto &tl : c->launches) { (void)hipEventDestroy(tl.a); (void)hipEventDestroy(tl.b); }
     for (auto e : c->eventPool) (void)hipEventDestroy(e);
     if (c->ownStream) (void)hipStreamDestroy(c->stream);
@@ -349,17 +343,16 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
                           (const uint8_t *)L.dDistHi.p, (const uint8_t *)L.dDistMask.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
         if (nbig) LAUNCH_ON(c, st, "k_lz_walk_big", (k_lz_walk<128>), dim3(nbig), dim3(1024), ZS_WALK_LDS(ZS_UNIT_MAX), (const uint8_t *)dSrc, dUB, block0, (const uint16_t *)L.dDist.p,
                             (const uint8_t *)L.dDistHi.p, (const uint8_t *)L.dDistMask.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
-        // the two entropy kernels are independent of each other: the sequences kernel runs on a side stream beside the literals kernel
-        const bool overlap = c->overlapEntropy;
-        hipStream_t st2 = overlap ? L.aux : st;
-        if (overlap) { (void)hipEventRecord(L.evWalk, st); (void)hipStreamWaitEvent(st2, L.evWalk, 0); }
-        LAUNCH_ON(c, st2, "k_encode_sequences", (k_encode_sequences<ZS_SEQ_GROUP>), dim3((nb + ZS_SEQ_GROUP - 1) / ZS_SEQ_GROUP), dim3(64 * ZS_SEQ_GROUP), 0, dB, nb, (ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
+        // sequences first: the literals kernel assembles the frames of one-block chunks as its workgroups finish, and reads the sequence
+        // sections then.  (The two side by side on two streams was measured slower: both want the whole LDS.)
+        LAUNCH_ON(c, st, "k_encode_sequences", (k_encode_sequences<ZS_SEQ_GROUP>), dim3((nb + ZS_SEQ_GROUP - 1) / ZS_SEQ_GROUP), dim3(64 * ZS_SEQ_GROUP), 0, dB, nb, (ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
                   (uint8_t *)L.dSeqSec.p, (ZsBlockMeta *)L.dMetas.p, c->stopSeq);
         LAUNCH_ON(c, st, "k_encode_literals", k_encode_literals, dim3(nb), dim3(256), 0, (const uint8_t *)dSrc, dB, (const ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
-                  (uint8_t *)L.dLits.p, (uint8_t *)L.dStreams.p, (uint8_t *)L.dLitSec.p, (ZsBlockMeta *)L.dMetas.p, c->stopLit);
-        if (overlap) { (void)hipEventRecord(L.evSeq, st2); (void)hipStreamWaitEvent(st, L.evSeq, 0); }
-        LAUNCH_ON(c, st, "k_assemble_frames", k_assemble_frames, dim3(chunk1 - chunk0), dim3(256), 0, (const uint8_t *)dSrc, (const ZsChunkDesc *)c->dChunks.p,
-                  (const ZsBlockDesc *)c->dBlocks.p, (const ZsBlockMeta *)L.dMetas.p, (const uint8_t *)L.dLitSec.p, (const uint8_t *)L.dSeqSec.p, block0, (uint8_t *)dDst, dDstSizes, chunk0);
+                  (uint8_t *)L.dLits.p, (uint8_t *)L.dStreams.p, (uint8_t *)L.dLitSec.p, (ZsBlockMeta *)L.dMetas.p, c->stopLit,
+                  (const ZsChunkDesc *)c->dChunks.p, (const uint8_t *)L.dSeqSec.p, (uint8_t *)dDst, dDstSizes);
+        if (maxChunkBlocks > 1)                    // chunks of several blocks
+            LAUNCH_ON(c, st, "k_assemble_frames", k_assemble_frames, dim3(chunk1 - chunk0), dim3(256), 0, (const uint8_t *)dSrc, (const ZsChunkDesc *)c->dChunks.p,
+                      (const ZsBlockDesc *)c->dBlocks.p, (const ZsBlockMeta *)L.dMetas.p, (const uint8_t *)L.dLitSec.p, (const uint8_t *)L.dSeqSec.p, block0, (uint8_t *)dDst, dDstSizes, chunk0);
         chunk0 = chunk1;
     }
     for (int i = 0; i < nLanes; i++) {
