@@ -1179,6 +1179,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
             SeqLds &B = LS[g];
             const uint32_t Tg = chainLane ? B.misc[3] : 0u;
             const uint32_t Tmax = wave_max(Tg);
+            const bool allFull = __ballot(chainLane && Tg != 0u && !B.ct[c].rle && Tg != 64u) == 0ull;   // no moving lane has a part-filled tile
             if (chainLane && !ZS_STOP_AT(3)) {                    // stopAt 3: timing aid, no chains
                 const FseCT &ct = B.ct[c];
                 const uint2 *op = B.u.tile.op[c];
@@ -1202,6 +1203,28 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                 }
                 // its wavefront issues ahead of the others on its SIMD
                 __builtin_amdgcn_s_setprio(3);
+                if (allFull) {
+                    // Every chain lane that moves has a whole tile of 64 (all tiles but a block's last): the lanes that do not move sit out the
+                    // loop as a whole (one exec mask for the tile), so a step needs no select, no per-step mask and no zeroed operands:
+                    // add, shift (the count taken straight from the sum's high half), shift-add onto the step's table address, the read.
+                    if (moves) {
+                        typedef const __attribute__((address_space(3))) uint16_t *LdsU16;
+                        const uint32_t tabAddr = (uint32_t)(uintptr_t)(LdsU16)ct.stateTable;   // LDS byte address of this lane's table
+                        uint2 cur = op[t0];
+                        #define CHAIN_STEP(t) { \
+                            const uint2 nxt = op[(t) + 1];                                 /* operands of step t+1: read before the dependent lookup of step t */ \
+                            uint32_t pre = tabAddr + (cur.y << 1);                         /* off the chain: known a step ahead */ \
+                            asm("" : "+v"(pre));                                           /* (kept apart, so the chain's last op is one shift-add) */ \
+                            const uint32_t nbo = (chainState + cur.x) >> 16; \
+                            const uint32_t ns = *(LdsU16)(uintptr_t)(pre + ((chainState >> nbo) << 1)); \
+                            outp[t] = (chainState & ((1u << nbo) - 1)) | (nbo << 16); \
+                            chainState = ns; cur = nxt; }
+                        uint32_t t = t0;
+                        while (t & 3u) { CHAIN_STEP(t) t++; }
+                        for (; t < 64u; t += 4) { CHAIN_STEP(t) CHAIN_STEP(t + 1) CHAIN_STEP(t + 2) CHAIN_STEP(t + 3) }
+                        #undef CHAIN_STEP
+                    }
+                } else {
                 uint2 cur = moves ? op[t0] : make_uint2(0, 0);
                 #pragma unroll 4
                 for (uint32_t t = t0; t < Tmax; t++) {
@@ -1214,6 +1237,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                     chainState = (t < Tact) ? ns : chainState;
                     cur = nxt;
                 }
+                }
                 __builtin_amdgcn_s_setprio(0);
             }
         }
@@ -1222,7 +1246,8 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
             uint64_t lo = 0; uint32_t hi = 0, nb = 0;
             if (lane < T) {
                 #define PUTB(v, b) { const uint32_t b_ = (b); if (b_) { const uint64_t v_ = (uint64_t)(v); if (nb < 64) { lo |= v_ << nb; if (nb + b_ > 64) hi |= (uint32_t)(v_ >> (64 - nb)); } else hi |= (uint32_t)(v_ << (nb - 64)); nb += b_; } }
-                const uint32_t sOF = L.u.tile.tileState[1][lane], sML = L.u.tile.tileState[2][lane], sLL = L.u.tile.tileState[0][lane];
+                // (a table in RLE mode has one state and writes no bits: its chain lane may have sat the tile out)
+                const uint32_t sOF = L.ct[1].rle ? 0u : L.u.tile.tileState[1][lane], sML = L.ct[2].rle ? 0u : L.u.tile.tileState[2][lane], sLL = L.ct[0].rle ? 0u : L.u.tile.tileState[0][lane];
                 PUTB(sOF & 0xFFFFu, sOF >> 16);
                 PUTB(sML & 0xFFFFu, sML >> 16);
                 PUTB(sLL & 0xFFFFu, sLL >> 16);
