@@ -403,15 +403,25 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
                 // a sequence reads < 12 bytes of stream: stop for a refill while that much is still inside the window
                 if (b.bitPos > 0 && base > 0 && ((b.bitPos - 1) >> 3) < base + 24) break;
                 if (b.bitPos < 0) { ok = false; break; }                 // stream exhausted before all sequences (:1582, :1594)
+                // One LDS round trip a sequence: the three cells and the 8 stream bytes below the position are read together (no bit
+                // container carried from sequence to sequence: its refill was a second, dependent LDS read and a branch most steps took
+                // in some lane).  Bytes below the stream start read as zeros, as in bc_refill.
+                const int32_t bp = b.bitPos;
+                const int32_t bh = (bp - 1) >> 3;                        // bp == 0: -1, the 8 zero bytes in front of the stream
                 const uint32_t cLL = cells[sLL], cOF = cells[OFB + sOF], cML = cells[MLB + sML];
+                const uint64_t raw = win64(win, (uint32_t)(bh - base + 1));
                 uint32_t bLL, bML, bOF, nL, nM, nO, yLL, yML, yOF;
                 zs_fastcell_open(cLL, bLL, nL, yLL); zs_fastcell_open(cML, bML, nM, yML); zs_fastcell_open(cOF, bOF, nO, yOF);
-                outp[t++] = zs_fastseq((uint32_t)b.bitPos, yLL, yML, yOF);
+                outp[t++] = zs_fastseq((uint32_t)bp, yLL, yML, yOF);
                 const uint32_t xbits = zs_llExtraBits(yLL) + zs_mlExtraBits(yML) + yOF;                     // skipped here, read by the execute kernel
                 const uint32_t sbits = nL + nM + nO;
-                if (xbits + sbits <= 57u) { FSEQ_NEED(xbits + sbits); b.c <<= xbits; b.avail -= xbits; b.bitPos -= (int32_t)xbits; }
-                else { b.bitPos -= (int32_t)xbits; b.avail = 0; FSEQ_NEED(sbits); }
-                const uint32_t x = bc_take(b, sbits);                    // LL bits on top, then ML, then OF (:1547-1550)
+                uint64_t c = raw << (7u - (uint32_t)((bp - 1) & 7));     // >= 57 valid bits from the top
+                const int32_t p2 = bp - (int32_t)xbits;
+                if (xbits + sbits <= 57u) c <<= xbits;
+                else if (p2 <= 0) c = 0;
+                else c = win64(win, (uint32_t)(((p2 - 1) >> 3) - base + 1)) << (7u - (uint32_t)((p2 - 1) & 7));   // rare: very long offset + long lengths
+                const uint32_t x = __builtin_amdgcn_ubfe((uint32_t)(c >> 32), 32u - sbits, sbits);   // LL bits on top, then ML, then OF (:1547-1550)
+                b.bitPos = p2 - (int32_t)sbits;
                 sLL = bLL + __builtin_amdgcn_ubfe(x, nM + nO, nL);
                 sML = bML + __builtin_amdgcn_ubfe(x, nO, nM);
                 sOF = bOF + __builtin_amdgcn_ubfe(x, 0u, nO);
