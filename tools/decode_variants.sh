@@ -1,1 +1,7 @@
-for f in zstandard_amd/lib/libzsmi.so zstandard_amd/lib/var_*.so; do echo $f; ZSMI_LIB_FILE=$PWD/$f timeout -k 10 200 python tools/bench_decode.py 2>/dev/null | tail -1 | cut -c1-600 || exit 1; done
+#!/bin/bash
+# Development aid (GPU box): decode leg of bench.py for the product library and every zstandard_amd/lib/var_<name>.so
+for f in zstandard_amd/lib/libzsmi.so zstandard_amd/lib/var_*.so; do
+    ZSMI_LIB_FILE=$PWD/$f timeout -k 10 200 python bench.py --steps 5 --warmup 2 --no-extras --no-cpu-baseline 2>/dev/null | tail -1 | python -c "
+import sys, json
+d = json.loads(sys.stdin.read())['decode']; print('$f', d['value'], d['roofline']['kernels_ms_per_step'])" || exit 1
+done
