@@ -243,10 +243,13 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
 
 // K dwords of the LDS copy starting at any byte offset, fetched as K + 1 aligned dwords and shifted into place
 // (an unaligned ds_read_b64 / b128 costs the LDS several passes: SQ_LDS_UNALIGNED_STALL was 80 % of its busy time)
+// (byteOff is an LDS address: the kernel's dynamic LDS starts at address 0 - there is no static LDS in it, checked at its start - so
+// the compiler has no symbol to add to every address)
+typedef const __attribute__((address_space(3))) uint32_t *ZsLdsU32;
 template <int K>
-__device__ __forceinline__ void lds_span(const uint8_t *ldsBase, uint32_t byteOff, uint32_t (&out)[K])
+__device__ __forceinline__ void lds_span(uint32_t byteOff, uint32_t (&out)[K])
 {
-    const uint32_t *d = reinterpret_cast<const uint32_t *>(ldsBase + (byteOff & ~3u));
+    ZsLdsU32 d = (ZsLdsU32)(uintptr_t)(byteOff & ~3u);
     uint32_t w[K + 1];
     #pragma unroll
     for (int k = 0; k <= K; k++) w[k] = d[k];
@@ -266,6 +269,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
     constexpr bool BIG = CAP > ZS_BLOCK_MAX;
     extern __shared__ __attribute__((aligned(16))) uint8_t walkLds[];
     uint8_t *ls = walkLds + ZS_WALK_FRONT;                                       // ls[p] = source byte p
+    if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)walkLds != 0u) __builtin_trap();   // lds_span addresses LDS from 0
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const ZsUnitDesc ud = units[blockIdx.x];
     const uint32_t slot = ud.firstBlock - block0;                                // scratch slot of the unit's first block
@@ -328,6 +332,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
     const uint32_t scanEnd = alive ? min(end, hashable) : 0;
 
     uint32_t ip = start, anchor = start, nseq = 0, mlSum = 0, rep0 = 0, rep1 = 0;
+    const uint32_t bit0 = 1u << sub, bit1 = 256u << sub;
     for (;;) {
         const bool run = ip < scanEnd;
         if (!__any(run)) break;
@@ -339,14 +344,16 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
             const bool in0 = run && q < wend && q + 4 <= limit;
             const bool t0 = in0 && rep0 != 0 && q >= rep0, t1 = in0 && rep1 != 0 && q >= rep1;
             uint32_t a[1], b[1], c[1];
-            lds_span<1>(walkLds, ZS_WALK_FRONT + q, a);
-            lds_span<1>(walkLds, ZS_WALK_FRONT + (t0 ? q - rep0 : q), b);
-            lds_span<1>(walkLds, ZS_WALK_FRONT + (t1 ? q - rep1 : q), c);
-            const uint64_t m0 = __ballot(t0 && a[0] == b[0]), m1 = __ballot(t1 && a[0] == c[0]);
-            // the walker's byte of a ballot: its 32-bit half, then a bit-field extract (no 64-bit shifts)
-            const uint32_t bsh = 8u * (grp & 3u);
-            rm0 = __builtin_amdgcn_ubfe((grp & 4u) ? (uint32_t)(m0 >> 32) : (uint32_t)m0, bsh, 8u);
-            rm1 = __builtin_amdgcn_ubfe((grp & 4u) ? (uint32_t)(m1 >> 32) : (uint32_t)m1, bsh, 8u);
+            lds_span<1>(ZS_WALK_FRONT + q, a);
+            lds_span<1>(ZS_WALK_FRONT + (t0 ? q - rep0 : q), b);
+            lds_span<1>(ZS_WALK_FRONT + (t1 ? q - rep1 : q), c);
+            // the walker's two bytes of flags: each lane's bit (1 << sub, 256 << sub) or-ed over its 8 lanes by three data-parallel moves
+            // (xor 1, xor 2 inside a quad, the mirrored lane of the other quad) -- a ballot cost two more extracts per flag
+            uint32_t v = ((t0 && a[0] == b[0]) ? bit0 : 0u) | ((t1 && a[0] == c[0]) ? bit1 : 0u);
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);     // row_half_mirror: lane i <- lane 7 - i
+            rm0 = v & 0xFFu; rm1 = v >> 8;
         }
         // ---- window: candidate bits of [ip, ip + 64) from LDS (the same for the walker's 8 lanes) or'ed with the recent-offset
         //      bits; lane sub takes the sub-th candidate position.  32-bit words: two funnel shifts give the window ----
@@ -355,10 +362,8 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
             const uint32_t *lw = reinterpret_cast<const uint32_t *>(lm) + (ip >> 5);
             const uint32_t w0 = lw[0], w1 = lw[1], w2 = lw[2], sh = ip & 31u, wlen = wend - ip;
             mlo = __builtin_amdgcn_alignbit(w1, w0, sh); mhi = __builtin_amdgcn_alignbit(w2, w1, sh);
-            if (wlen < 64u) {
-                mlo = (wlen >= 32u) ? mlo : __builtin_amdgcn_ubfe(mlo, 0u, wlen);           // width 0 gives 0
-                mhi = (wlen > 32u) ? __builtin_amdgcn_ubfe(mhi, 0u, wlen - 32u) : 0u;
-            }
+            const uint64_t keep = ~0ull >> (64u - wlen);                                    // 1 <= wlen <= 64 while run
+            mlo &= (uint32_t)keep; mhi &= (uint32_t)(keep >> 32);
             mlo |= rm0 | rm1;
         }
         const uint32_t clo = (uint32_t)__popc(mlo);
@@ -387,8 +392,8 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
         int key = 0;
         if (active) {
             uint32_t a[6], b[6];                                                 // bytes [q - 8, q + 16) of both sides
-            lds_span<6>(walkLds, ZS_WALK_FRONT + q - 8, a);
-            lds_span<6>(walkLds, ZS_WALK_FRONT + q - off - 8, b);
+            lds_span<6>(ZS_WALK_FRONT + q - 8, a);
+            lds_span<6>(ZS_WALK_FRONT + q - off - 8, b);
             const uint64_t xb = zs_u64(a[0] ^ b[0], a[1] ^ b[1]), x0 = zs_u64(a[2] ^ b[2], a[3] ^ b[3]), x1 = zs_u64(a[4] ^ b[4], a[5] ^ b[5]);
             const uint32_t cap = min(limit - q, ZS_LCAP);
             const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
@@ -425,8 +430,8 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
                 const uint32_t fo = 16 * sub;
                 if (fo < cap) {
                     uint32_t a[4], b[4];
-                    lds_span<4>(walkLds, ZS_WALK_FRONT + pos + fo, a);
-                    lds_span<4>(walkLds, ZS_WALK_FRONT + pos - boff + fo, b);
+                    lds_span<4>(ZS_WALK_FRONT + pos + fo, a);
+                    lds_span<4>(ZS_WALK_FRONT + pos - boff + fo, b);
                     const uint64_t x0 = zs_u64(a[0] ^ b[0], a[1] ^ b[1]), x1 = zs_u64(a[2] ^ b[2], a[3] ^ b[3]);
                     const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
                     const uint32_t n1 = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u;
