@@ -9,7 +9,7 @@
 #include <type_traits>
 
 // ---------------------------------------------------------------------------------------------
-// k_lz_candidates<TLOG, NT> : one workgroup of 2 NT wavefronts per LZ unit: an OWNER and a HASHER wavefront per table.
+// k_lz_candidates<TLOG, NT> : one workgroup of 3 NT wavefronts per LZ unit: an OWNER, a HASHER and a MERGER wavefront per table.
 //   table 0 "short": hash of the 5 bytes at p, table 1 "long" (NT == 2: level >= 3): hash of the 8 bytes at p;
 //   2^TLOG 32-bit slots each (TLOG 13: units <= 64 KiB, 64 KiB of LDS for both; TLOG 14: units <= 128 KiB, 128 KiB).
 //   slot = tag (the 15 hash bits below the index bits) << 17 | position; 0xFFFFFFFF = empty.
@@ -22,11 +22,12 @@
 //
 // Only the exchanges have to be made in order by one wavefront; everything around them is data parallel, and a wavefront that did
 // all of it was alone on its SIMD waiting out every latency (round 2, first shape: 1875 cycles per group of 512 positions, a third of
-// them issuing).  So the work of a table is cut in two roles that run side by side, a group (G = 8 steps of 64 positions) apart:
+// them issuing).  So the work of a table is cut in three roles that run side by side, a group (G = 8 steps of 64 positions) apart:
 //   hasher, interval i: hashes group i -- lane l takes the 8 positions 8 l .. 8 l + 7 of the group from two coalesced 8-byte loads
-//           (prefetched 4 .. 8 groups ahead) -- and leaves an operand word per position (tag << 17 | slot index) in an LDS ring;
-//           then merges group i - 2: long distance, else short; dist[] (low 16 bits), distHi (bit 16, big units), distMask.
-//   owner,  interval i: group i - 1: operand -> entry, exchange, distance (same tag and an earlier position) written over the operand.
+//           (prefetched 2 .. 4 groups ahead) -- and leaves an operand word per position (tag << 17 | slot index) in an LDS ring;
+//   owner,  interval i: group i - 1: operand -> entry, exchange, distance (same tag and an earlier position) written over the operand;
+//   merger, interval i: group i - 2, half of its steps (the other table's merger takes the other half): long distance, else short
+//           -> dist[] (low 16 bits), distHi (bit 16, big units), distMask.  (ZS_CAND_MERGERS 0: the hashers merge.)
 // One barrier per interval.  The operand ring holds 3 groups per table; a step's 64 words are ZS_CAND_ROW = 65 words apart, which
 // spreads both the hashers' writes (8 consecutive positions a lane) and the owners' reads (64 consecutive) over all banks and keeps
 // every address of the form base + constant.
@@ -36,7 +37,7 @@
 #define ZS_CAND_G 8                // steps of 64 positions per group
 #endif
 #ifndef ZS_CAND_DEPTH
-#define ZS_CAND_DEPTH 2            // a register set holds the source loads of this many groups (two sets: 4 .. 8 groups in flight)
+#define ZS_CAND_DEPTH 2            // a register set holds the source loads of this many groups (two sets: 2 .. 4 groups in flight; 4: 0.64 vs 0.52 ms, the unrolled body grows)
 #endif
 #ifndef ZS_CAND_MERGERS
 #define ZS_CAND_MERGERS 1            // 1: a third wavefront per table merges and stores (0: the hashers do)
