@@ -1,5 +1,8 @@
-// Entropy stage of the block encoder: k_encode_block turns the sequences left by k_lz_walk into one
-// Zstandard compressed block (literals section + sequences section).  One wavefront per block.
+// Entropy stage of the block encoder: the sequences left by k_lz_walk become one Zstandard compressed block per 64 KiB block.
+//   k_encode_sequences  (4 blocks = 4 wavefronts per workgroup)  -> sequences section: recent-offset codes, histograms, FSE tables, bitstream
+//   k_encode_literals   (1 block, 4 wavefronts per workgroup)    -> literals section: gather, Huffman lengths / codes / description / streams;
+//                                                                    writes the frame of a one-block chunk as its workgroup finishes
+//   k_assemble_frames   (1 chunk per workgroup)                  -> frames of chunks of several blocks
 // Scalar statement of the same algorithm: oracle/zso_encoder.c (compressBlock and below); the two
 // must agree bit for bit.  Every piece is the format-inverse of a function of the reference decoder:
 //   literals section        <-> DecodeLiteralsBlock            csharp/src/ZStdDecompress.cs:683-821
