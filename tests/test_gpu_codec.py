@@ -431,3 +431,28 @@ def test_decode_two_block_frames_fast_path_and_its_fallbacks(codec):
         zf = [O.zstd_compress(c, 3) for c in chunks[:4]]
         for (sz, got), c in zip(_decompress_many(codec, zf, [len(c) for c in chunks[:4]]), chunks[:4]):
             assert sz == len(c) and got == c
+
+
+def test_kernel_timing_modes(codec):
+    """zsmi_enableKernelTiming: 1 = events around every launch, 2 = only around the dominant kernel of each direction
+    (what bench.py's timed region carries), 0 = none; the data path is the same in all three"""
+    chunks = [D.zipf_log(65536, seed_lo=900 + i).tobytes() for i in range(40)] + [D.zipf_log(131072, seed_lo=990).tobytes()]
+    ref = _compress_many(codec, chunks)
+    try:
+        codec.enable_timing(2)
+        fr = _compress_many(codec, chunks)
+        t2c = codec.kernel_times()
+        back = _decompress_many(codec, fr, [len(c) for c in chunks])
+        t2d = codec.kernel_times()
+        codec.enable_timing(True)
+        fr1 = _compress_many(codec, chunks)
+        t1c = codec.kernel_times()
+    finally:
+        codec.enable_timing(False)
+    assert fr == ref and fr1 == ref
+    assert [b for _, b in back] == chunks
+    assert t2c and all(k.startswith("k_lz_walk") for k in t2c), t2c
+    assert set(t2d) == {"k_dec_execute"}, t2d
+    assert {"k_lz_candidates", "k_lz_walk", "k_encode_sequences", "k_encode_literals", "k_assemble_frames"} <= set(t1c), t1c
+    assert all(s > 0 and n > 0 for s, n in list(t2c.values()) + list(t1c.values()))
+    assert codec.kernel_times() == {}
