@@ -244,8 +244,8 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
 
 // K dwords of the LDS copy starting at any byte offset, fetched as K + 1 aligned dwords and shifted into place
 // (an unaligned ds_read_b64 / b128 costs the LDS several passes: SQ_LDS_UNALIGNED_STALL was 80 % of its busy time)
-// (byteOff is an LDS address: the kernel's dynamic LDS starts at address 0 - there is no static LDS in it, checked at its start - so
-// the compiler has no symbol to add to every address)
+// (byteOff is an LDS address: the kernel's dynamic LDS starts at address 0 - there is no static LDS in it, which zsmi_createCtx checks
+// through hipFuncGetAttributes - so the compiler has no symbol to add to every address)
 typedef const __attribute__((address_space(3))) uint32_t *ZsLdsU32;
 template <int K>
 __device__ __forceinline__ void lds_span(uint32_t byteOff, uint32_t (&out)[K])
@@ -270,7 +270,6 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
     constexpr bool BIG = CAP > ZS_BLOCK_MAX;
     extern __shared__ __attribute__((aligned(16))) uint8_t walkLds[];
     uint8_t *ls = walkLds + ZS_WALK_FRONT;                                       // ls[p] = source byte p
-    if ((uint32_t)(uintptr_t)(const __attribute__((address_space(3))) uint8_t *)walkLds != 0u) __builtin_trap();   // lds_span addresses LDS from 0
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
     const ZsUnitDesc ud = units[blockIdx.x];
     const uint32_t slot = ud.firstBlock - block0;                                // scratch slot of the unit's first block

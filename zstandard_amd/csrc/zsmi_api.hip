@@ -178,6 +178,10 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
         ok &= hipFuncSetAttribute((const void *)k_lz_candidates<ZS_TABLE_LOG_BIG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZS_CAND_LDS(ZS_TABLE_LOG_BIG, 2)) == hipSuccess;
         ok &= hipFuncSetAttribute((const void *)k_lz_walk<64>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_BLOCK_MAX)) == hipSuccess;
         ok &= hipFuncSetAttribute((const void *)k_lz_walk<128>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_UNIT_MAX)) == hipSuccess;
+        // k_lz_walk addresses its (dynamic) LDS from 0: that holds as long as the kernel has no static LDS in front of it
+        hipFuncAttributes fa;
+        ok &= hipFuncGetAttributes(&fa, (const void *)k_lz_walk<64>) == hipSuccess && fa.sharedSizeBytes == 0;
+        ok &= hipFuncGetAttributes(&fa, (const void *)k_lz_walk<128>) == hipSuccess && fa.sharedSizeBytes == 0;
         if (!ok) { (void)hipGetLastError(); if (c->ownStream) (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
     }
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
