@@ -60,7 +60,7 @@ def run(name, host, total, cs, level):
         ours += len(f); zs += len(O.zstd_compress(chunk, level))
     print(json.dumps({"config": name, "chunks": n, "chunk_bytes": cs, "level": level, "bytes": total, "distinct_input_mib": len(host) >> 20,
                       "compress_gib_s": round(total / tc / 2**30, 2), "ratio": round(total / csum, 4), "size_vs_libzstd_same_level_sample": round(ours / zs, 4),
-                      "decode_gib_s": round(total / td / 2**30, 2), "sub_batches": (n * ((cs + 65535) // 65536) + 8191) // 8192,
+                      "decode_gib_s": round(total / td / 2**30, 2), "sub_batches": (n * ((cs + 65535) // 65536) + 16383) // 16384,
                       "verified": "torch.equal over the whole output; %d frames decoded by oracle D on the host" % len(idx)}), flush=True)
     del d_src, d_frames, d_out
     torch.cuda.empty_cache()

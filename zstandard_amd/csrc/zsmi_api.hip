@@ -115,7 +115,7 @@ struct zsmi_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     bool ownStream = false;
-    uint32_t maxBlocksInFlight = 8192;
+    uint32_t maxBlocksInFlight = 16384;   // ZSMI_BLOCKS_IN_FLIGHT: 64 KiB blocks per sub-batch (scratch ~0.6 MiB a block, reserved for what a call needs); 2 GiB of 128 KiB chunks: 8192: 86.5, 16384: 88.2, 32768: 89.4 GiB/s
     // compress workspace: plan (shared) + one scratch set per internal stream ("lane")
     DevBuf dBlocks, dChunks, dUnits;     // dUnits: small units (<= 64 KiB) first, then big ones, each in chunk order
     struct Scratch { DevBuf dDist, dDistHi, dDistMask, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
