@@ -131,7 +131,7 @@ struct SeqLds {                      // sequences kernel.  Kept under 10 KiB: 16
     FseCT ct[3];                     // LL, OF, ML
     int16_t norm[64];
     union {
-        struct { uint8_t tableSymbol[512]; uint32_t cumul[66]; uint32_t symCount[64]; } build;      // while a table is built
+        struct { uint8_t tableSymbol[512]; uint32_t cumul[66]; uint32_t symCount[64]; uint32_t symMask[128]; } build;      // while a table is built
         struct { uint2    op[3][66];         // per tile and table: {deltaNbBits, deltaFindState} of each sequence's code (+ padding)
                  uint32_t tileState[3][64];  // per tile: state bits out (value | nbBits << 16)
                } tile;                                                                                 // while the bitstream is written
@@ -936,25 +936,32 @@ __device__ static void buildCTableWave(SeqLds &L, FseCT &ct, const int16_t *norm
         L.u.build.tableSymbol[(j * step) & tableMask] = (uint8_t)lo;
     }
     wave_sync();
-    // stateTable[cumul[sym] + (rank of cell u among the cells of sym)] = tableSize + u, cells taken in ascending u
+    // stateTable[cumul[sym] + (rank of cell u among the cells of sym)] = tableSize + u, cells taken in ascending u.
+    // 64 cells at a time: every lane ors its bit into its symbol's 64-bit lane mask (LDS); the mask read back gives the lane its rank
+    // among the chunk's cells of that symbol (bits below it) and the symbol's count in the chunk, which the symbol's first lane adds to
+    // the running count.  (A loop over the chunk's distinct symbols, a ballot each, was ~25 rounds of three LDS round trips per chunk:
+    // most of the kernel's table stage.)
+    uint32_t *symMask = L.u.build.symMask;
     for (uint32_t base = 0; base < tableSize; base += 64) {
         const uint32_t u = base + lane;
         const bool in = u < tableSize;
-        const uint32_t sym = in ? L.u.build.tableSymbol[u] : 0xFFFFu;
-        uint64_t todo = __ballot(in);
-        while (todo) {
-            const int leader = __builtin_ctzll(todo);
-            const uint32_t ls = wave_get(sym, leader);
-            const uint64_t same = __ballot(in && sym == ls);
-            if (in && sym == ls) {
-                const uint32_t rank = (uint32_t)__popcll(same & ((1ull << lane) - 1));
-                ct.stateTable[L.u.build.symCount[ls] + rank] = (uint16_t)(tableSize + u);
-            }
-            wave_sync();
-            if (lane == (uint32_t)leader) L.u.build.symCount[ls] += (uint32_t)__popcll(same);
-            wave_sync();
-            todo &= ~same;
+        const uint32_t sym = in ? L.u.build.tableSymbol[u] : 0u;
+        symMask[2 * lane] = 0; symMask[2 * lane + 1] = 0;
+        wave_sync();
+        if (in) atomicOr(&symMask[2 * sym + (lane >> 5)], 1u << (lane & 31u));
+        wave_sync();
+        uint32_t start = 0, rank = 1, cnt = 0;
+        if (in) {
+            const uint32_t lo = symMask[2 * sym], hi = symMask[2 * sym + 1];
+            const uint32_t belowLo = (lane < 32u) ? ((1u << lane) - 1u) : 0xFFFFFFFFu, belowHi = (lane < 32u) ? 0u : ((1u << (lane - 32u)) - 1u);
+            rank = (uint32_t)__popc(lo & belowLo) + (uint32_t)__popc(hi & belowHi);
+            cnt = (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
+            start = L.u.build.symCount[sym];
+            ct.stateTable[start + rank] = (uint16_t)(tableSize + u);
         }
+        wave_sync();
+        if (in && rank == 0) L.u.build.symCount[sym] = start + cnt;
+        wave_sync();
     }
     wave_sync();
 }
