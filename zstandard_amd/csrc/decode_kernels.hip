@@ -80,6 +80,7 @@ struct DLds {
         struct { uint8_t weights[256]; uint16_t symStart[256]; uint32_t rank[16]; int16_t norm[64]; uint16_t symbolNext[64];
                  struct { uint16_t newState; uint8_t symbol; uint8_t nbBits; } wfse[64];   // weight FSE table (tableLog <= 6)
                  uint32_t hdrWin[66];                                                        // the header being parsed: 256 bytes + zero pad
+                 uint32_t symMask[128];                                                      // table build: a 64-bit lane mask per symbol
                } tb;                                                                        // a table is being parsed / built
         uint32_t litWin[4][(ZS_LITWIN + 8) / 4 + 2];                                        // the Huffman streams run
         struct { uint32_t tileLL[64], tileML[64], tileOff[64]; uint32_t win[(ZS_SEQWIN + 8) / 4 + 2]; } sq;   // sequences run
@@ -246,26 +247,32 @@ __device__ __forceinline__ void buildSeqTableWave(DLds &L, SeqSym *cells, uint32
         validBefore += (uint32_t)__popcll(vm);
     }
     wave_sync();
+    // nextState numbers in ascending cell order (:1017-1027), 64 cells at a time: every lane ors its bit into its symbol's 64-bit lane
+    // mask (LDS); the mask read back gives its rank among the chunk's cells of that symbol and the symbol's count in the chunk, which
+    // the symbol's first lane adds to symbolNext.  (A loop over the chunk's distinct symbols cost three LDS round trips per symbol.)
+    uint32_t *symMask = L.u.tb.symMask;
     for (uint32_t base = 0; base < tableSize; base += 64) {
         const uint32_t u = base + lane;
         const bool in = u < tableSize;
-        const uint32_t sym = in ? cells[u].sym : 0xFFFFu;
-        uint64_t todo = __ballot(in);
-        while (todo) {
-            const int leader = __builtin_ctzll(todo);
-            const uint32_t ls = wave_get(sym, leader);
-            const uint64_t same = __ballot(in && sym == ls);
-            if (in && sym == ls) {
-                const uint32_t nextState = (uint32_t)symbolNext[ls] + (uint32_t)__popcll(same & below);     // :1021-1023
-                const uint32_t nb = tableLog - zs_highbit(nextState);
-                cells[u].nbBits = (uint8_t)nb;
-                cells[u].nextState = (uint16_t)((nextState << nb) - tableSize);
-            }
-            wave_sync();
-            if (lane == (uint32_t)leader) symbolNext[ls] = (uint16_t)(symbolNext[ls] + (uint32_t)__popcll(same));
-            wave_sync();
-            todo &= ~same;
+        const uint32_t sym = in ? cells[u].sym : 0u;
+        symMask[2 * lane] = 0; symMask[2 * lane + 1] = 0;
+        wave_sync();
+        if (in) atomicOr(&symMask[2 * sym + (lane >> 5)], 1u << (lane & 31u));
+        wave_sync();
+        uint32_t first = 0, rank = 1, cnt = 0;
+        if (in) {
+            const uint32_t lo = symMask[2 * sym], hi = symMask[2 * sym + 1];
+            rank = (uint32_t)__popc(lo & (uint32_t)below) + (uint32_t)__popc(hi & (uint32_t)(below >> 32));
+            cnt = (uint32_t)__popc(lo) + (uint32_t)__popc(hi);
+            first = symbolNext[sym];
+            const uint32_t nextState = first + rank;                                                       // :1021-1023
+            const uint32_t nb = tableLog - zs_highbit(nextState);
+            cells[u].nbBits = (uint8_t)nb;
+            cells[u].nextState = (uint16_t)((nextState << nb) - tableSize);
         }
+        wave_sync();
+        if (in && rank == 0) symbolNext[sym] = (uint16_t)(first + cnt);
+        wave_sync();
     }
     wave_sync();
 }
