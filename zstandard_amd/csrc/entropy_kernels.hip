@@ -117,7 +117,7 @@ struct K3Lds {                       // literals kernel
     uint8_t  weights[256];
     union {
         struct { uint32_t pkg[10][256]; uint32_t S[512]; uint32_t npk[12]; } pm;      // package-merge (levels 2..11)
-        struct { FseCT ct[1]; int16_t norm[64]; uint8_t tableSymbol[512]; uint32_t cumul[66]; } fse;   // weights table
+        struct { FseCT ct[1]; int16_t norm[64]; uint8_t tableSymbol[512]; uint32_t cumul[66]; uint16_t stepOut[256]; uint32_t bits[64]; } fse;   // weights table; per step: state bits out | count << 8; the description's bitstream
         uint32_t tile[4][208];       // bit-packing tiles, one per wavefront (streams are written after the tables are done)
         uint32_t hist[8][257];       // literal gather: eight private histograms (lane & 7), rows one word apart in the banks
     } u;
@@ -385,53 +385,99 @@ __device__ __forceinline__ uint32_t cstate_init(const FseCT &ct, uint32_t symbol
     return ct.stateTable[(v >> nbBitsOut) + ct.deltaFindState[symbol]];
 }
 
-// weights -> FSE (inverse of FSE_decompress_wksp as used by ReadStats, EntropyCommon.cs:226-231).  One lane; the weight
-// histogram L.wcount[] (all 16 entries) is already filled.
-__device__ static uint32_t fseCompressWeights(K3Lds &L, uint8_t *dst, uint32_t cap, const uint8_t *weights, uint32_t nw)
+// weights -> FSE (inverse of FSE_decompress_wksp as used by ReadStats, EntropyCommon.cs:226-231), by one wavefront; the weight
+// histogram L.wcount[] (all 16 entries) is already filled.  Lane 0 makes the table (<= 13 symbols, <= 64 cells).  The encoder's two
+// interleaved states run side by side on lanes 0 and 1 (state "first" takes the symbols nw-3, nw-5, ..., "second" nw-4, nw-6, ...;
+// per step: value | bit count << 8 into LDS), then all lanes place the steps' bits by a prefix sum of the counts - the scalar form
+// (one lane, a byte-wise bit writer, ~250 dependent steps) was a third of the kernel's time between the code lengths and the streams.
+// Same bytes as fseCompressWeights in oracle/zso_encoder.c.
+__device__ __forceinline__ uint32_t fseCompressWeightsWave(K3Lds &L, uint8_t *dst, uint32_t cap, const uint8_t *weights, uint32_t nw)
 {
-    uint32_t *count = L.wcount; int16_t *norm = L.wnorm;
-    uint32_t maxSym = 0, tableLog;
-    if (nw <= 1) return 0;
-    for (uint32_t i = 0; i < 16; i++) if (count[i]) maxSym = i;
-    for (uint32_t i = 0; i <= maxSym; i++) if (count[i] == nw) return 0;
-    tableLog = 6;
-    while (tableLog > 5 && (1u << (tableLog - 1)) >= nw) tableLog--;
-    { uint32_t present = 0; for (uint32_t i = 0; i <= maxSym; i++) present += count[i] != 0; if (present > (1u << tableLog)) return 0; }
-    normalizeCounts(norm, tableLog, count, nw, maxSym);
-    const uint32_t hsize = writeNCount(dst, cap, norm, maxSym, tableLog);
-    if (!hsize) return 0;
-    FseCT &ct = L.u.fse.ct[0];
-    buildCTable(ct, L.u.fse.tableSymbol, L.u.fse.cumul, norm, maxSym, tableLog);
-    BitW b; bw_init(b, dst + hsize, cap - hsize);
-    {
-        uint32_t st1, st2; int n = (int)nw; const uint8_t *ip = weights + nw;
-        #define ENC(st, sym) { const uint32_t s_ = (sym); const uint32_t nbo = ((st) + ct.deltaNbBits[s_]) >> 16; bw_add(b, (st), nbo); (st) = ct.stateTable[((st) >> nbo) + ct.deltaFindState[s_]]; }
-        if (n & 1) { st1 = cstate_init(ct, *--ip); st2 = cstate_init(ct, *--ip); ENC(st1, *--ip); n -= 3; }
-        else { st2 = cstate_init(ct, *--ip); st1 = cstate_init(ct, *--ip); n -= 2; }
-        while (n > 0) { ENC(st2, *--ip); ENC(st1, *--ip); n -= 2; }
-        #undef ENC
-        bw_add(b, st2, tableLog);
-        bw_add(b, st1, tableLog);
+    const uint32_t lane = (uint32_t)zs_lane();
+    if (lane == 0) {
+        uint32_t hs = 0, tl = 0;
+        do {
+            uint32_t *count = L.wcount; int16_t *norm = L.wnorm;
+            uint32_t maxSym = 0, tableLog;
+            if (nw <= 1) break;
+            for (uint32_t i = 0; i < 16; i++) if (count[i]) maxSym = i;
+            bool one = false;
+            for (uint32_t i = 0; i <= maxSym; i++) if (count[i] == nw) one = true;
+            if (one) break;
+            tableLog = 6;
+            while (tableLog > 5 && (1u << (tableLog - 1)) >= nw) tableLog--;
+            { uint32_t present = 0; for (uint32_t i = 0; i <= maxSym; i++) present += count[i] != 0; if (present > (1u << tableLog)) break; }
+            normalizeCounts(norm, tableLog, count, nw, maxSym);
+            hs = writeNCount(dst, cap, norm, maxSym, tableLog);
+            if (!hs) break;
+            buildCTable(L.u.fse.ct[0], L.u.fse.tableSymbol, L.u.fse.cumul, norm, maxSym, tableLog);
+            tl = tableLog;
+        } while (0);
+        L.misc[12] = hs; L.misc[13] = tl;
     }
-    const uint32_t s = bw_close(b);
-    if (!s) return 0;
-    return hsize + s;
+    L.u.fse.bits[lane] = 0;
+    wave_sync();
+    const uint32_t hsize = L.misc[12], tableLog = L.misc[13];
+    if (!hsize) return 0;
+    const FseCT &ct = L.u.fse.ct[0];
+    const uint32_t K = nw - 2;                                            // encode steps; step k takes symbol nw - 3 - k
+    uint16_t *stepOut = L.u.fse.stepOut;
+    uint32_t fin = 0;
+    if (lane < 2) {
+        uint32_t st = cstate_init(ct, weights[nw - 1 - lane]);
+        for (uint32_t k = lane; k < K; k += 2) {
+            const uint32_t sym = weights[nw - 3 - k];
+            const uint32_t nbo = (st + ct.deltaNbBits[sym]) >> 16;
+            stepOut[k] = (uint16_t)((st & ((1u << nbo) - 1u)) | (nbo << 8));
+            st = ct.stateTable[(st >> nbo) + ct.deltaFindState[sym]];
+        }
+        fin = st;
+    }
+    wave_sync();
+    // final states go out st2 first, then st1: with an odd count the first state is st1, with an even count st2
+    const uint32_t stFirst = wave_get(fin, 0), stSecond = wave_get(fin, 1);
+    const uint32_t st2 = (nw & 1u) ? stSecond : stFirst, st1 = (nw & 1u) ? stFirst : stSecond;
+    uint32_t *bits = L.u.fse.bits;
+    uint32_t total = 0;
+    for (uint32_t k0 = 0; k0 < K + 3; k0 += 64) {
+        const uint32_t k = k0 + lane;
+        uint32_t val = 0, nb = 0;
+        if (k < K) { const uint32_t e = stepOut[k]; val = e & 0xFFu; nb = e >> 8; }
+        else if (k == K) { val = st2 & ((1u << tableLog) - 1u); nb = tableLog; }
+        else if (k == K + 1) { val = st1 & ((1u << tableLog) - 1u); nb = tableLog; }
+        else if (k == K + 2) { val = 1; nb = 1; }                         // the end mark
+        const uint32_t incl = wave_incl_scan(nb);
+        const uint32_t off = total + incl - nb;
+        if (nb) {
+            const uint32_t w = off >> 5, sh = off & 31u;
+            atomicOr(&bits[w], val << sh);
+            if (sh + nb > 32u) atomicOr(&bits[w + 1], val >> (32u - sh));
+        }
+        total += wave_last(incl);
+    }
+    wave_sync();
+    const uint32_t bytes = (total + 7u) >> 3;
+    if (bytes > cap - hsize) return 0;
+    const uint8_t *bb = reinterpret_cast<const uint8_t *>(bits);
+    for (uint32_t j = lane; j < bytes; j += 64) dst[hsize + j] = bb[j];
+    return hsize + bytes;
 }
 
-// Huffman table description (inverse of ReadStats, EntropyCommon.cs:198-269).  One lane; L.weights[0..maxSym) and the
+// Huffman table description (inverse of ReadStats, EntropyCommon.cs:198-269), by one wavefront; L.weights[0..maxSym) and the
 // histogram of those weights are already filled.
-__device__ __forceinline__ uint32_t writeHuffHeader(K3Lds &L, uint8_t *dst, uint32_t cap, uint32_t maxSym, uint32_t tableLog)
+__device__ __forceinline__ uint32_t writeHuffHeaderWave(K3Lds &L, uint8_t *dst, uint32_t cap, uint32_t maxSym, uint32_t tableLog)
 {
+    const uint32_t lane = (uint32_t)zs_lane();
     uint8_t *weights = L.weights;
     if (maxSym >= 2 && cap > 1) {
-        const uint32_t h = fseCompressWeights(L, dst + 1, cap - 1 < 127 ? cap - 1 : 127, weights, maxSym);
-        if (h > 1 && h < maxSym / 2 && h < 128) { dst[0] = (uint8_t)h; return h + 1; }
+        const uint32_t h = fseCompressWeightsWave(L, dst + 1, cap - 1 < 127 ? cap - 1 : 127, weights, maxSym);
+        if (h > 1 && h < maxSym / 2 && h < 128) { if (lane == 0) dst[0] = (uint8_t)h; return h + 1; }
     }
     if (maxSym > 128) return 0;
     if ((maxSym + 1) / 2 + 1 > cap) return 0;
-    dst[0] = (uint8_t)(128 + (maxSym - 1));
-    weights[maxSym] = 0;
-    for (uint32_t s = 0; s < maxSym; s += 2) dst[s / 2 + 1] = (uint8_t)((weights[s] << 4) + weights[s + 1]);
+    if (lane == 0) { dst[0] = (uint8_t)(128 + (maxSym - 1)); weights[maxSym] = 0; }
+    wave_sync();
+    for (uint32_t s = 2 * lane; s < maxSym; s += 128) dst[s / 2 + 1] = (uint8_t)((weights[s] << 4) + weights[s + 1]);
     return (maxSym + 1) / 2 + 1;
 }
 
@@ -825,7 +871,7 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
         const uint32_t lhSize = 3 + (nlit >= 1024) + (nlit >= 16384);
         const bool single = nlit < 256;
         huffCodesAndWeights(L, maxSym, tableLog);
-        if (tid == 0) L.misc[0] = writeHuffHeader(L, payload + lhSize, cap - lhSize, maxSym, tableLog);
+        if (wave == 0) { const uint32_t hs_ = writeHuffHeaderWave(L, payload + lhSize, cap - lhSize, maxSym, tableLog); if (lane == 0) L.misc[0] = hs_; }
         __syncthreads();
         const uint32_t hsz = L.misc[0];
         if (ZS_STOP_AT(3)) FINISH(0, 0, 0);    // stop after codes + table description
