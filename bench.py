@@ -153,8 +153,8 @@ def decode_leg(bc, args, rank, world, distributed, barrier, torch, dist):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--chunks", type=int, default=4096, help="64 KiB chunks per GPU per step")
     ap.add_argument("--chunk-size", type=int, default=65536)
     ap.add_argument("--level", type=int, default=3)
