@@ -104,6 +104,9 @@ struct FseCT {                       // encoding table of one symbol type
 #ifndef ZS_LIT_MINWG
 #define ZS_LIT_MINWG 8
 #endif
+#ifndef ZS_LIT_BITMAP
+#define ZS_LIT_BITMAP 1             // literal gather as a stream compaction of the block (0: sequence by sequence)
+#endif
 #ifndef ZS_LIT_TILES
 #define ZS_LIT_TILES 2               // tiles of 64 sequences the literal gather keeps in flight per wavefront
 #endif
@@ -120,6 +123,7 @@ struct K3Lds {                       // literals kernel
         struct { FseCT ct[1]; int16_t norm[64]; uint8_t tableSymbol[512]; uint32_t cumul[66]; uint16_t stepOut[256]; uint32_t bits[64]; } fse;   // weights table; per step: state bits out | count << 8; the description's bitstream
         uint32_t tile[4][208];       // bit-packing tiles, one per wavefront (streams are written after the tables are done)
         uint32_t hist[8][257];       // literal gather: eight private histograms (lane & 7), rows one word apart in the banks
+        struct { uint32_t T[2052]; uint32_t wpar[4], wcnt[4]; uint32_t sel[16]; } gm;   // literal gather: a bit per block byte (toggles at match ends -> inside a match -> literal), per-wavefront parities / literal counts, byte-compaction selectors
     } u;
     uint32_t misc[16];
     uint32_t rngN[ZS_WALK_RANGES], rngCarry[ZS_WALK_RANGES], litBase[ZS_WALK_RANGES];
@@ -739,8 +743,10 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     if (n < 16) FINISH(0, 0, 0);
 
     if (wave == 0) loadRangesWave(hdr, L.rngN, L.rngCarry, nullptr, L.litBase, L.rngFirst, &L.misc[1], &L.misc[2]);
+#if !ZS_LIT_BITMAP
     #pragma unroll
     for (uint32_t k = 0; k < 8; k++) L.u.hist[k][tid] = 0;
+#endif
     __syncthreads();
     const uint32_t lastLits = L.misc[1];
     const uint32_t nlit = L.misc[2];
@@ -751,6 +757,139 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     // them are issued together, then their source loads, then the stores.  A tile alone is two dependent memory round
     // trips, and the loop was bound by exactly that latency.
     uint32_t *hist = L.u.hist[lane & 7u];                                  // this lane's private histogram
+#if ZS_LIT_BITMAP
+    // The literals of a block are its bytes outside every match, in order.  So: a bit per byte, toggled at every match start and
+    // end (LDS atomics, lane = sequence); a prefix xor turns the toggles into "inside a match"; the rest is a stream compaction of
+    // the source, 16 bytes a lane and round, every lane busy with contiguous, coalesced bytes.  (Taking the literal runs sequence by
+    // sequence - a run of ~3 bytes per lane, its own load and store pieces - was ~300 instructions per 64 sequences, issue-bound.)
+    {
+        uint32_t *T = L.u.gm.T;
+        for (uint32_t i = tid; i < 2052; i += 256) T[i] = 0;
+        if (tid < 16) {                                                   // byte selectors of v_perm for a 4-bit mask: the set bytes in order, then zeros
+            uint32_t sel = 0, k = 0;
+            for (uint32_t bsel = 0; bsel < 4; bsel++) if (tid & (1u << bsel)) { sel |= bsel << (8 * k); k++; }
+            for (; k < 4; k++) sel |= 0x0Cu << (8 * k);
+            L.u.gm.sel[tid] = sel;
+        }
+        __syncthreads();
+        // 1. toggles.  Wavefront w takes ranges w, w + 4, ...; four ranges at a time, their record loads (<= 4 per lane and range) issued together
+        for (uint32_t r0 = wave; r0 < ZS_WALK_RANGES; r0 += 16) {
+            uint2 rec[4][4]; uint32_t ns[4];
+            #pragma unroll
+            for (uint32_t g = 0; g < 4; g++) {
+                const uint32_t r = r0 + 4 * g;
+                ns[g] = (r < ZS_WALK_RANGES) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)L.rngN[r]) : 0u;
+                const ZsSeqRec *rb = seqBase + (size_t)min(r, (uint32_t)ZS_WALK_RANGES - 1) * ZS_SEQ_PER_RANGE + L.rngFirst[min(r, (uint32_t)ZS_WALK_RANGES - 1)];
+                #pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    rec[g][q] = make_uint2(0, 0);
+                    if (64 * q < ns[g] && lane + 64 * q < ns[g]) rec[g][q] = *reinterpret_cast<const uint2 *>(rb + lane + 64 * q);
+                }
+            }
+            #pragma unroll
+            for (uint32_t g = 0; g < 4; g++) {
+                #pragma unroll
+                for (uint32_t q = 0; q < 4; q++) {
+                    if (64 * q < ns[g] && lane + 64 * q < ns[g]) {
+                        const uint32_t p0 = zs_rec_pos(rec[g][q].y), p1 = p0 + zs_rec_ml(rec[g][q].x);
+                        atomicXor(&T[p0 >> 5], 1u << (p0 & 31u));
+                        atomicXor(&T[p1 >> 5], 1u << (p1 & 31u));
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // 2. prefix xor over the 65536 bits (thread t: dwords 8 t .. 8 t + 7), literal bits = its complement below n, literals per wavefront region
+        uint32_t x[8];
+        {
+            uint32_t carry = 0;
+            #pragma unroll
+            for (uint32_t d = 0; d < 8; d++) {
+                uint32_t y = T[8 * tid + d];
+                y ^= y << 1; y ^= y << 2; y ^= y << 4; y ^= y << 8; y ^= y << 16;
+                y ^= 0u - carry;                                          // the dwords before end inside a match: all flipped
+                carry = y >> 31;
+                x[d] = y;
+            }
+            const uint64_t pm = __ballot(carry != 0);
+            const uint32_t pin = (uint32_t)__popcll(pm & ((1ull << lane) - 1ull)) & 1u;
+            if (lane == 0) L.u.gm.wpar[wave] = (uint32_t)__popcll(pm) & 1u;
+            __syncthreads();
+            uint32_t flip = pin;
+            for (uint32_t v = 0; v < wave; v++) flip ^= L.u.gm.wpar[v];
+            uint32_t cnt = 0;
+            #pragma unroll
+            for (uint32_t d = 0; d < 8; d++) {
+                const uint32_t bitBase = (8 * tid + d) * 32;
+                uint32_t lm = ~(x[d] ^ (0u - flip));
+                if (bitBase + 32 > n) lm = (bitBase < n) ? (lm & ((1u << (n - bitBase)) - 1u)) : 0u;
+                T[8 * tid + d] = lm;
+                cnt += (uint32_t)__popc(lm);
+            }
+            const uint32_t tot = wave_sum(cnt);
+            if (lane == 0) L.u.gm.wcnt[wave] = tot;
+        }
+        __syncthreads();
+        // 3. compaction: wavefront w takes the bytes [16384 w, 16384 (w + 1)), 1 KiB a round (two rounds' loads in flight)
+        uint32_t running = 0;
+        for (uint32_t v = 0; v < wave; v++) running += L.u.gm.wcnt[v];
+        const uint32_t regionEnd = min(n, 16384u * (wave + 1));
+        for (uint32_t p0 = 16384u * wave; p0 < regionEnd; p0 += 2048) {
+            uint64_t a[2], b[2]; uint32_t m16[2];
+            #pragma unroll
+            for (uint32_t h = 0; h < 2; h++) {
+                const uint32_t p = p0 + 1024 * h + 16 * lane;
+                a[h] = 0; b[h] = 0; m16[h] = 0;
+                if (p < n) {
+                    m16[h] = (T[p >> 5] >> (p & 31u)) & 0xFFFFu;
+                    if (p + 16 <= n) { a[h] = zs_load64(s + p); b[h] = zs_load64(s + p + 8); }
+                    else for (uint32_t j = 0; p + j < n; j++) { const uint64_t c = s[p + j]; if (j < 8) a[h] |= c << (8 * j); else b[h] |= c << (8 * (j - 8)); }
+                }
+            }
+            #pragma unroll
+            for (uint32_t h = 0; h < 2; h++) {
+                if (p0 + 1024 * h >= regionEnd) continue;
+                const uint32_t m = m16[h];
+                const uint32_t c0 = (uint32_t)__popc(m & 0xFu), c1 = (uint32_t)__popc(m & 0xF0u), c2 = (uint32_t)__popc(m & 0xF00u), c3 = (uint32_t)__popc(m & 0xF000u);
+                const uint32_t q0 = __builtin_amdgcn_perm(0u, (uint32_t)a[h], L.u.gm.sel[m & 15u]);
+                const uint32_t q1 = __builtin_amdgcn_perm(0u, (uint32_t)(a[h] >> 32), L.u.gm.sel[(m >> 4) & 15u]);
+                const uint32_t q2 = __builtin_amdgcn_perm(0u, (uint32_t)b[h], L.u.gm.sel[(m >> 8) & 15u]);
+                const uint32_t q3 = __builtin_amdgcn_perm(0u, (uint32_t)(b[h] >> 32), L.u.gm.sel[(m >> 12) & 15u]);
+                const uint64_t lo = (uint64_t)q0 | ((uint64_t)q1 << (8 * c0)), hi = (uint64_t)q2 | ((uint64_t)q3 << (8 * c2));   // <= 8 bytes each
+                const uint32_t cl = c0 + c1, cnt = cl + c2 + c3;
+                // 16 compacted bytes (w0 low, w1 high): lo, then hi from byte cl
+                const uint64_t w0 = (cl < 8) ? (lo | (hi << (8 * cl))) : lo;
+                const uint64_t w1 = (cl == 0) ? 0ull : ((cl < 8) ? (hi >> (64 - 8 * cl)) : hi);
+                const uint32_t incl = wave_incl_scan(cnt);
+                uint8_t *dp = lits + running + incl - cnt;
+                if (cnt == 16) { zs_store64(dp, w0); zs_store64(dp + 8, w1); }
+                else {
+                    uint64_t t = w0; uint32_t at = 0;
+                    if (cnt & 8) { zs_store64(dp, t); t = w1; at = 8; }
+                    if (cnt & 4) { zs_store32(dp + at, (uint32_t)t); t >>= 32; at += 4; }
+                    if (cnt & 2) { zs_store16(dp + at, (uint16_t)t); t >>= 16; at += 2; }
+                    if (cnt & 1) dp[at] = (uint8_t)t;
+                }
+                running += wave_last(incl);
+            }
+        }
+        __syncthreads();                                                  // the bit plane is done with: the histograms take its place
+    }
+    #pragma unroll
+    for (uint32_t k = 0; k < 8; k++) L.u.hist[k][tid] = 0;
+    __syncthreads();
+    // 4. histogram of the gathered literals, four bytes a thread and round
+    for (uint32_t j = 4 * tid; j < nlit; j += 1024) {
+        const uint32_t w = zs_load32(lits + j);                           // (the buffer has 64 bytes of slack)
+        const uint32_t k = min(4u, nlit - j);
+        atomicAdd(&hist[w & 0xFFu], 1u);
+        if (k > 1) atomicAdd(&hist[(w >> 8) & 0xFFu], 1u);
+        if (k > 2) atomicAdd(&hist[(w >> 16) & 0xFFu], 1u);
+        if (k > 3) atomicAdd(&hist[w >> 24], 1u);
+    }
+    (void)lastLits;
+    __syncthreads();
+#else
     {
         constexpr uint32_t GT = ZS_LIT_TILES;
         auto rangeN = [&](uint32_t r) -> uint32_t { return (uint32_t)__builtin_amdgcn_readfirstlane((int)L.rngN[r]); };
@@ -831,6 +970,7 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     }
     for (uint32_t j = tid; j < lastLits; j += 256) { const uint8_t c = s[n - lastLits + j]; lits[nlit - lastLits + j] = c; atomicAdd(&hist[c], 1u); }
     __syncthreads();
+#endif
     {
         uint32_t c = 0;
         #pragma unroll
