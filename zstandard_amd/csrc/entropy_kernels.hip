@@ -14,8 +14,10 @@
 // -DZSMI_DEBUG_HOOKS (the library the product ships ignores the stopAt argument).
 #ifdef ZSMI_DEBUG_HOOKS
 #define ZS_STOP_AT(v) (stopAt == (v))
+#define ZS_STOPPED (stopAt != 0)     // a stopped kernel writes no frame (its stage time is what is asked for)
 #else
 #define ZS_STOP_AT(v) false
+#define ZS_STOPPED false
 #endif
 
 #define MaxLL 35
@@ -715,7 +717,7 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     // one on the stream, its section and meta fields are there) - k_assemble_frames is launched only for batches with longer chunks
     #define FINISH(tp, lsz, rb) do { \
         if (tid == 0) { metas[blk].type = (tp); metas[blk].rleByte = (rb); metas[blk].litSecSize = (lsz); } \
-        if (bd.firstInChunk && bd.lastInChunk) { \
+        if (bd.firstInChunk && bd.lastInChunk && !ZS_STOPPED) { \
             __syncthreads();                         /* the literal section was written by all wavefronts */ \
             ZsBlockMeta m_ = metas[blk]; m_.type = (tp); m_.rleByte = (rb); m_.litSecSize = (lsz); \
             const ZsChunkDesc cd_ = chunks[bd.chunk]; \
