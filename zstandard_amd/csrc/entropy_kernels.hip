@@ -501,11 +501,23 @@ __device__ static uint32_t huffLengths(K3Lds &L, uint32_t maxSym, uint32_t maxBi
     // 256 threads: thread s owns symbol s, later leaf rank s / package index s
     const uint32_t tid = threadIdx.x;
     const uint32_t c = (tid <= maxSym) ? L.count[tid] : 0u;
-    const uint32_t n = (uint32_t)__syncthreads_count(c != 0);
     L.nbBits[tid] = 0;
+    // leaves in ascending (count, symbol) order.  The symbols that occur are packed first (key = count << 8 | symbol, in S), so a
+    // symbol's rank is a count over the ~90 keys of a text block, not a test of all 256 counters
+    uint32_t *keys = L.u.pm.S;
+    const uint32_t lane_ = tid & 63u, wave_ = tid >> 6;
+    const uint64_t pres = __ballot(c != 0);
+    if (lane_ == 0) L.u.pm.npk[4 + wave_] = (uint32_t)__popcll(pres);      // npk[0..11] is free until the levels start
+    __syncthreads();
+    uint32_t before = 0, n = 0;
+    #pragma unroll
+    for (uint32_t v = 0; v < 4; v++) { const uint32_t k = L.u.pm.npk[4 + v]; if (v < wave_) before += k; n += k; }
+    const uint32_t key = (c << 8) | tid;
+    if (c) keys[before + (uint32_t)__popcll(pres & ((1ull << lane_) - 1ull))] = key;
+    __syncthreads();
     if (c) {
         uint32_t rank = 0;
-        for (uint32_t t = 0; t <= maxSym; t++) { const uint32_t ct = L.count[t]; rank += (ct && (ct < c || (ct == c && t < tid))) ? 1u : 0u; }
+        for (uint32_t t = 0; t < n; t++) rank += (keys[t] < key) ? 1u : 0u;
         L.leafW[rank] = c; L.leafSym[rank] = (uint16_t)tid;
     }
     __syncthreads();
