@@ -593,14 +593,21 @@ __device__ __forceinline__ uint32_t huffEncodeStream(K3Lds &L, uint32_t *tile, u
     const uint32_t lane = (uint32_t)zs_lane();
     BitSink sink; sink_init(sink, tmp, tile);
     uint32_t remaining = len;
+    // lane l takes symbols k = 8l .. 8l+7 of the tile, i.e. the 8 literals ending at position from + remaining - 1 - 8l, last first
+    const uint32_t k0 = lane * 8;
+    auto fetch = [&](uint32_t rem) -> uint64_t {
+        const uint32_t T = min(512u, rem);
+        uint64_t e = 0;
+        if (k0 + 8 <= T) e = zs_load64(lits + from + rem - 8 - k0);
+        else for (uint32_t j = 0; j < 8; j++) if (k0 + j < T) e |= (uint64_t)lits[from + rem - 1 - k0 - j] << (8 * (7 - j));
+        return e;
+    };
+    uint64_t next = remaining ? fetch(remaining) : 0ull;                   // the next tile's bytes travel while this one is packed
     while (remaining) {
         const uint32_t T = min(512u, remaining);
         uint64_t lo = 0; uint32_t hi = 0, nb = 0;
-        // lane l takes symbols k = 8l .. 8l+7 of the tile, i.e. the 8 literals ending at position from + remaining - 1 - 8l, last first
-        const uint32_t k0 = lane * 8;
-        uint64_t eight = 0;
-        if (k0 + 8 <= T) eight = zs_load64(lits + from + remaining - 8 - k0);
-        else for (uint32_t j = 0; j < 8; j++) if (k0 + j < T) eight |= (uint64_t)lits[from + remaining - 1 - k0 - j] << (8 * (7 - j));
+        const uint64_t eight = next;
+        if (remaining > T) next = fetch(remaining - T);
         #pragma unroll
         for (uint32_t j = 0; j < 8; j++) {
             if (k0 + j < T) {
