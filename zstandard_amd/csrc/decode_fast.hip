@@ -447,23 +447,88 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
     if (mine && !ok) descs[item].fast = 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The matches of one tile of <= 64 sequences, lane t = sequence t: destination mdst, length ml, offset off (ml == 0: no sequence).
+// The literals of the whole block are in place already (k_dec_execute expands them before any match).  Same order rules as
+// execTileT in decode_kernels.hip: matches whose source ends before the tile's first output byte side by side, then the matches
+// that read this tile's own output in groups none of whose members reads what the group writes.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, uint32_t off, uint8_t *dstBase, uint32_t tileStart)
+{
+    const uint32_t lane = (uint32_t)zs_lane();
+    const uint32_t msrc = mdst - off;
+    const bool indep = ml && (msrc + ml <= tileStart);
+    auto copyShort = [&]() {                                            // <= 32 bytes, source and destination do not overlap
+        if (ml >= 8) {
+            uint64_t v[4]; const uint32_t lastAt = ml - 8;
+            #pragma unroll
+            for (uint32_t k = 0; k < 4; k++) v[k] = zs_load64(dstBase + msrc + min(8 * k, lastAt));
+            #pragma unroll
+            for (uint32_t k = 0; k < 4; k++) if (8 * k < ml) __builtin_memcpy(dstBase + mdst + min(8 * k, lastAt), &v[k], 8);
+        } else if (ml >= 4) {
+            const uint32_t x0 = zs_load32(dstBase + msrc), x1 = zs_load32(dstBase + msrc + ml - 4);
+            __builtin_memcpy(dstBase + mdst, &x0, 4); __builtin_memcpy(dstBase + mdst + ml - 4, &x1, 4);
+        } else for (uint32_t j = 0; j < ml; j++) dstBase[mdst + j] = dstBase[msrc + j];
+    };
+    if (indep && ml <= 32) copyShort();
+    for (uint64_t lm = __ballot(indep && ml > 32); lm; lm &= lm - 1) {
+        const int t = __builtin_ctzll(lm);
+        const uint32_t m2 = wave_get(ml, t), s2 = wave_get(msrc, t), d2 = wave_get(mdst, t);
+        for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j];
+    }
+    wave_mem_sync();
+    for (uint64_t rem = __ballot(ml && !indep); rem; ) {
+        const int g0 = __builtin_ctzll(rem);
+        const uint32_t lo = wave_get(mdst, g0);
+        const uint64_t viol = __ballot(((rem >> lane) & 1ull) && (int)lane > g0 && (msrc + ml > lo));
+        const uint64_t grp = viol ? (rem & ((1ull << __builtin_ctzll(viol)) - 1ull)) : rem;
+        const bool in = (grp >> lane) & 1ull;
+        const bool self = in && (off < ml);                              // only lane g0 can be
+        if (in && !self && ml <= 32) copyShort();
+        for (uint64_t lm = __ballot(in && (self || ml > 32)); lm; lm &= lm - 1) {
+            const int t = __builtin_ctzll(lm);
+            const uint32_t m2 = wave_get(ml, t), o2 = wave_get(off, t), s2 = wave_get(msrc, t), d2 = wave_get(mdst, t);
+            if (o2 >= m2) { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j]; }
+            else { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + (j % o2)]; }      // period = offset
+        }
+        wave_mem_sync();
+        rem &= ~grp;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // k_dec_execute : one wavefront per item: the decoded sequences, 64 at a time, through execTile; last literals; size check.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifndef ZS_EXEC_PREEXPAND
+#define ZS_EXEC_PREEXPAND 1             // 1: a block's literals are spread into the output before its matches (0: literals tile by tile, execTile)
+#endif
+#define ZS_EXEC_WINDOW 32768u           // output bytes whose literal bits a wavefront holds in LDS at a time
 #ifndef ZS_EXEC_MINWG
 #define ZS_EXEC_MINWG 6                 // 6 workgroups = 6 wavefronts per SIMD at <= 80 VGPRs (24 bytes of spill); measured 1: 5.86 ms, 6: 5.42, 7: 5.43, 8: 6.46
 #endif
 template <int F>
 __global__ void __launch_bounds__(64 * F, ZS_EXEC_MINWG)
 k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-              const ZsFastSeq *__restrict__ seqAll, uint8_t *__restrict__ litScratchAll, uint8_t *dstAll, uint32_t *__restrict__ dstSizes, uint32_t cap)
+              ZsFastSeq *seqAll, uint8_t *__restrict__ litScratchAll, uint8_t *dstAll, uint32_t *__restrict__ dstSizes, uint32_t cap)
 {
     __shared__ uint32_t tiles[F][3][64];
     __shared__ uint32_t codeTabs[36 + 53];                                      // base | extra bits << 24 of the LL / ML codes
+#if ZS_EXEC_PREEXPAND
+    __shared__ uint32_t litBits[F][ZS_EXEC_WINDOW / 32 + 4];                   // a bit per output byte of the window: toggles at match ends -> inside a match -> literal
+    __shared__ uint32_t expSel[16];                                             // v_perm selectors that spread the next literals over a 4-bit mask's set bytes
+#endif
     const uint32_t w = threadIdx.x >> 6, lane = (uint32_t)zs_lane();
     const uint32_t item = blockIdx.x * F + w;
     if (threadIdx.x < 36) codeTabs[threadIdx.x] = d_LL_base[threadIdx.x] | ((uint32_t)d_LL_bits[threadIdx.x] << 24);
     else if (threadIdx.x >= 64 && threadIdx.x < 64 + 53) codeTabs[36 + threadIdx.x - 64] = d_ML_base[threadIdx.x - 64] | ((uint32_t)d_ML_bits[threadIdx.x - 64] << 24);
+#if ZS_EXEC_PREEXPAND
+    if (threadIdx.x >= 128 && threadIdx.x < 144) {
+        const uint32_t m = threadIdx.x - 128; uint32_t sel = 0, k = 0;
+        for (uint32_t j = 0; j < 4; j++) { if (m & (1u << j)) { sel |= k << (8 * j); k++; } else sel |= 0x0Cu << (8 * j); }
+        expSel[m] = sel;
+    }
+#endif
     __syncthreads();                                                            // the only workgroup barrier: before any wavefront leaves
     if (item >= nItems) return;
     // the item index is the same in every lane: said so, its descriptor and item record are scalar loads (27 + 6 registers that
@@ -490,7 +555,7 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     const uint8_t *litPtr = litBuf;
     if (d.litType == 0) litPtr = srcAll + it.srcOff + d.litSrc;
     else if (d.litType == 1) { for (uint32_t j = lane; j < d.litSize; j += 64) litBuf[j] = (uint8_t)d.litSrc; wave_mem_sync(); }
-    const ZsFastSeq *seqs = seqAll + slot * ZS_FAST_MAXSEQ;
+    ZsFastSeq *seqs = seqAll + slot * ZS_FAST_MAXSEQ;                           // (pass A writes each sequence back in place)
     const uint8_t *bits = srcAll + it.srcOff + d.seqOff;                        // the sequence bitstream, d.seqSize bytes
     // the 64 stream bits below bit position p, top aligned (bit p - 1 at bit 63); bits below the stream start read as 0
     auto bitsBelow = [&](int32_t p) -> uint64_t {
@@ -502,6 +567,7 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
         return wv << (7u - (uint32_t)((p - 1) & 7));
     };
     uint32_t litPos = 0;
+    const uint32_t blockStart32 = (uint32_t)op; (void)blockStart32;       // where this block's output starts (a 32-bit position: the item's capacity is a 32-bit count)
     for (uint32_t t0 = 0; t0 < d.nbSeq; t0 += 64) {
         const uint32_t T = min(64u, d.nbSeq - t0);
         // lane t: the extra bits of sequence t0 + t (:1487-1545) -> lengths, offset value and its recent-offset class
@@ -584,6 +650,26 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
             }
         }
         wave_sync();
+#if ZS_EXEC_PREEXPAND
+        {   // pass A: positions and the reference's checks (ExecSequence :1265-1352; any failure hands the item to the general decoder);
+            // the sequence goes back to its 8-byte slot as (ll + ml) | ml << 18 | offset << 35 for the two passes below
+            const uint32_t ll = (lane < T) ? tiles[w][0][lane] : 0u, ml = (lane < T) ? tiles[w][1][lane] : 0u, off = (lane < T) ? tiles[w][2][lane] : 0u;
+            const uint32_t incl = wave_incl_scan(ll + ml), inclL = wave_incl_scan(ll);
+            const uint64_t outStart64 = op + (incl - ll - ml);
+            const uint32_t litStart = litPos + (inclL - ll);
+            bool e = false;
+            if (lane < T) {
+                if ((uint64_t)ll + ml > oend - outStart64 || outStart64 > oend) e = true;
+                else if (ll > d.litSize - litStart || litStart > d.litSize) e = true;
+                else if (off > outStart64 + ll || off >= (1u << 29) || ml >= (1u << 17) || ll + ml >= (1u << 18)) e = true;
+                else seqs[t0 + lane] = (uint64_t)(ll + ml) | ((uint64_t)ml << 18) | ((uint64_t)off << 35);
+            }
+            if (__ballot(e)) { bad = true; break; }
+            op += wave_last(incl); litPos += wave_last(inclL);
+        }
+        wave_sync();
+    }
+#else
 #ifdef ZS_EXEC_PROFILE
         { const uint64_t now = __builtin_amdgcn_s_memtime(); pf[3] += now - pfMark; }          // records, bits, recent offsets
         if (execTile(tiles[w][0], tiles[w][1], tiles[w][2], T, dstBase, 0, oend, litPtr, d.litSize, op, litPos, pf)) { bad = true; break; }
@@ -596,12 +682,98 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
 #ifdef ZS_EXEC_PROFILE
     if (lane == 0 && blk == 0) { uint64_t *o = reinterpret_cast<uint64_t *>(litBuf + (1u << 17)); pf[4] = __builtin_amdgcn_s_memtime() - pfStart; pf[5] = d.nbSeq; for (int k = 0; k < 8; k++) o[k] = pf[k]; }
 #endif
+#endif
+#if ZS_EXEC_PREEXPAND
+    if (!bad) {
+        const uint32_t lastLL = d.litSize - litPos;
+        if (lastLL > oend - op) bad = true;
+        else {
+            const uint32_t blockStart = blockStart32, blockEnd = (uint32_t)op + lastLL;
+            uint32_t *bm = litBits[w];
+            wave_mem_sync();                                              // pass A's records are read back below
+            // ---- the literals: window by window a bit per output byte, toggled at the ends of every match (clipped to the window), prefix xor =
+            //      inside a match; then 16 output bytes a lane and round: the next popcount(literal bits) literals, spread by v_perm ----
+            for (uint32_t w0 = blockStart; w0 < blockEnd; w0 += ZS_EXEC_WINDOW) {
+                const uint32_t w1 = min(w0 + ZS_EXEC_WINDOW, blockEnd);
+                for (uint32_t i = lane; i < ZS_EXEC_WINDOW / 32 + 4; i += 64) bm[i] = 0;
+                wave_sync();
+                uint32_t pos = blockStart, matchBefore = 0;
+                for (uint32_t t0 = 0; t0 < d.nbSeq; t0 += 64) {
+                    const uint64_t r = (t0 + lane < d.nbSeq) ? seqs[t0 + lane] : 0ull;
+                    const uint32_t tot = (uint32_t)r & 0x3FFFFu, ml = (uint32_t)(r >> 18) & 0x1FFFFu;
+                    const uint32_t incl = wave_incl_scan(tot);
+                    const uint32_t mend = pos + incl, mst = mend - ml;
+                    const uint32_t a = max(mst, w0), b = min(mend, w1);
+                    if (ml && a < b) { atomicXor(&bm[(a - w0) >> 5], 1u << ((a - w0) & 31u)); atomicXor(&bm[(b - w0) >> 5], 1u << ((b - w0) & 31u)); }
+                    matchBefore += wave_sum(min(mend, w0) - min(mst, w0));
+                    pos += wave_last(incl);
+                }
+                wave_sync();
+                {   // prefix xor over the window (lane l: dwords 16 l .. 16 l + 15), literal bit = not inside a match
+                    uint32_t x[16]; uint32_t carry = 0;
+                    #pragma unroll
+                    for (uint32_t k = 0; k < 16; k++) {
+                        uint32_t y = bm[16 * lane + k];
+                        y ^= y << 1; y ^= y << 2; y ^= y << 4; y ^= y << 8; y ^= y << 16;
+                        y ^= 0u - carry; carry = y >> 31; x[k] = y;
+                    }
+                    const uint64_t pm = __ballot(carry != 0);
+                    const uint32_t flip = (uint32_t)__popcll(pm & ((1ull << lane) - 1ull)) & 1u;
+                    #pragma unroll
+                    for (uint32_t k = 0; k < 16; k++) bm[16 * lane + k] = ~(x[k] ^ (0u - flip));
+                }
+                wave_sync();
+                uint32_t running = (w0 - blockStart) - matchBefore;        // literals of the block in front of the window
+                for (uint32_t r0 = w0; r0 < w1; r0 += 1024) {
+                    const uint32_t p = r0 + 16 * lane;
+                    uint32_t m16 = 0;
+                    if (p < w1) {
+                        m16 = (bm[(p - w0) >> 5] >> ((p - w0) & 31u)) & 0xFFFFu;
+                        if (w1 - p < 16) m16 &= (1u << (w1 - p)) - 1u;
+                    }
+                    const uint32_t cnt = (uint32_t)__popc(m16);
+                    const uint32_t incl = wave_incl_scan(cnt);
+                    const uint32_t so = running + incl - cnt;
+                    if (cnt) {
+                        uint64_t A = 0, B = 0;                            // the 16 literal bytes from so (what lies behind the literals is not read)
+                        if (so + 16 <= d.litSize) { A = zs_load64(litPtr + so); B = zs_load64(litPtr + so + 8); }
+                        else for (uint32_t j = 0; j < cnt; j++) { const uint64_t c = litPtr[so + j]; if (j < 8) A |= c << (8 * j); else B |= c << (8 * (j - 8)); }
+                        const uint32_t c0 = (uint32_t)__popc(m16 & 0xFu), c01 = (uint32_t)__popc(m16 & 0xFFu), c2 = (uint32_t)__popc(m16 & 0xF00u);
+                        const uint64_t S1 = (c01 == 0) ? A : ((c01 >= 8) ? B : ((A >> (8 * c01)) | (B << (64 - 8 * c01))));   // literal bytes from c01 on
+                        const uint32_t o0 = __builtin_amdgcn_perm(0u, (uint32_t)A, expSel[m16 & 15u]);
+                        const uint32_t o1 = __builtin_amdgcn_perm(0u, (uint32_t)(A >> (8 * c0)), expSel[(m16 >> 4) & 15u]);
+                        const uint32_t o2 = __builtin_amdgcn_perm(0u, (uint32_t)S1, expSel[(m16 >> 8) & 15u]);
+                        const uint32_t o3 = __builtin_amdgcn_perm(0u, (uint32_t)(S1 >> (8 * c2)), expSel[(m16 >> 12) & 15u]);
+                        uint8_t *dp = dstBase + p;
+                        if (w1 - p >= 16) { const uint64_t lo = (uint64_t)o0 | ((uint64_t)o1 << 32), hi = (uint64_t)o2 | ((uint64_t)o3 << 32); __builtin_memcpy(dp, &lo, 8); __builtin_memcpy(dp + 8, &hi, 8); }
+                        else { const uint32_t ow[4] = { o0, o1, o2, o3 }; for (uint32_t j = 0; j < w1 - p; j++) if ((m16 >> j) & 1u) dp[j] = (uint8_t)(ow[j >> 2] >> (8 * (j & 3u))); }
+                    }
+                    running += wave_last(incl);
+                }
+                wave_sync();
+            }
+            wave_mem_sync();                                              // the matches read literals
+            // ---- pass B: the matches, tile by tile ----
+            uint32_t pos = blockStart;
+            for (uint32_t t0 = 0; t0 < d.nbSeq; t0 += 64) {
+                const uint64_t r = (t0 + lane < d.nbSeq) ? seqs[t0 + lane] : 0ull;
+                const uint32_t tot = (uint32_t)r & 0x3FFFFu, ml = (uint32_t)(r >> 18) & 0x1FFFFu, off = (uint32_t)(r >> 35);
+                const uint32_t incl = wave_incl_scan(tot);
+                execTileMatchesFast(pos + incl - ml, ml, off, dstBase, pos);
+                pos += wave_last(incl);
+            }
+            op = blockEnd;
+            wave_mem_sync();                                              // the next block's matches read these bytes
+        }
+    }
+#else
     if (!bad) {
         const uint32_t lastLL = d.litSize - litPos;
         if (lastLL > oend - op) bad = true;
         else { for (uint32_t j = lane; j < lastLL; j += 64) dstBase[op + j] = litPtr[litPos + j]; op += lastLL; }
         wave_mem_sync();                                                        // the next block's matches read these bytes
     }
+#endif
     }   // blocks of the item
     if (!bad && hasContentSize && op != contentSize) bad = true;
     if (lane == 0) { if (bad) descs[item].fast = 0; else dstSizes[item] = (uint32_t)op; }

@@ -404,7 +404,7 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
                 LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, blk, cap);
                 LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, ZS_FAST_SEQGROUP>), dim3((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, blk, cap);
             }
-            LAUNCH(c, "k_dec_execute", (k_dec_execute<4>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const ZsFastSeq *)c->dSeqOut.p,
+            LAUNCH(c, "k_dec_execute", (k_dec_execute<4>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (ZsFastSeq *)c->dSeqOut.p,
                    (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap);
             LAUNCH(c, "k_dec_checksum", k_dec_checksum, dim3((cnt + 63) / 64), dim3(64), 0, dI, cnt, (const ZsFastDesc *)dD, (const uint8_t *)dDst, dDstSizes + i0);
             doneFlags = &dD->fast;
