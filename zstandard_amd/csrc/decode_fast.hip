@@ -568,6 +568,10 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     };
     uint32_t litPos = 0;
     const uint32_t blockStart32 = (uint32_t)op; (void)blockStart32;       // where this block's output starts (a 32-bit position: the item's capacity is a 32-bit count)
+#if ZS_EXEC_PREEXPAND
+    for (uint32_t i = lane; i < ZS_EXEC_WINDOW / 32 + 4; i += 64) litBits[w][i] = 0;      // pass A toggles the first window's bits as it goes
+    wave_sync();
+#endif
     for (uint32_t t0 = 0; t0 < d.nbSeq; t0 += 64) {
         const uint32_t T = min(64u, d.nbSeq - t0);
         // lane t: the extra bits of sequence t0 + t (:1487-1545) -> lengths, offset value and its recent-offset class
@@ -662,7 +666,14 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
                 if ((uint64_t)ll + ml > oend - outStart64 || outStart64 > oend) e = true;
                 else if (ll > d.litSize - litStart || litStart > d.litSize) e = true;
                 else if (off > outStart64 + ll || off >= (1u << 29) || ml >= (1u << 17) || ll + ml >= (1u << 18)) e = true;
-                else seqs[t0 + lane] = (uint64_t)(ll + ml) | ((uint64_t)ml << 18) | ((uint64_t)off << 35);
+                else {
+                    seqs[t0 + lane] = (uint64_t)(ll + ml) | ((uint64_t)ml << 18) | ((uint64_t)off << 35);
+                    const uint32_t ms = (uint32_t)outStart64 + ll - blockStart32, me = ms + ml;            // the match, relative to the block's output
+                    if (ml && ms < ZS_EXEC_WINDOW) {
+                        const uint32_t b = min(me, ZS_EXEC_WINDOW);
+                        atomicXor(&litBits[w][ms >> 5], 1u << (ms & 31u)); atomicXor(&litBits[w][b >> 5], 1u << (b & 31u));
+                    }
+                }
             }
             if (__ballot(e)) { bad = true; break; }
             op += wave_last(incl); litPos += wave_last(inclL);
@@ -695,10 +706,9 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
             //      inside a match; then 16 output bytes a lane and round: the next popcount(literal bits) literals, spread by v_perm ----
             for (uint32_t w0 = blockStart; w0 < blockEnd; w0 += ZS_EXEC_WINDOW) {
                 const uint32_t w1 = min(w0 + ZS_EXEC_WINDOW, blockEnd);
-                for (uint32_t i = lane; i < ZS_EXEC_WINDOW / 32 + 4; i += 64) bm[i] = 0;
-                wave_sync();
                 uint32_t pos = blockStart, matchBefore = 0;
-                for (uint32_t t0 = 0; t0 < d.nbSeq; t0 += 64) {
+                if (w0 != blockStart) { for (uint32_t i = lane; i < ZS_EXEC_WINDOW / 32 + 4; i += 64) bm[i] = 0; wave_sync(); }
+                for (uint32_t t0 = 0; w0 != blockStart && t0 < d.nbSeq; t0 += 64) {      // (the first window's toggles were made by pass A)
                     const uint64_t r = (t0 + lane < d.nbSeq) ? seqs[t0 + lane] : 0ull;
                     const uint32_t tot = (uint32_t)r & 0x3FFFFu, ml = (uint32_t)(r >> 18) & 0x1FFFFu;
                     const uint32_t incl = wave_incl_scan(tot);
