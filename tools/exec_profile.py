@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Development aid (GPU box, library built with -DZS_EXEC_PROFILE): where k_dec_execute's wavefronts spend their time,
 from s_memtime stamps per item (fast-path items only)."""
-import os; os.environ["ZSMI_DEBUG_LIB"] = "1"          # the library built with -DZSMI_DEBUG_HOOKS (zstandard_amd/_lib.py)
+import os; os.environ["ZSMI_DEBUG_LIB"] = "1"          # the library built with -DZSMI_DEBUG_HOOKS (zstandard_amd/_lib.py); build it with ZSMI_HIPCC_FLAGS="-DZS_EXEC_PROFILE -DZS_EXEC_PREEXPAND=0" (the stamps sit in the tile-by-tile form)
 import sys, os, ctypes
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
