@@ -27,7 +27,7 @@
 #endif                     // bytes of each sequence bitstream staged in LDS at a time
 #define ZS_FAST_GROUP    16u                      // items per wavefront of the Huffman kernel (4 lanes each)
 #ifndef ZS_FAST_SEQGROUP
-#define ZS_FAST_SEQGROUP 4u                       // items per wavefront of the sequences kernel (2.5 KiB of tables each); measured 2: 3.06 ms, 4: 2.32, 8: 3.28, 16: 2.51 per 16384 items
+#define ZS_FAST_SEQGROUP 16u                      // items per wavefront of the sequences kernel (2.5 KiB of tables each); 16384 two-block frames of 128 KiB: 2: 10.4 ms, 4: 8.5, 8: 8.2, 16: 7.0 (round 1, with the carried bit container: 4 was best)
 #endif
 #ifndef ZS_FAST_SEQGROUP_SMALL
 #define ZS_FAST_SEQGROUP_SMALL 16u                // the same for items with tables of <= 2^8 cells (1.5 KiB): measured 4: 4.36 ms, 8: 3.70, 16: 3.16 per 57344 items
