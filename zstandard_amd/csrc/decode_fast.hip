@@ -29,6 +29,7 @@
 #ifndef ZS_FAST_SEQGROUP
 #define ZS_FAST_SEQGROUP 16u                      // items per wavefront of the sequences kernel (2.5 KiB of tables each); 16384 two-block frames of 128 KiB: 2: 10.4 ms, 4: 8.5, 8: 8.2, 16: 7.0 (round 1, with the carried bit container: 4 was best)
 #endif
+#define ZS_FAST_SEQGROUP_MANY 12288u                // items in a launch from which the 2.5 KiB class takes ZS_FAST_SEQGROUP items a wavefront (below: 4)
 #ifndef ZS_FAST_SEQGROUP_SMALL
 #define ZS_FAST_SEQGROUP_SMALL 16u                // the same for items with tables of <= 2^8 cells (1.5 KiB): measured 4: 4.36 ms, 8: 3.70, 16: 3.16 per 57344 items
 #endif
