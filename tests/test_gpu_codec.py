@@ -456,3 +456,31 @@ def test_kernel_timing_modes(codec):
     assert {"k_lz_candidates", "k_lz_walk", "k_encode_sequences", "k_encode_literals", "k_assemble_frames"} <= set(t1c), t1c
     assert all(s > 0 and n > 0 for s, n in list(t2c.values()) + list(t1c.values()))
     assert codec.kernel_times() == {}
+
+
+def test_decode_literal_spread_across_windows(codec):
+    """the fast execute kernel spreads a block's literals through 32 KiB windows of a bit per output byte: one-block frames whose block is
+    up to 128 KiB (libzstd's block size: four windows), with long literal runs, long matches and matches that cross window borders;
+    every frame also under oracle D"""
+    if not O.libzstd():
+        pytest.skip("libzstd not present")
+    rng = np.random.default_rng(77)
+    log = D.zipf_log(1 << 20, seed_lo=4242).tobytes()
+    noise = rng.integers(0, 256, 1 << 17, dtype=np.uint8).tobytes()
+    chunks = []
+    for n in (131072, 131071, 98304 + 5, 65536 + 32768, 32768 + 1, 32768, 32767, 100000):
+        chunks.append(log[:n])                                                      # text: short literal runs everywhere
+        chunks.append((noise[:20000] + log[:30000] + noise[20000:33000] + log[:40000] + bytes(30000))[:n])   # long literal runs, long matches, a run of zeros
+        chunks.append((log[:1000] * 200)[:n])                                       # period 1000: matches far longer than a window
+        chunks.append((noise[:32760] + noise[:32760] + noise[100:40000] + log[:40000])[:n])                  # a match that straddles window borders
+    frames = [O.zstd_compress(c, 3) for c in chunks]
+    try:
+        codec.enable_timing(True)
+        res = _decompress_many(codec, frames, [len(c) for c in chunks])
+        kt = codec.kernel_times()
+    finally:
+        codec.enable_timing(False)
+    assert "k_dec_execute" in kt
+    for i, (f, c, (sz, got)) in enumerate(zip(frames, chunks, res)):
+        assert O.decompress(f, len(c)) == c
+        assert sz == len(c) and got == c, (i, len(c), sz)
