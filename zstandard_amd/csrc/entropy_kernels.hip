@@ -697,7 +697,7 @@ __device__ __forceinline__ uint32_t zs_emit_block(uint8_t *out, uint32_t pos, co
     }
     if (type == 2) {
         if (tid == 0) { const uint32_t h = last + (2u << 1) + (total << 3); out[pos] = (uint8_t)h; out[pos + 1] = (uint8_t)(h >> 8); out[pos + 2] = (uint8_t)(h >> 16); }
-        zs_block_copy(out + pos + 3, p1, m.litSecSize, tid, nthreads);
+        if (p1 != out + pos + 3) zs_block_copy(out + pos + 3, p1, m.litSecSize, tid, nthreads);       // (the literals kernel builds a one-block chunk's section in place)
         zs_block_copy(out + pos + 3 + m.litSecSize, p2, m.seqHdrSize, tid, nthreads);
         zs_block_copy(out + pos + 3 + m.litSecSize + m.seqHdrSize, p2 + m.seqHdrSize + m.seqGap, m.seqSecSize - m.seqHdrSize, tid, nthreads);
         return 3 + total;
@@ -729,7 +729,11 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     const ZsRangeHdr *hdr = hdrAll + (size_t)blk * ZS_WALK_RANGES;
     uint8_t *lits = litsAll + (size_t)blk * (ZS_BLOCK_MAX + 64);
     uint8_t *streams = streamAll + (size_t)blk * 4 * ZS_STREAM_STRIDE;
+    // the literal section of a one-block chunk is built where its frame wants it (behind the frame header and the 3-byte block header: the
+    // slot holds zsmi_compressBound(n) >= n + 27 bytes, the section never more than n + 3), every other block's in the section buffer
+    const bool solo = bd.firstInChunk && bd.lastInChunk && !ZS_STOPPED;
     uint8_t *payload = litSecAll + (size_t)blk * ZS_LITSEC_STRIDE;
+    if (solo) { const ZsChunkDesc cd0 = chunks[bd.chunk]; payload = dst + cd0.dstOff + zs_frame_header(nullptr, cd0.size, false) + 3; }
     const uint32_t cap = n + 512;
 
     // The block's literal side is done: its meta goes out; a chunk of ONE block is assembled right here (the sequences kernel ran before this
