@@ -20,11 +20,13 @@
  *  1. candidates: two unit-wide hash tables (short: 5 bytes hashed, long: 8 bytes hashed, level >= 3 only),
  *     every position inserted in order, last writer keeps the slot, slots carry a 15-bit tag.  A position's
  *     candidate = previous owner of its long slot, else of its short slot (tag must agree).  -> dist[p]
- *  2. parse: each block is cut in walk ranges of 1 KiB; each is walked greedily and independently: the first
- *     LOOK candidate positions of a 64-position window (stage-1 candidates, and repeats of the walker's two
- *     recent offsets) are scored, the best one becomes a sequence; matches may pass the range end.
- *  3. stitch: ranges give up what an earlier range's match already covers; the ranges are concatenated,
- *     offsets become repcodes through the decoder's 3-entry recent-offset list
+ *  2. parse: each block is cut in walk ranges of 256 bytes (512 at levels <= 2); each is walked greedily and
+ *     independently: the first LOOK candidate positions of a 32-position window (stage-1 candidates, and repeats of
+ *     the walker's two recent offsets) are scored, the best one becomes a sequence; matches may pass the range end
+ *     by up to 1 KiB.
+ *  3. stitch: ranges give up what an earlier range's match already covers; a range's first match that continues the
+ *     match it meets (same offset, no gap) is joined to it, so a long match found piecewise is one sequence; the ranges
+ *     are concatenated, offsets become repcodes through the decoder's 3-entry recent-offset list
  *     (inverse of ZStdDecompress.cs:1509-1530).
  *  4. literals: histogram, length-limited (11 bit) Huffman by package-merge, weights
  *     written direct or FSE-compressed (inverse of EntropyCommon.cs:198-269 and
@@ -50,10 +52,9 @@ typedef uint64_t U64;
 /* ---- tunables (the HIP kernels are built with the same values) ---- */
 #define BLOCK_MAX   65536u          /* bytes per block */
 #define UNIT_MAX    131072u         /* bytes per LZ unit (match window): two blocks */
-#define WALK_LOG    10              /* the walk cuts a block in ranges of 1 KiB */
-#define WALK_SIZE   (1u << WALK_LOG)
-#define SEQ_PER_RANGE 256u          /* a range's matches start inside it and are >= 4 bytes long */
-#define CROSS_MAX   16384u           /* a match may pass its range's end by this much (and never the block's end) */
+#define WALK_LOG_MIN 8              /* the walk cuts a block in ranges of 256 bytes (level >= 3) or 512 bytes (level <= 2) */
+#define OUT_LOG     10              /* the ranges are handed on in groups of 1 KiB (the HIP walk kernel's output layout) */
+#define CROSS_MAX   1024u           /* a match may pass its range's end by this much (and never the block's end) */
 #define MINMATCH    5               /* shortest match kept; a recent-offset match may be 4 */
 #define MAX_TABLE_LOG 14
 #define HUF_MAXBITS 11
@@ -64,12 +65,14 @@ typedef uint64_t U64;
 #define MLFSELog 9
 #define OffFSELog 8
 
-/* level <= 2 ("fast"): the short table only, LOOK 4 ; level >= 3 ("double"): short + long table, LOOK 8. */
-typedef struct { int useLong; int look; } EParams;
+/* level <= 2 ("fast"): the short table only, walk ranges of 512 bytes, recent offsets tried on 8 positions;
+ * level 3 ("double"): short + long table, ranges of 256 bytes, recent offsets tried on 4 positions;
+ * level >= 4: as 3 with LOOK 8 and recent offsets on 8 positions. */
+typedef struct { int useLong; int look; int walkLog; int repWin; } EParams;
 static EParams paramsForLevel(int level)
 {
     EParams p;
-    p.useLong = level >= 3; p.look = (level <= 2) ? 4 : 8;
+    p.useLong = level >= 3; p.look = (level <= 3) ? 4 : 8; p.walkLog = (level <= 2) ? 9 : 8; p.repWin = (level == 3) ? 4 : 8;
     return p;
 }
 
@@ -504,9 +507,8 @@ typedef struct { U32 start, ml, off; } ASeq;   /* match start (unit position, af
 typedef struct {
     U32 dist[UNIT_MAX];                       /* candidate distance per unit position, 0 = none */
     U32 tabS[1u << MAX_TABLE_LOG], tabL[1u << MAX_TABLE_LOG];
-    ASeq rangeSeq[BLOCK_MAX / WALK_SIZE][SEQ_PER_RANGE];
-    U32 rangeN[BLOCK_MAX / WALK_SIZE];
-    struct { U32 first, nseq, trailing, litSum; } hdr[BLOCK_MAX / WALK_SIZE];
+    ASeq rangeSeq[BLOCK_MAX / 4];             /* a range's records start at (range start - block start) / 4: its matches start inside it and are >= 4 bytes long */
+    U32 rangeN[BLOCK_MAX >> WALK_LOG_MIN];
     Seq seqs[BLOCK_MAX / 3 + 8];
     BYTE lits[BLOCK_MAX + 8];
     BYTE llCode[BLOCK_MAX / 3 + 8], mlCode[BLOCK_MAX / 3 + 8], ofCode[BLOCK_MAX / 3 + 8];
@@ -563,32 +565,33 @@ static U32 matchLen(const BYTE *src, U32 a, U32 b, U32 limit)   /* common prefix
     return l;
 }
 
-/* stage 2 : one walk range [start, end), walked by 8 lanes on the GPU; matches may run on to `limit` (> end: the next
- * ranges' territory, given back by the stitch below).
- * Each step looks at the WINDOW = 64 positions from ip.  A position holds a candidate if (in this order of preference)
- * one of the walker's two recent offsets repeats 4 bytes there (only the first REPWIN positions of the window are
- * tried) or stage 1 left a distance.  The first LOOK (<= 8) such positions are scored: forward match length (the score
- * counts at most FCAP bytes), backward extension into the pending literals (at most BCAP bytes), offset cost (none
- * for a recent offset), literals skipped.  The best one becomes a sequence with its full forward length. */
-#define WINDOW 64u
-#define REPWIN 8u
+/* stage 2 : one walk range [start, end), walked by one walker on the GPU; matches may run on to `limit` (> end: the
+ * next ranges' territory, given back by the stitch below).
+ * Each step looks at the WINDOW = 32 positions from ip.  A position holds a candidate if (in this order of preference)
+ * one of the walker's two recent offsets repeats 4 bytes there (only the first repWin positions of the window are
+ * tried, and only while ip lies at least that offset inside the unit) or stage 1 left a distance.  The first LOOK such
+ * positions are scored: forward match length (the score counts at most FCAP bytes), backward extension into the
+ * pending literals (at most BCAP bytes), offset cost (none for a recent offset), literals skipped.  The best one (the
+ * earliest among equals) becomes a sequence with its full forward length. */
+#define WINDOW 32u
 #define FCAP 8u
-#define BCAP 8u
+#define BCAP 4u
 #define REPMIN 4u
 static U32 walkRange(Work *w, const BYTE *src, U32 n, U32 start, U32 end, U32 limit, const EParams *prm, ASeq *out)
 {
     U32 ip = start, anchor = start, nseq = 0, rep0 = 0, rep1 = 0;
     U32 const hashable = (n >= 8) ? n - 7 : 0;
-    U32 const look = (U32)prm->look;
+    U32 const look = (U32)prm->look, repWin = (U32)prm->repWin;
     U32 const scanEnd = (end < hashable) ? end : hashable;     /* candidates start below this */
     while (ip < scanEnd) {
         int bestGain = 0, have = 0; U32 bestQ = 0, bestFwd = 0, bestBack = 0, bestOff = 0, q, seen = 0;
         U32 const wend = (ip + WINDOW < scanEnd) ? ip + WINDOW : scanEnd;
+        int const try0 = rep0 && ip >= rep0, try1 = rep1 && ip >= rep1;
         for (q = ip; q < wend && seen < look; q++) {
             U32 off = 0, fwd, back = 0; int isRep = 0, gain;
-            if (q < ip + REPWIN && q + 4 <= limit) {
-                if (rep0 && q >= rep0 && rd32(src + q) == rd32(src + q - rep0)) { off = rep0; isRep = 1; }
-                else if (rep1 && q >= rep1 && rd32(src + q) == rd32(src + q - rep1)) { off = rep1; isRep = 1; }
+            if (q < ip + repWin && q + 4 <= limit) {
+                if (try0 && rd32(src + q) == rd32(src + q - rep0)) { off = rep0; isRep = 1; }
+                else if (try1 && rd32(src + q) == rd32(src + q - rep1)) { off = rep1; isRep = 1; }
             }
             if (!off) off = w->dist[q];
             if (!off) continue;
@@ -608,34 +611,52 @@ static U32 walkRange(Work *w, const BYTE *src, U32 n, U32 start, U32 end, U32 li
     return nseq;
 }
 
-/* stage 3a, the stitch: reach[r] = farthest match end of the ranges up to r (as walked).  Range r owns the territory
- * [max(start_r, reach[r-1]), max(end_r, reach[r])): its sequences that end inside an earlier range's match are dropped, one
- * that straddles the border loses its front (and goes if fewer than MINMATCH bytes are left).  What a range keeps is a
- * suffix [first, first + nseq) of its list.  Every range decides from reach[] alone: one lane per range on the GPU, which
- * also leaves litSum (literals in front of the kept matches inside the territory) and trailing (behind the last one). */
-static void stitch(Work *w, U32 blockOff, U32 n)
+/* stages 2 + 3a for one block: every range walked on its own, then the stitch.  reach = farthest match end of the ranges
+ * so far (as walked).  A range's records that end at or before the reach are dropped; one that straddles it loses its front
+ * (and goes if fewer than MINMATCH bytes are left).  The first record a range keeps is JOINED to the match that defines the
+ * reach -- instead of becoming a sequence -- when it starts exactly at the reach, has that match's offset, and that match
+ * (the last record of its range) was itself kept: a long match found piecewise by consecutive ranges is one sequence.
+ * Every decision follows from the ranges' last match ends and last offsets alone, so the GPU decides all ranges at once
+ * (k_lz_walk: a scan of the ends, one lane per range, a second scan for the joined lengths).
+ * Leaves w->seqs / w->lits; returns the number of sequences. */
+static U32 parseBlock(Work *w, const BYTE *src, U32 unitN, U32 blockOff, U32 n, const EParams *prm, U32 *nlitOut)
 {
-    U32 const nRanges = (n + WALK_SIZE - 1) >> WALK_LOG;
+    U32 nseq = 0, nlit = 0;
+    U32 const WS = 1u << prm->walkLog;
+    U32 const nRanges = (n + WS - 1) >> prm->walkLog;
     U32 const blockEnd = blockOff + n;
-    U32 reach = blockOff, r;
+    U32 r, reach = blockOff, pos = blockOff;       /* pos: end of the last sequence's match (<= reach) */
+    U32 reachOff = 0; int reachKept = 0;            /* the match that defines the reach: its offset; whether it is the last sequence */
     for (r = 0; r < nRanges; r++) {
-        U32 const own = reach;                         /* reach[r-1] */
+        U32 const start = blockOff + (r << prm->walkLog);
+        U32 const end = (start + WS < blockEnd) ? start + WS : blockEnd;
+        U32 const limit = (end + CROSS_MAX < blockEnd) ? end + CROSS_MAX : blockEnd;
+        w->rangeN[r] = walkRange(w, src, unitN, start, end, limit, prm, w->rangeSeq + ((start - blockOff) >> 2));
+    }
+    for (r = 0; r < nRanges; r++) {
+        ASeq *const rs = w->rangeSeq + (r << (prm->walkLog - 2));
+        U32 const own = reach;                         /* reach of the ranges before r */
         U32 const ns = w->rangeN[r];
-        U32 const rs = blockOff + (r << WALK_LOG), re = (rs + WALK_SIZE < blockEnd) ? rs + WALK_SIZE : blockEnd;
-        U32 const le = ns ? w->rangeSeq[r][ns - 1].start + w->rangeSeq[r][ns - 1].ml : 0;
-        U32 es, te, f = 0, k, sumMl = 0, lastEnd;
-        if (le > reach) reach = le;
-        es = rs > own ? rs : own; te = re > reach ? re : reach;
+        U32 const le = ns ? rs[ns - 1].start + rs[ns - 1].ml : 0;
+        U32 f = 0, k;
         while (f < ns) {
-            ASeq *s = &w->rangeSeq[r][f];
+            ASeq *s = &rs[f];
             if (s->start + s->ml <= own) { f++; continue; }
             if (s->start < own) { U32 const cut = own - s->start; if (s->ml - cut < MINMATCH) { f++; continue; } s->start += cut; s->ml -= cut; }
             break;
         }
-        for (k = f; k < ns; k++) sumMl += w->rangeSeq[r][k].ml;
-        lastEnd = (ns > f) ? le : es;
-        w->hdr[r].first = f; w->hdr[r].nseq = ns - f; w->hdr[r].trailing = te - lastEnd; w->hdr[r].litSum = (lastEnd - es) - sumMl;
+        for (k = f; k < ns; k++) {
+            ASeq const s = rs[k];
+            if (k == f && reachKept && s.start == own && s.off == reachOff) { w->seqs[nseq - 1].matchLength += s.ml; pos = s.start + s.ml; continue; }
+            w->seqs[nseq].litLength = s.start - pos; w->seqs[nseq].matchLength = s.ml; w->seqs[nseq].offset = s.off; nseq++;
+            memcpy(w->lits + nlit, src + pos, s.start - pos); nlit += s.start - pos;
+            pos = s.start + s.ml;
+        }
+        if (le > reach) { reach = le; reachOff = rs[ns - 1].off; reachKept = (f < ns); }
     }
+    memcpy(w->lits + nlit, src + pos, blockEnd - pos); nlit += blockEnd - pos;    /* last literals */
+    *nlitOut = nlit;
+    return nseq;
 }
 
 /* ======================================================================= *
@@ -646,32 +667,9 @@ static void stitch(Work *w, U32 blockOff, U32 n)
 static size_t encodeParsed(Work *w, BYTE *dst, size_t cap, U32 nseq, U32 nlit, int firstBlock);
 static size_t compressBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32 unitN, U32 blockOff, U32 n, const EParams *prm, int firstBlock)
 {
-    U32 nseq = 0, nlit = 0;
-    U32 const nRanges = (n + WALK_SIZE - 1) >> WALK_LOG;
-    U32 const blockEnd = blockOff + n;
-    U32 r;
+    U32 nseq, nlit = 0;
     if (n < 16) return 0;
-    /* stage 2: every range on its own */
-    for (r = 0; r < nRanges; r++) {
-        U32 const start = blockOff + (r << WALK_LOG);
-        U32 const end = (start + WALK_SIZE < blockEnd) ? start + WALK_SIZE : blockEnd;
-        U32 const limit = (end + CROSS_MAX < blockEnd) ? end + CROSS_MAX : blockEnd;
-        w->rangeN[r] = walkRange(w, src, unitN, start, end, limit, prm, w->rangeSeq[r]);
-    }
-    stitch(w, blockOff, n);
-    {   /* concatenate what the ranges keep; what lies between kept matches is literals */
-        U32 pos = blockOff;                            /* end of the last kept match */
-        for (r = 0; r < nRanges; r++) {
-            U32 k;
-            for (k = w->hdr[r].first; k < w->hdr[r].first + w->hdr[r].nseq; k++) {
-                ASeq const s = w->rangeSeq[r][k];
-                w->seqs[nseq].litLength = s.start - pos; w->seqs[nseq].matchLength = s.ml; w->seqs[nseq].offset = s.off; nseq++;
-                memcpy(w->lits + nlit, src + pos, s.start - pos); nlit += s.start - pos;
-                pos = s.start + s.ml;
-            }
-        }
-        memcpy(w->lits + nlit, src + pos, blockEnd - pos); nlit += blockEnd - pos;    /* last literals */
-    }
+    nseq = parseBlock(w, src, unitN, blockOff, n, prm, &nlit);
     return encodeParsed(w, dst, cap, nseq, nlit, firstBlock);
 }
 
@@ -862,32 +860,25 @@ int zso_debugCandidates(uint32_t *distOut, const void *src, uint32_t n, int leve
     free(w);
     return 0;
 }
-/* after the stitch, as the GPU walk kernel leaves it.  The unit's blocks are taken in turn; per walk range r (1 KiB) of the unit:
- * hdrOut[r*4 ..] = first, nseq, trailing, litSum; seqOut[(r*256 + k)*3 ..] = (start in its block, matchLength, offset) of record k */
-int zso_debugWalk(uint32_t *seqOut, uint32_t *hdrOut, const void *src, uint32_t n, int level)
+/* after the stitch: the sequences of the unit's blocks in turn.  seqOut[3 k ..] = (match start in its block, matchLength, offset) of the
+ * block's k-th sequence, nseqOut[b] = sequences of block b (what the GPU walk kernel leaves, its output ranges read in order) */
+int zso_debugWalk(uint32_t *seqOut, uint32_t *nseqOut, const void *src, uint32_t n, int level)
 {
     EParams const prm = paramsForLevel(level);
     Work *w = (Work *)malloc(sizeof(Work));
-    U32 blockOff;
+    U32 blockOff, b = 0, o = 0;
     if (!w || n > UNIT_MAX) { free(w); return -1; }
     findCandidates(w, (const BYTE *)src, n, &prm);
-    for (blockOff = 0; blockOff < n; blockOff += BLOCK_MAX) {
+    for (blockOff = 0; blockOff < n; blockOff += BLOCK_MAX, b++) {
         U32 const bn = (n - blockOff < BLOCK_MAX) ? n - blockOff : BLOCK_MAX;
-        U32 const blockEnd = blockOff + bn, nRanges = (bn + WALK_SIZE - 1) >> WALK_LOG;
-        U32 r, k;
-        if (bn < 16) { for (r = 0; r < nRanges; r++) w->rangeN[r] = 0; }
-        else for (r = 0; r < nRanges; r++) {
-            U32 const start = blockOff + (r << WALK_LOG);
-            U32 const end = (start + WALK_SIZE < blockEnd) ? start + WALK_SIZE : blockEnd;
-            U32 const limit = (end + CROSS_MAX < blockEnd) ? end + CROSS_MAX : blockEnd;
-            w->rangeN[r] = walkRange(w, (const BYTE *)src, n, start, end, limit, &prm, w->rangeSeq[r]);
+        U32 nlit = 0, k, pos = 0;
+        U32 const ns = (bn < 16) ? 0 : parseBlock(w, (const BYTE *)src, n, blockOff, bn, &prm, &nlit);
+        for (k = 0; k < ns; k++) {
+            pos += w->seqs[k].litLength;
+            seqOut[o++] = pos; seqOut[o++] = w->seqs[k].matchLength; seqOut[o++] = w->seqs[k].offset;
+            pos += w->seqs[k].matchLength;
         }
-        stitch(w, blockOff, bn);
-        for (r = 0; r < nRanges; r++) {
-            U32 const ur = (blockOff >> WALK_LOG) + r;
-            hdrOut[ur * 4] = w->hdr[r].first; hdrOut[ur * 4 + 1] = w->hdr[r].nseq; hdrOut[ur * 4 + 2] = w->hdr[r].trailing; hdrOut[ur * 4 + 3] = w->hdr[r].litSum;
-            for (k = 0; k < w->rangeN[r]; k++) { seqOut[(ur * 256 + k) * 3] = w->rangeSeq[r][k].start - blockOff; seqOut[(ur * 256 + k) * 3 + 1] = w->rangeSeq[r][k].ml; seqOut[(ur * 256 + k) * 3 + 2] = w->rangeSeq[r][k].off; }
-        }
+        nseqOut[b] = ns;
     }
     free(w);
     return 0;
