@@ -21,7 +21,7 @@
  *     every position inserted in order, last writer keeps the slot, slots carry a 15-bit tag.  A position's
  *     candidate = previous owner of its long slot, else of its short slot (tag must agree).  -> dist[p]
  *  2. parse: each block is cut in walk ranges of 256 bytes (512 at levels <= 2); each is walked greedily and
- *     independently: the first LOOK candidate positions of a 32-position window (stage-1 candidates, and repeats of
+ *     independently: the first LOOK candidate positions of a 9 .. 16-position window (stage-1 candidates, and repeats of
  *     the walker's two recent offsets) are scored, the best one becomes a sequence; matches may pass the range end
  *     by up to 1 KiB.
  *  3. stitch: ranges give up what an earlier range's match already covers; a range's first match that continues the
@@ -567,13 +567,15 @@ static U32 matchLen(const BYTE *src, U32 a, U32 b, U32 limit)   /* common prefix
 
 /* stage 2 : one walk range [start, end), walked by one walker on the GPU; matches may run on to `limit` (> end: the
  * next ranges' territory, given back by the stitch below).
- * Each step looks at the WINDOW = 32 positions from ip.  A position holds a candidate if (in this order of preference)
+ * Each step looks at the positions from ip to the end of the second aligned group of 8 (9 .. 16 positions: what the GPU walker's two
+ * lanes load of the candidate distances, 16 bytes each).  A position holds a candidate if (in this order of preference)
  * one of the walker's two recent offsets repeats 4 bytes there (only the first repWin positions of the window are
  * tried, and only while ip lies at least that offset inside the unit) or stage 1 left a distance.  The first LOOK such
  * positions are scored: forward match length (the score counts at most FCAP bytes), backward extension into the
  * pending literals (at most BCAP bytes), offset cost (none for a recent offset), literals skipped.  The best one (the
  * earliest among equals) becomes a sequence with its full forward length. */
-#define WINDOW 32u
+#define WINDOW_GROUPS 2u           /* = lanes of a GPU walker (ZS_WALK_LPW): each loads one group's candidate distances, 16 bytes */
+#define WINDOW (8u * WINDOW_GROUPS)
 #define FCAP 8u
 #define BCAP 4u
 #define REPMIN 4u
@@ -585,7 +587,7 @@ static U32 walkRange(Work *w, const BYTE *src, U32 n, U32 start, U32 end, U32 li
     U32 const scanEnd = (end < hashable) ? end : hashable;     /* candidates start below this */
     while (ip < scanEnd) {
         int bestGain = 0, have = 0; U32 bestQ = 0, bestFwd = 0, bestBack = 0, bestOff = 0, q, seen = 0;
-        U32 const wend = (ip + WINDOW < scanEnd) ? ip + WINDOW : scanEnd;
+        U32 const wend = ((ip & ~7u) + WINDOW < scanEnd) ? (ip & ~7u) + WINDOW : scanEnd;   /* WINDOW_GROUPS aligned groups of 8 positions: 9 .. 16 positions */
         int const try0 = rep0 && ip >= rep0, try1 = rep1 && ip >= rep1;
         for (q = ip; q < wend && seen < look; q++) {
             U32 off = 0, fwd, back = 0; int isRep = 0, gain;

@@ -22,15 +22,16 @@ typedef struct {
     int estOff;       /* 1: the estimate counts the offset's cost */
     int initRep;      /* 1: a range starts with rep0 = the distance of the nearest candidate position below its start */
     int bcap, fcap;   /* backward cap, forward score cap */
+    int walign;       /* 1: the window ends at an aligned group of 8: (ip & ~7) + window */
     int estRun;       /* 1: the estimate adds the run of candidate positions that follows (cap FCAP) */
 } WP;
-static WP P = { 10, 16384, 0, 0, 64, 8, 0, 0, 0, 0, 0, 8, 5, 4, 5, 1, 1, 0, 8, 8, 0 };
+static WP P = { 10, 16384, 0, 0, 64, 8, 0, 0, 0, 0, 0, 8, 5, 4, 5, 1, 1, 0, 8, 8, 0, 0 };
 static BYTE wlLong[UNIT_MAX];
 static struct { unsigned long long steps, emptySteps, scored, emitted, kept, extBytes, ranges, merged; } S;
 void wl_set(const char *k, int v)
 {
 #define K(name) if (!strcmp(k, #name)) { P.name = v; return; }
-    K(walkLog) K(crossMax) K(look) K(merge) K(window) K(repwin) K(longEven) K(carryRep) K(skipFirst) K(lazyMax) K(approx) K(estLong) K(estShort) K(estRep) K(estSkip) K(useBack) K(estOff) K(initRep) K(bcap) K(fcap) K(estRun)
+    K(walkLog) K(crossMax) K(look) K(merge) K(window) K(repwin) K(longEven) K(carryRep) K(skipFirst) K(lazyMax) K(approx) K(estLong) K(estShort) K(estRep) K(estSkip) K(useBack) K(estOff) K(initRep) K(bcap) K(fcap) K(walign) K(estRun)
 #undef K
     fprintf(stderr, "unknown %s\n", k); abort();
 }
@@ -72,7 +73,8 @@ static U32 wlWalk(Work *w, const BYTE *src, U32 n, U32 start, U32 end, U32 limit
     U32 mySteps = 0;
     while (ip < scanEnd) {
         int bestGain = 0, have = 0; U32 bestQ = 0, bestFwd = 0, bestBack = 0, bestOff = 0, q, seen = 0;
-        U32 const wend = (ip + (U32)P.window < scanEnd) ? ip + (U32)P.window : scanEnd;
+        U32 const wbase = P.walign ? (ip & ~7u) : ip;
+        U32 const wend = (wbase + (U32)P.window < scanEnd) ? wbase + (U32)P.window : scanEnd;
         S.steps++; mySteps++;
         if (P.approx) {
             U32 cq[16], coff[16]; int crep[16], cest[16], nc = 0, k, tries;

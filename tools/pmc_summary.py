@@ -2,7 +2,7 @@ import re, csv, glob, collections, sys, os
 tag = sys.argv[1]
 root = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
 res = collections.defaultdict(dict)
-for d in "abcde":
+for d in "abcdef":
     fs = glob.glob(f"{root}/pmc_{tag}_{d}/*/*_counter_collection.csv")
     if not fs: continue
     rows = list(csv.DictReader(open(fs[0])))

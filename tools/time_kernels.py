@@ -2,7 +2,8 @@
 """Development aid (GPU box): per-kernel times of the compress path without any output check (for timing-aid builds /
 ZSMI_STOP_SEQ / ZSMI_STOP_LIT runs whose output is not a valid frame)."""
 import sys, os
-os.environ["ZSMI_DEBUG_LIB"] = "1"          # the library built with -DZSMI_DEBUG_HOOKS (zstandard_amd/_lib.py)
+if not os.environ.get("ZSMI_LIB_FILE"):
+    os.environ["ZSMI_DEBUG_LIB"] = "1"      # the library built with -DZSMI_DEBUG_HOOKS (zstandard_amd/_lib.py); ZSMI_LIB_FILE: a variant build
 import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))

@@ -1263,7 +1263,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                     uint32_t val;
                     if (ll) { val = (off == prev) ? 1u : (off == a) ? 2u : (off == b) ? 3u : 0u; }
                     else    { val = (off == a) ? 1u : (off == b) ? 2u : 0u; }
-                    rp->x = (raw.x & 0x07FFFFFFu) | (val << 27);
+                    rp->x = zs_rec_with_rep(raw.x, val);
                     const uint32_t v = val ? val : off + 3;
                     atomicAdd(&L.count[llCodeOf(ll)], 1u);
                     atomicAdd(&L.count[64 + zs_highbit(v)], 1u);

@@ -224,23 +224,45 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------
-// k_lz_walk<NW> : one workgroup of NW / 8 wavefronts per LZ unit; NW = 64 (unit <= 64 KiB) or 128 (<= 128 KiB).
-// The unit's source bytes are staged in LDS once (NW KiB + pads), so every compare of the walk is an LDS read and
-// the unit is fetched from HBM once.  The lanes are NW independent walkers of 8 lanes; walker g walks the walk
-// range g (1 KiB).  A walker step looks at the 64 positions from ip: the candidate bits of stage 1 (LDS copy of the
-// bit plane), plus, for the first ZS_REPWIN = 8 positions, the positions where one of the walker's two recent offsets repeats
-// 4 bytes (lane sub tries ip + sub).  The first LOOK positions holding a candidate go one per lane; a lane
-// takes the recent offset or fetches the stage-1 distance (global), compares 16 bytes forward (the score counts ZS_FCAP of
-// them) and 8 bytes backward (into the pending literals) and scores; the best one of the walker becomes a sequence
-// (extended by the walker's 8 lanes if it hit the 16-byte cap).  A match may run past the range end, ZS_CROSS_MAX bytes at most.
-// After a barrier one lane per range stitches (compressBlock in oracle/zso_encoder.c): reach = running maximum of the
-// ranges' last match ends; a range drops the records an earlier range's match covers and cuts the front of one that
-// straddles; its header gets first / nseq / litSum / trailing for its territory [max(start, reach before), max(end, reach)).
-// Scalar statement: walkRange + the stitch in oracle/zso_encoder.c.
+// k_lz_walk<LPW, LOOK, REPWIN, BIG, NT> : one workgroup of NT threads per LZ unit (BIG: 64 KiB < unit <= 128 KiB).
+// The unit's source bytes are staged in LDS once (+ pads): every compare of the walk is an LDS read and the unit is fetched from HBM
+// once.  The unit is cut in walk ranges of R = 1 << rangeLog bytes (256; 512 at levels <= 2); a WALKER = 4 adjacent lanes takes ranges
+// from a queue (an LDS counter) and walks each on its own (walkRange in oracle/zso_encoder.c).  A step looks at the positions from ip to
+// the end of the fourth aligned group of 8: lane j of the walker has group j's stage-1 distances brought into its slot of the wavefront's
+// exchange buffer in LDS (16 coalesced bytes by LDS-DMA: the walker's 64 bytes are one cache line; requested a step ahead, right after ip
+// is known) and turns them into 8 candidate bits; plus, for the first REPWIN positions, the positions where one of the walker's two recent offsets
+// repeats 4 bytes.  The first LOOK such positions are scored, LOOK / 4 per lane: recent offset or the distance from the exchange buffer,
+// 8 bytes forward and 4 backward compared in LDS; the walker's best becomes a record (start, length, offset) in the range's slots of
+// recAll, after its lanes measured its whole length (16 bytes a lane and round).  A match may run past the range end, ZS_CROSS_MAX bytes
+// at most, never past the block end.
+// (Round 2 gave a walker 8 lanes with one candidate each and ranges of 1 KiB: of its ~215 vector instructions a step ~100 were the
+// same in all 8 lanes, and 8 candidates a step were measured of which the next step measured most again.  The first form of this
+// kernel fetched each candidate's distance with its own 2-byte load: 4 requests to L2 a step, none of them hitting L1, 14 K a unit,
+// and the kernel sat at the rate the vector cache takes misses: profiles/r3_walk_first_pmc.csv.)
+// Then the stitch, one lane per range and block (parseBlock in oracle/zso_encoder.c): reach = running maximum of the ranges' last match
+// ends (a scan); a range drops the records that end at or below the reach before it and cuts the front of one that straddles; its first
+// record left is JOINED to the match that defines the reach if it starts there with the same offset (long matches are found piecewise:
+// the walkers cannot see each other); a second, backward scan gives every range's last record the end of what was joined to it.
+// Last, the records that count are packed, 1 KiB of source (an OUTPUT RANGE = 1024 / R walk ranges) at a time, into the layout the
+// entropy kernels read: seqAll[block][64 output ranges][256 records] + hdrAll (nseq, trailing, litSum, first = 0).
 // ---------------------------------------------------------------------------------------------
+#ifndef ZS_WALK_NT
+#define ZS_WALK_NT 512             // threads per unit <= 64 KiB: 128 walkers for its 256 walk ranges of 256 bytes
+#endif
+#ifndef ZS_WALK_NT_BIG
+#define ZS_WALK_NT_BIG 1024        // threads per unit <= 128 KiB
+#endif
+#ifndef ZS_WALK_MINW
+#define ZS_WALK_MINW 1             // waves per SIMD the small-unit kernel is compiled for (register budget)
+#endif
+#ifndef ZS_WALK_LPW
+#define ZS_WALK_LPW 2               // lanes per walker = aligned groups of 8 positions a step looks at (oracle: WINDOW_GROUPS)
+#endif
+#define ZS_WALK_KERNEL(LOOK, REPW, BIG) k_lz_walk<ZS_WALK_LPW, LOOK, REPW, BIG, ((BIG) ? ZS_WALK_NT_BIG : ZS_WALK_NT)>
 #define ZS_WALK_FRONT 16u          // LDS bytes in front of the unit (backward reads near position 0)
 #define ZS_WALK_TAIL  144u         // zero bytes behind the unit (forward reads near the end)
-#define ZS_WALK_LDS(CAPB) (ZS_WALK_FRONT + (CAPB) + ZS_WALK_TAIL + (CAPB) / 8 + 16 + ((CAPB) >> ZS_WALK_LOG) * 16)   // source + candidate bit plane + per-range results
+// exchange buffer (16 bytes a lane) + source + queue head + a byte a lane (BIG: bit 16 of the distances)
+#define ZS_WALK_LDS(CAPB) (ZS_WALK_FRONT + (CAPB) + ZS_WALK_TAIL + (CAPB) / 8 + 16 + 16 + 1024)
 
 // K dwords of the LDS copy starting at any byte offset, fetched as K + 1 aligned dwords and shifted into place
 // (an unaligned ds_read_b64 / b128 costs the LDS several passes: SQ_LDS_UNALIGNED_STALL was 80 % of its busy time)
@@ -258,53 +280,131 @@ __device__ __forceinline__ void lds_span(uint32_t byteOff, uint32_t (&out)[K])
     #pragma unroll
     for (int k = 0; k < K; k++) out[k] = __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh);
 }
-__device__ __forceinline__ uint64_t zs_u64(uint32_t lo, uint32_t hi) { return (uint64_t)lo | ((uint64_t)hi << 32); }
-template <int NW>
-__global__ void __launch_bounds__(NW * 8)
-k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units, uint32_t block0,
-          const uint16_t *__restrict__ distAll, const uint8_t *__restrict__ distHiAll, const uint8_t *__restrict__ distMaskAll,
-          ZsSeqRec *__restrict__ seqAll, ZsRangeHdr *__restrict__ hdrAll, int look)
+// the 4 bytes at byte offset I of a span (I a constant)
+template <int I, int K>
+__device__ __forceinline__ uint32_t span_at(const uint32_t (&v)[K])
 {
-    constexpr uint32_t WLOG = ZS_WALK_LOG, WSIZE = 1u << WLOG;                     // bytes per walk range
-    constexpr uint32_t CAP = NW * WSIZE;                                          // unit capacity in bytes
-    constexpr bool BIG = CAP > ZS_BLOCK_MAX;
+    if constexpr ((I & 3) == 0) return v[I >> 2];
+    else return __builtin_amdgcn_alignbyte(v[(I >> 2) + 1], v[I >> 2], I & 3);
+}
+// bytes two 16-byte pieces agree on from their start (16: all)
+__device__ __forceinline__ uint32_t zs_agree16(const uint32_t (&a)[4], const uint32_t (&b)[4])
+{
+    const uint64_t x0 = (uint64_t)(a[0] ^ b[0]) | ((uint64_t)(a[1] ^ b[1]) << 32), x1 = (uint64_t)(a[2] ^ b[2]) | ((uint64_t)(a[3] ^ b[3]) << 32);
+    const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
+    const uint32_t n1 = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u;
+    return (n0 < 8u) ? n0 : 8u + n1;
+}
+// or / max / min over the LPW (2 or 4) adjacent lanes of a walker (data-parallel-primitive moves inside a quad: no LDS round trip)
+template <int LPW> __device__ __forceinline__ uint32_t walker_or(uint32_t v)
+{
+    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+    if constexpr (LPW == 4) v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+    return v;
+}
+template <int LPW> __device__ __forceinline__ int walker_max(int v)
+{
+    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));
+    if constexpr (LPW == 4) v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));
+    return v;
+}
+template <int LPW> __device__ __forceinline__ uint32_t walker_min(uint32_t v)
+{
+    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+    if constexpr (LPW == 4) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+    return v;
+}
+// inclusive maximum over the threads 0 .. t of the workgroup (DIR = 1) or t .. NT - 1 (DIR = -1); wv: NT / 64 words of LDS.  Two barriers.
+template <int NT, int DIR>
+__device__ __forceinline__ uint32_t block_scan_max(uint32_t v, uint32_t *wv, uint32_t tid, uint32_t *total)
+{
+    const uint32_t lane = tid & 63u, wave = tid >> 6;
+    #pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = (uint32_t)(DIR > 0 ? __shfl_up((int)v, d) : __shfl_down((int)v, d));
+        if (DIR > 0 ? (int)lane >= d : (int)lane + d < 64) v = max(v, o);
+    }
+    __syncthreads();                                                     // (the words may still be read from the scan before)
+    if (lane == (DIR > 0 ? 63u : 0u)) wv[wave] = v;
+    __syncthreads();
+    uint32_t pre = 0, all = 0;
+    #pragma unroll
+    for (uint32_t k = 0; k < NT / 64; k++) { const uint32_t x = wv[k]; all = max(all, x); if (DIR > 0 ? k < wave : k > wave) pre = max(pre, x); }
+    *total = all;
+    return max(v, pre);
+}
+// 8 distances (16 bits each) -> bit i: distance i is not zero
+__device__ __forceinline__ uint32_t zs_nonzero8(const uint4 d)
+{
+    typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
+    const u16x2 one = { 1, 1 };
+    auto nz = [&](uint32_t w) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, w), one)); };   // v_pk_min_u16: 1 per half that is not zero
+    const uint32_t v = nz(d.x) | (nz(d.y) << 2) | (nz(d.z) << 4) | (nz(d.w) << 6);       // low halves at bits 0, 2, 4, 6; high halves at bits 16, 18, 20, 22
+    return (v | (v >> 15)) & 0xFFu;
+}
+
+#ifdef ZS_WALK_PROFILE
+// diagnostic build (tools/walk_profile.py): s_memtime stamps per wavefront and step part, every outstanding memory operation waited for at a stamp
+// (so the parts do not overlap as they do in the product); the sums go behind all blocks' range results (the output stays valid)
+#define WPROF_STAMP(k) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); __builtin_amdgcn_sched_barrier(0); wprof[k] += t_ - wlast; wlast = t_; }
+#else
+#define WPROF_STAMP(k)
+#endif
+template <int LPW, int LOOK, int REPWIN, bool BIG, int NT>
+__global__ void __launch_bounds__(NT, BIG ? 1 : ZS_WALK_MINW)
+k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units, uint32_t block0,
+          const uint16_t *__restrict__ distAll, const uint8_t *__restrict__ distHiAll,
+          uint2 *__restrict__ recAll, uint32_t junkSlot, uint4 *__restrict__ resAll, int rangeLogArg)
+{
+    constexpr uint32_t CAP = BIG ? ZS_UNIT_MAX : ZS_BLOCK_MAX;                  // unit capacity in bytes
+    constexpr uint32_t CPL = LOOK / LPW, RPL = REPWIN / LPW;                     // candidates / recent-offset positions per lane and step
+    static_assert((LPW == 2 || LPW == 4) && LOOK % LPW == 0 && REPWIN % LPW == 0 && CPL >= 1 && RPL >= 1 && LOOK <= 8 && REPWIN <= 8, "a walker's lanes share the candidates evenly");
+    static_assert(NT >= 256 && NT % 64 == 0 && NT * 16 <= CAP / 8, "the stitch takes a block's <= 256 ranges a thread each; the exchange buffer holds 16 bytes a lane");
     extern __shared__ __attribute__((aligned(16))) uint8_t walkLds[];
-    uint8_t *ls = walkLds + ZS_WALK_FRONT;                                       // ls[p] = source byte p
-    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+    // LDS: exchange buffer (the low addresses: the LDS-DMA's base register is not known to reach beyond 64 KiB), front pad, source, tail pad, results, queue, xhi
+    constexpr uint32_t SRC = CAP / 8 + 16 + ZS_WALK_FRONT;                       // LDS address of source byte 0
+    uint8_t *ls = walkLds + SRC;                                                 // ls[p] = source byte p
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t rangeLog = (uint32_t)rangeLogArg, R = 1u << rangeLog;
     const ZsUnitDesc ud = units[blockIdx.x];
     const uint32_t slot = ud.firstBlock - block0;                                // scratch slot of the unit's first block
     const uint8_t *s = src + ud.srcOff;
     const uint32_t n = ud.size;
     const uint16_t *dist = distAll + (size_t)slot * ZS_BLOCK_MAX;
     const uint8_t *distHi = distHiAll + (size_t)slot * (ZS_BLOCK_MAX / 8);
-    const uint64_t *distMask = reinterpret_cast<const uint64_t *>(distMaskAll + (size_t)slot * (ZS_BLOCK_MAX / 8));
-    uint64_t *lm = reinterpret_cast<uint64_t *>(walkLds + ZS_WALK_FRONT + CAP + ZS_WALK_TAIL);     // lm: bit p set = position p has a candidate
-    uint4 *res = reinterpret_cast<uint4 *>(walkLds + ZS_WALK_FRONT + CAP + ZS_WALK_TAIL + CAP / 8 + 16);   // per range: nseq, last match end, sum of match lengths
-    const uint32_t grp = lane >> 3, sub = lane & 7u;
-    const uint32_t walker = wave * 8 + grp;
-    ZsSeqRec *seqs = seqAll + (size_t)slot * (ZS_BLOCK_MAX / 4) + (size_t)walker * (WSIZE / 4);
+    uint4 *xbuf = reinterpret_cast<uint4 *>(walkLds);                              // exchange buffer: lane t's 8 distances at xbuf[t]
+    uint32_t *queue = reinterpret_cast<uint32_t *>(walkLds + SRC + CAP + ZS_WALK_TAIL);
+    uint4 *res = resAll + (size_t)slot * ZS_RES_PER_BLOCK;                       // per walk range (R >= 256: at most 256 a block): records, last match end in its block, last offset
+    uint8_t *xhi = reinterpret_cast<uint8_t *>(queue + 4);                        // BIG: lane t's byte of bit 16 of its 8 distances
+    uint2 *recs = recAll + (size_t)slot * (ZS_BLOCK_MAX / 4);                     // range at unit position p: slots from p / 4 (its matches start inside it, >= 4 bytes each)
+    const uint32_t sub = lane & (LPW - 1u);
+#ifdef ZS_WALK_PROFILE
+    unsigned long long wprof[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 }, wlast;
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wlast) :: "memory");
+#endif
 
     // ---- stage the unit ----
-    if (tid < ZS_WALK_FRONT / 4) reinterpret_cast<uint32_t *>(walkLds)[tid] = 0;
+    if (tid < ZS_WALK_FRONT / 4) reinterpret_cast<uint32_t *>(walkLds + SRC - ZS_WALK_FRONT)[tid] = 0;
+    if (tid == 0) *queue = 0;
     {
-        // whole 16-byte pieces: the (up to 8) loads of a thread are issued together (a load behind a branch, followed by its LDS
+        // whole 16-byte pieces: the loads of a thread are issued together (a load behind a branch, followed by its LDS
         // store, would wait out one memory round trip per piece); then the partial piece and the zero tail
-        constexpr uint32_t T = NW * 8, PER = CAP / 16 / T;                       // threads, pieces per thread (8)
+        constexpr uint32_t PER = CAP / 16 / NT;                                  // pieces per thread
         const uint32_t nFull = n & ~15u;
         uint4 v[PER];
         #pragma unroll
         for (uint32_t k = 0; k < PER; k++) {
-            const uint32_t i = (tid + k * T) * 16;
+            const uint32_t i = (tid + k * NT) * 16;
             const uint32_t ii = (i + 16 <= nFull) ? i : 0u;                      // clamped: always a valid address when nFull >= 16
             v[k] = make_uint4(0, 0, 0, 0);
             if (nFull >= 16) __builtin_memcpy(&v[k], s + ii, 16);
         }
         #pragma unroll
         for (uint32_t k = 0; k < PER; k++) {
-            const uint32_t i = (tid + k * T) * 16;
+            const uint32_t i = (tid + k * NT) * 16;
             if (i + 16 <= nFull) *reinterpret_cast<uint4 *>(ls + i) = v[k];
         }
-        for (uint32_t i = nFull + tid * 16; i < n + ZS_WALK_TAIL; i += T * 16) {
+        for (uint32_t i = nFull + tid * 16; i < n + ZS_WALK_TAIL; i += NT * 16) {
             uint4 w = make_uint4(0, 0, 0, 0);
             if (i < n) {
                 uint64_t lo = 0, hi = 0;
@@ -314,188 +414,319 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
             if (i + 16 <= CAP + ZS_WALK_TAIL) *reinterpret_cast<uint4 *>(ls + i) = w;
         }
     }
+#if defined(ZS_WALK_STOP) && ZS_WALK_STOP == 1
+    if (n) return;                                                               // timing aid: staging only
+#endif
     const uint32_t hashable = (n >= 8) ? n - 7 : 0;
-    // candidate bits of the positions that can start a match; the word behind them reads as zero
-    {
-        const uint32_t words = (hashable + 63) >> 6;
-        for (uint32_t i = tid; i <= words; i += NW * 8) lm[i] = (i < words) ? distMask[i] : 0ull;
-    }
     __syncthreads();
+    WPROF_STAMP(0)
 
-    const uint32_t start = walker << WLOG;
-    const uint32_t blockStart = start & ~(ZS_BLOCK_MAX - 1);                     // the walker's block inside the unit
-    const uint32_t blockN = (blockStart < n) ? min(n - blockStart, ZS_BLOCK_MAX) : 0u;
-    const uint32_t blockEnd = blockStart + blockN;
-    const bool alive = (start < n) && (blockN >= 16);
-    const uint32_t end = min(start + WSIZE, n);
-    const uint32_t limit = min(end + ZS_CROSS_MAX, blockEnd);                     // matches end at or before this
-    const uint32_t scanEnd = alive ? min(end, hashable) : 0;
-
-    uint32_t ip = start, anchor = start, nseq = 0, mlSum = 0, rep0 = 0, rep1 = 0;
-    const uint32_t bit0 = 1u << sub, bit1 = 256u << sub;
-    for (;;) {
-        const bool run = ip < scanEnd;
-        if (!__any(run)) break;
-        const uint32_t wend = min(ip + ZS_WINDOW, scanEnd);
-        // ---- recent offsets: lane sub tries position ip + sub (ZS_REPWIN = 8 = the walker's lanes) ----
-        uint32_t rm0 = 0, rm1 = 0;                                               // bit i: rep0 / rep1 repeats 4 bytes at ip + i
-        {
-            const uint32_t q = ip + sub;
-            const bool in0 = run && q < wend && q + 4 <= limit;
-            const bool t0 = in0 && rep0 != 0 && q >= rep0, t1 = in0 && rep1 != 0 && q >= rep1;
-            uint32_t a[1], b[1], c[1];
-            lds_span<1>(ZS_WALK_FRONT + q, a);
-            lds_span<1>(ZS_WALK_FRONT + (t0 ? q - rep0 : q), b);
-            lds_span<1>(ZS_WALK_FRONT + (t1 ? q - rep1 : q), c);
-            // the walker's two bytes of flags: each lane's bit (1 << sub, 256 << sub) or-ed over its 8 lanes by three data-parallel moves
-            // (xor 1, xor 2 inside a quad, the mirrored lane of the other quad) -- a ballot cost two more extracts per flag
-            uint32_t v = ((t0 && a[0] == b[0]) ? bit0 : 0u) | ((t1 && a[0] == c[0]) ? bit1 : 0u);
-            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
-            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
-            v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, false);     // row_half_mirror: lane i <- lane 7 - i
-            rm0 = v & 0xFFu; rm1 = v >> 8;
-        }
-        // ---- window: candidate bits of [ip, ip + 64) from LDS (the same for the walker's 8 lanes) or'ed with the recent-offset
-        //      bits; lane sub takes the sub-th candidate position.  32-bit words: two funnel shifts give the window ----
-        uint32_t mlo = 0, mhi = 0;
-        if (run) {
-            const uint32_t *lw = reinterpret_cast<const uint32_t *>(lm) + (ip >> 5);
-            const uint32_t w0 = lw[0], w1 = lw[1], w2 = lw[2], sh = ip & 31u, wlen = wend - ip;
-            mlo = __builtin_amdgcn_alignbit(w1, w0, sh); mhi = __builtin_amdgcn_alignbit(w2, w1, sh);
-            const uint64_t keep = ~0ull >> (64u - wlen);                                    // 1 <= wlen <= 64 while run
-            mlo &= (uint32_t)keep; mhi &= (uint32_t)(keep >> 32);
-            mlo |= rm0 | rm1;
-        }
-        const uint32_t clo = (uint32_t)__popc(mlo);
-        const uint32_t ncand = min(clo + (uint32_t)__popc(mhi), (uint32_t)look);
-        const bool active = run && sub < ncand;
-        uint32_t idx = 0;
-        {   // position of the sub-th set bit
-            const bool upper = sub >= clo;
-            uint32_t mm = upper ? mhi : mlo; const uint32_t skip = upper ? sub - clo : sub;     // skip <= 7
-            // clear the lowest skip set bits, branch free: 4, 2, 1 of them by the bits of skip
-            { uint32_t t = mm & (mm - 1); t &= t - 1; t &= t - 1; t &= t - 1; mm = (skip & 4u) ? t : mm; }
-            { uint32_t t = mm & (mm - 1); t &= t - 1; mm = (skip & 2u) ? t : mm; }
-            { const uint32_t t = mm & (mm - 1); mm = (skip & 1u) ? t : mm; }
-            idx = mm ? (uint32_t)__builtin_ctz(mm) + (upper ? 32u : 0u) : 0u;
-        }
-        const uint32_t q = ip + idx;
-        const bool isR0 = active && idx < 8u && ((rm0 >> (idx & 7u)) & 1u) != 0, isR1 = active && !isR0 && idx < 8u && ((rm1 >> (idx & 7u)) & 1u) != 0;
-        const bool isRep = isR0 || isR1;
-        uint32_t off = isR0 ? rep0 : (isR1 ? rep1 : 0u);
-        if (active && !isRep) {
-            off = (uint32_t)dist[q];
-            if (BIG) off |= (((uint32_t)distHi[q >> 3] >> (q & 7u)) & 1u) << 16;
-        }
-        // ---- compare from LDS: 16 bytes forward, 8 bytes backward, both sides ----
-        uint32_t fwd = 0, back = 0;
-        int key = 0;
-        if (active) {
-            uint32_t a[6], b[6];                                                 // bytes [q - 8, q + 16) of both sides
-            lds_span<6>(ZS_WALK_FRONT + q - 8, a);
-            lds_span<6>(ZS_WALK_FRONT + q - off - 8, b);
-            const uint64_t xb = zs_u64(a[0] ^ b[0], a[1] ^ b[1]), x0 = zs_u64(a[2] ^ b[2], a[3] ^ b[3]), x1 = zs_u64(a[4] ^ b[4], a[5] ^ b[5]);
-            const uint32_t cap = min(limit - q, ZS_LCAP);
-            const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
-            const uint32_t n1 = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u;
-            fwd = min((n0 < 8u) ? n0 : 8u + n1, cap);
-            const uint32_t maxBack = min(min(q - anchor, q - off), ZS_BCAP);
-            back = min(xb ? ((uint32_t)__builtin_clzll(xb) >> 3) : 8u, maxBack);
-            if (fwd >= (isRep ? ZS_REPMIN : ZS_MINMATCH)) {
-                const int gain = (int)(min(fwd, ZS_FCAP) + back) * 4 - (isRep ? 0 : (int)zs_highbit(off + 1)) - 4 * ((int)(q - back) - (int)ip) - (int)(q - ip);
-                key = ((gain + 2048) << 3) | (int)(7u - sub);
-            }
-        }
-        // best candidate of the walker's 8 lanes, by data-parallel-primitive moves (xor 1, xor 2 inside a quad, then the mirrored
-        // lane of the other quad): a max over the keys, then two ds_bpermute reads of the winner's words
-        int best = key;
-        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0xB1, 0xF, 0xF, false));     // quad_perm [1,0,3,2]
-        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x4E, 0xF, 0xF, false));     // quad_perm [2,3,0,1]
-        best = max(best, __builtin_amdgcn_update_dpp(0, best, 0x141, 0xF, 0xF, false));    // row_half_mirror: lane i <- lane 7 - i
-        const uint32_t bl = (lane & ~7u) + (7u - (uint32_t)(best & 7));          // lane holding the best candidate
-        const uint32_t packed = (uint32_t)__shfl((int)(idx | (fwd << 8) | (back << 16)), (int)bl);
-        const uint32_t boff = (uint32_t)__shfl((int)off, (int)bl);
-        const uint32_t bq = ip + (packed & 0xFFu);
-        uint32_t bfwd = (packed >> 8) & 0xFFu;
-        const uint32_t bback = packed >> 16;
-        const bool took = run && best != 0;
-        // ---- long match: the walker's 8 lanes extend it, 128 bytes per round (LDS) ----
-        bool need = took && bfwd == ZS_LCAP && (limit - bq) > ZS_LCAP;
-        const bool extended = need;
-        uint32_t pos = bq + ZS_LCAP;
-        while (__any(need)) {
-            uint32_t nb = 0;
-            if (need) {
-                const uint32_t cap = limit - pos;          // pos < limit while need
-                const uint32_t fo = 16 * sub;
-                if (fo < cap) {
-                    uint32_t a[4], b[4];
-                    lds_span<4>(ZS_WALK_FRONT + pos + fo, a);
-                    lds_span<4>(ZS_WALK_FRONT + pos - boff + fo, b);
-                    const uint64_t x0 = zs_u64(a[0] ^ b[0], a[1] ^ b[1]), x1 = zs_u64(a[2] ^ b[2], a[3] ^ b[3]);
-                    const uint32_t n0 = x0 ? ((uint32_t)__builtin_ctzll(x0) >> 3) : 8u;
-                    const uint32_t n1 = x1 ? ((uint32_t)__builtin_ctzll(x1) >> 3) : 8u;
-                    nb = min((n0 < 8u) ? n0 : 8u + n1, cap - fo);
+    // ---- the walk ----
+    {
+        const uint32_t nRanges = (n + R - 1) >> rangeLog;
+        bool active = false, more = true;                                        // walking a range / the queue may hold more
+        uint32_t r = 0, ip = 0, anchor = 0, scanEnd = 0, limit = 0, rep0 = 0, rep1 = 0, nseq = 0, lastOff = 0, recBase = 0, blockBase = 0;
+        const uint32_t perBlockLog = 16u - rangeLog;                             // walk ranges per block
+        auto resIndex = [&](uint32_t rr) { return (rr >> perBlockLog) * ZS_RES_PER_BLOCK + (rr & ((1u << perBlockLog) - 1u)); };
+        // distances of the group (ip >> 3) + sub, requested as soon as ip is known: 16 bytes a lane straight into the lane's slot of the
+        // exchange buffer (LDS-DMA: no registers carried around the loop, no wait the compiler places for me; behind the hashable positions
+        // whatever the scratch holds: those bits are cut off the window).  BIG: bit 16 of the distances, a byte per group, by an ordinary load.
+        // (The load is an asm statement: hipcc counts a __builtin_amdgcn_global_load_lds and then waits vmcnt(0) in front of every LDS access it
+        // cannot tell apart from the destination; this one is waited for by hand: "s_waitcnt vmcnt(0)" at the top of the step and where a
+        // walker takes a new range.  M0 = LDS destination of lane 0, set inside the statement that uses it.)
+        typedef __attribute__((address_space(3))) uint4 *ZsLdsU4;
+        const uint32_t xwaveLds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(ZsLdsU4)(xbuf + (tid & ~63u)));
+        uint32_t gh = 0;
+        auto loadGroup = [&](uint32_t p) {
+            const uint32_t g = (p >> 3) + sub;
+            const uint16_t *gsrc = dist + (size_t)g * 8u;
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(xwaveLds) : "memory");
+            if (BIG) gh = (uint32_t)distHi[g];
+        };
+        for (;;) {
+            if (__any(!active && more)) {
+                // idle walkers take the next ranges of the queue: one LDS atomic per wavefront
+                const uint64_t idle = __ballot(!active && more && sub == 0);
+                uint32_t base = 0;
+                if (lane == 0) base = atomicAdd(queue, (uint32_t)__popcll(idle));
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                if (!active && more) {
+                    const uint32_t leader = lane & ~(LPW - 1u);
+                    r = base + (uint32_t)__popcll(idle & ((1ull << leader) - 1ull));
+                    if (r >= nRanges) more = false;
+                    else {
+                        const uint32_t start = r << rangeLog;
+                        const uint32_t blockStart = start & ~(ZS_BLOCK_MAX - 1);     // the range's block inside the unit
+                        const uint32_t blockEnd = blockStart + min(n - blockStart, ZS_BLOCK_MAX);
+                        const uint32_t end = min(start + R, blockEnd);
+                        limit = min(end + ZS_CROSS_MAX, blockEnd);               // matches end at or before this
+                        scanEnd = (blockEnd - blockStart >= 16) ? min(end, hashable) : 0;
+                        ip = start; anchor = start; rep0 = 0; rep1 = 0; nseq = 0; lastOff = 0; recBase = start >> 2; blockBase = blockStart;
+                        active = ip < scanEnd;
+                        if (!active && sub == 0) res[resIndex(r)] = make_uint4(0, 0, 0, 0);    // nothing to scan
+                        if (active) { loadGroup(ip); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }    // (its first group: nothing to overlap it with)
+                    }
                 }
             }
-            const uint64_t stopm = __ballot(nb < 16u);
-            const uint32_t g8 = __builtin_amdgcn_ubfe((grp & 4u) ? (uint32_t)(stopm >> 32) : (uint32_t)stopm, 8u * (grp & 3u), 8u);
-            const uint32_t f = g8 ? (uint32_t)__builtin_ctz(g8) : 0u;
-            const uint32_t part = (uint32_t)__shfl((int)nb, (int)((lane & ~7u) + f));
-            if (need) {
-                if (g8) { pos += 16 * f + part; need = false; }
-                else { pos += 128; if (pos >= limit) { pos = limit; need = false; } }
+            if (!__any(active)) { if (!__any(more)) break; continue; }
+            WPROF_STAMP(1)
+#ifdef ZS_WALK_PROFILE
+            wprof[8] += 1; wprof[9] += (unsigned long long)__popcll(__ballot(active));
+#endif
+            const uint32_t wend = min((ip & ~7u) + 8u * LPW, scanEnd);            // the walker's LPW groups
+            // ---- recent offsets: the walker's lanes try RPL positions each ----
+            uint32_t rm0 = 0, rm1 = 0;                                           // bit i: rep0 / rep1 repeats 4 bytes at ip + i
+            {
+                const bool t0 = active && rep0 != 0 && ip >= rep0, t1 = active && rep1 != 0 && ip >= rep1;
+                const uint32_t p0 = ip + sub * RPL;
+                constexpr int SP = (RPL + 3 + 3) / 4;                            // dwords that hold RPL + 3 bytes
+                uint32_t a[SP], b[SP], c[SP];
+                lds_span<SP>(SRC + p0, a);
+                lds_span<SP>(SRC + (t0 ? p0 - rep0 : p0), b);
+                lds_span<SP>(SRC + (t1 ? p0 - rep1 : p0), c);
+                auto tryAt = [&](auto iTag) {
+                    constexpr int I = decltype(iTag)::value;
+                    const uint32_t q = p0 + I;
+                    const bool ok = q < wend && q + 4 <= limit;
+                    const uint32_t av = span_at<I>(a);
+                    if (t0 && ok && av == span_at<I>(b)) rm0 |= 1u << (sub * RPL + I);
+                    if (t1 && ok && av == span_at<I>(c)) rm1 |= 1u << (sub * RPL + I);
+                };
+                tryAt(std::integral_constant<int, 0>{});
+                if constexpr (RPL >= 2) tryAt(std::integral_constant<int, 1>{});
+                if constexpr (RPL >= 4) { tryAt(std::integral_constant<int, 2>{}); tryAt(std::integral_constant<int, 3>{}); }
+                rm0 = walker_or<LPW>(rm0); rm1 = walker_or<LPW>(rm1);
+                rm1 &= ~rm0;                                                     // rep0 is tried first
             }
+            WPROF_STAMP(2)
+            // ---- the window: the walker's four groups of distances are in the exchange buffer (requested a step ago); my group's candidate bits, the four groups' side by side ----
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const uint4 gd = xbuf[tid];
+            if (BIG) xhi[tid] = (uint8_t)gh;
+            uint32_t m = walker_or<LPW>((zs_nonzero8(gd) | gh) << (8u * sub)) >> (ip & 7u);            // bit i: position ip + i has a candidate
+            if (active) m = (m & (0xFFFFFFFFu >> (32u - (wend - ip)))) | rm0 | rm1; else m = 0;   // 1 <= wend - ip <= 8 LPW while active
+            {                                                                    // lane sub takes the candidates sub * CPL ..: clear the lower ones
+                const uint32_t skip = sub * CPL;
+                if constexpr ((LPW - 1) * CPL >= 4) { uint32_t t = m & (m - 1); t &= t - 1; t &= t - 1; t &= t - 1; m = (skip & 4u) ? t : m; }
+                if constexpr ((((LPW - 1) * CPL) & 2) != 0 || (LPW == 4 && CPL == 2)) { uint32_t t = m & (m - 1); t &= t - 1; m = (skip & 2u) ? t : m; }
+                if constexpr ((CPL & 1) != 0) { const uint32_t t = m & (m - 1); m = (skip & 1u) ? t : m; }
+            }
+            uint32_t idx[CPL], off[CPL]; bool have[CPL], isRep[CPL];
+            #pragma unroll
+            for (uint32_t c = 0; c < CPL; c++) {
+                have[c] = m != 0;
+                idx[c] = have[c] ? (uint32_t)__builtin_ctz(m) : 0u;
+                m &= m - 1;
+                const uint32_t q = ip + idx[c];
+                const bool r0 = ((rm0 >> idx[c]) & 1u) != 0, r1 = ((rm1 >> idx[c]) & 1u) != 0;
+                isRep[c] = have[c] && (r0 || r1);
+                // the distance: group (q >> 3) - (ip >> 3) of the walker, that lane's slot of the exchange buffer (same wavefront: in order behind the stores above)
+                const uint32_t owner = (tid & ~(LPW - 1u)) + ((q >> 3) - (ip >> 3));
+                uint32_t d = reinterpret_cast<const uint16_t *>(xbuf + owner)[q & 7u];
+                if (BIG) d |= (((uint32_t)xhi[owner] >> (q & 7u)) & 1u) << 16;
+                off[c] = r0 ? rep0 : (r1 ? rep1 : d);
+                if (!have[c]) off[c] = 0;
+            }
+            WPROF_STAMP(3)
+            // ---- score: 8 bytes forward, 4 bytes backward, from LDS ----
+            int bestKey = 0; uint32_t bestPack = 0, bestOff = 0;
+            #pragma unroll
+            for (uint32_t c = 0; c < CPL; c++) {
+                const uint32_t q = ip + idx[c];
+                uint32_t a[3], b[3];                                             // bytes [q - 4, q + 8) of both sides
+                lds_span<3>(SRC + q - 4, a);
+                lds_span<3>(SRC + q - off[c] - 4, b);
+                const uint32_t xb = a[0] ^ b[0], x0 = a[1] ^ b[1], x1 = a[2] ^ b[2];
+                const uint32_t f0 = x0 ? (uint32_t)__builtin_ctz(x0) : 32u, f1 = x1 ? (uint32_t)__builtin_ctz(x1) : 32u;
+                const uint32_t fwd = min(((x0 ? f0 : 32u + f1)) >> 3, limit - q);
+                const uint32_t maxBack = min(min(q - anchor, q - off[c]), ZS_BCAP);
+                const uint32_t back = min(xb ? ((uint32_t)__builtin_clz(xb) >> 3) : 4u, maxBack);
+                if (have[c] && fwd >= (isRep[c] ? ZS_REPMIN : ZS_MINMATCH)) {
+                    const int gain = (int)(4u * fwd + 8u * back) - (isRep[c] ? 0 : (int)zs_highbit(off[c] + 1)) - 5 * (int)idx[c];
+                    const int key = ((gain + 2048) << 3) | (int)(7u - (sub * CPL + c));
+                    if (key > bestKey) { bestKey = key; bestPack = idx[c] | (fwd << 8) | (back << 16); bestOff = off[c]; }
+                }
+            }
+            const int best = walker_max<LPW>(bestKey);
+            const bool took = active && best != 0;
+            const uint32_t packed = walker_or<LPW>(bestKey == best ? bestPack : 0u), boff = walker_or<LPW>(bestKey == best ? bestOff : 0u);
+            const uint32_t bq = ip + (packed & 0xFFu), bback = packed >> 16;
+            uint32_t bfwd = (packed >> 8) & 0xFFu;
+            WPROF_STAMP(4)
+            // ---- the match's whole length: the walker's lanes compare on, 16 bytes a lane and round ----
+            const bool extend = took && bfwd == ZS_FCAP && (limit - bq) > ZS_FCAP;
+            bool need = extend;
+            uint32_t pos = bq + ZS_FCAP;
+            while (__any(need)) {
+                uint32_t e = 0xFFFFFFFFu;                                        // bytes gained if the match ends in this lane's piece
+                if (need) {
+                    const uint32_t cap = limit - pos, fo = 16u * sub;            // cap >= 1 while need
+                    uint32_t nb = 0;
+                    if (fo < cap) {
+                        uint32_t a[4], b[4];
+                        lds_span<4>(SRC + pos + fo, a);
+                        lds_span<4>(SRC + pos - boff + fo, b);
+                        nb = zs_agree16(a, b);
+                    }
+                    if (nb < 16u || fo + 16u >= cap) e = min(fo + nb, cap);
+                }
+                e = walker_min<LPW>(e);
+                if (need) {
+                    if (e != 0xFFFFFFFFu) { pos += e; need = false; }
+                    else pos += 16u * LPW;
+                }
+            }
+            if (extend) bfwd = pos - bq;
+            WPROF_STAMP(5)
+            uint32_t recLl = 0;
+            if (took) {
+                recLl = bq - bback - anchor;                                     // literals in front of the match, inside the range (< R <= 512)
+                nseq++; lastOff = boff;
+                ip = bq + bfwd; anchor = ip;
+                if (boff == rep1) { rep1 = rep0; rep0 = boff; }
+                else if (boff != rep0) { rep1 = rep0; rep0 = boff; }
+            } else if (active) ip = wend;
+            // the record leaves (the walker's first lane, a step that took a match); the next step's distances are requested (walkers with a
+            // step to come): the memory system takes a wavefront's small requests one by one, and the kernel's time follows their number
+            // (every lane loading and storing every step, walkers at rest included: 4 requests a walker step, 0.95 ms; profiles/r3_walk_*)
+            if (took && sub == 0) recs[recBase + nseq - 1] = make_uint2((bq - bback - blockBase) | ((bback + bfwd) << 17), boff | (recLl << 17));    // start: position in its block; offset, literals
+            if (active && ip >= scanEnd) {
+                if (sub == 0) res[resIndex(r)] = make_uint4(nseq, nseq ? anchor - blockBase : 0u, lastOff, 0u);
+                active = false;
+            }
+            if (active) loadGroup(ip);
+            WPROF_STAMP(6)
         }
-        if (extended) bfwd = pos - bq;
-        if (took) {
-            const uint32_t mstart = bq - bback, ml = bback + bfwd;
-            if (sub == 0) { ZsSeqRec r; r.x = zs_rec_x(mstart - anchor, ml, boff); r.y = zs_rec_y(boff, mstart - blockStart); seqs[nseq] = r; }
-            nseq++; mlSum += ml;
-            ip = bq + bfwd; anchor = ip;
-            if (boff == rep1) { rep1 = rep0; rep0 = boff; }
-            else if (boff != rep0) { rep1 = rep0; rep0 = boff; }
-        } else if (run) ip = wend;
     }
-    if (sub == 0) res[walker] = make_uint4(nseq, nseq ? anchor : 0u, mlSum, 0u);
+    WPROF_STAMP(1)
+#ifdef ZS_WALK_PROFILE
     __syncthreads();
+    if (lane == 0) { unsigned long long *o = reinterpret_cast<unsigned long long *>(resAll + (size_t)(junkSlot / 64)) + ((size_t)blockIdx.x * (NT / 64) + (tid >> 6)) * 10;   /* behind all blocks' results */ for (int k = 0; k < 10; k++) o[k] = wprof[k]; }
+#endif
+}
 
-    // ---- the stitch: wavefront b takes block b of the unit, lane r its walk range r ----
-    if (wave < (BIG ? 2u : 1u)) {
-        const uint32_t bStart = wave * ZS_BLOCK_MAX;
-        const uint32_t bN = (bStart < n) ? min(n - bStart, ZS_BLOCK_MAX) : 0u;
-        const uint32_t bEnd = bStart + bN;
-        const uint32_t rg = wave * 64 + lane;                                     // range index in the unit
-        const uint4 rr = res[rg];
+// ---------------------------------------------------------------------------------------------
+// k_lz_stitch : one workgroup of 256 threads per block, thread t = walk range t of the block (parseBlock in oracle/zso_encoder.c):
+// the stitch of the ranges' records and their packing into the entropy kernels' layout (see k_lz_walk).  A kernel of its own: these
+// are chains of dependent loads with little arithmetic, which many small workgroups per CU overlap, while inside k_lz_walk they held
+// 64 KiB of LDS and 8 wavefronts for a sixth of that kernel's time.
+// ---------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_lz_stitch(const ZsBlockDesc *__restrict__ blocks, const uint2 *__restrict__ recAll, const uint4 *__restrict__ resAll,
+            ZsSeqRec *__restrict__ seqAll, ZsRangeHdr *__restrict__ hdrAll, int rangeLogArg)
+{
+    constexpr int NT = 256;
+    __shared__ uint32_t sa[9 * 256 + 16];
+    uint32_t *sKept = sa, *sCnt = sa + 256, *sTrail = sa + 512, *sFOut = sa + 768, *sNs = sa + 1024, *sOwn = sa + 1280, *sEs = sa + 1536, *sPend = sa + 1792, *sChain = sa + 2048, *sWave = sa + 2304;
+    const uint32_t tid = threadIdx.x, lane = tid & 63u;
+    const uint32_t rangeLog = (uint32_t)rangeLogArg, R = 1u << rangeLog;
+    const uint32_t slot = blockIdx.x;
+    const uint32_t NRB = ZS_BLOCK_MAX >> rangeLog;                               // walk ranges per block
+    const uint32_t gLog = ZS_OUT_LOG - rangeLog, G = 1u << gLog;                 // walk ranges per output range
+    const uint2 *recs = recAll + (size_t)slot * (ZS_BLOCK_MAX / 4);
+    const uint4 *res = resAll + (size_t)slot * ZS_RES_PER_BLOCK;
+    {
+        const uint32_t bStart = 0, bi = 0;
+        const uint32_t bN = blocks[slot].size;
+        const uint32_t bEnd = bN;
+        const uint32_t t = tid;
+        const bool mine = t < NRB;
+        const bool walked = mine && bN >= 16 && (t << rangeLog) < bN;            // (ranges of a block too small to compress, or behind its end, leave no result)
+        const uint4 rr = walked ? res[t] : make_uint4(0, 0, 0, 0);
         const uint32_t ns = rr.x, le = rr.y;
-        uint32_t sumMl = rr.z;
-        // reach before me: maximum of the earlier ranges' last match ends (and the block start)
-        uint32_t incl = max(le, bStart);
-        #pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const uint32_t o = (uint32_t)__shfl_up((int)incl, d); if ((int)lane >= d) incl = max(incl, o); }
-        uint32_t own = (uint32_t)__shfl_up((int)incl, 1); if (lane == 0) own = bStart;
-        const uint32_t reach = incl;
-        const uint32_t rs = min(rg << WLOG, bEnd), re = min((rg << WLOG) + WSIZE, bEnd);   // the range, cut at the block end
-        const uint32_t es = max(rs, own), te = max(re, reach);
-        ZsSeqRec *recs = seqAll + (size_t)slot * (ZS_BLOCK_MAX / 4) + (size_t)rg * (WSIZE / 4);
-        uint32_t f = 0;
-        if (ns && own > rs) {
-            while (f < ns) {
-                const ZsSeqRec r = recs[f];
-                const uint32_t st = zs_rec_pos(r.y) + bStart, ml = zs_rec_ml(r.x), off = zs_rec_off(r.x, r.y);
-                if (st + ml <= own) { sumMl -= ml; f++; continue; }              // covered by an earlier range's match
-                if (st < own) {                                                  // straddles: the front goes
-                    const uint32_t left = st + ml - own;
-                    if (left < ZS_MINMATCH) { sumMl -= ml; f++; continue; }
-                    ZsSeqRec w; w.x = zs_rec_x(0, left, off); w.y = zs_rec_y(off, own - bStart); recs[f] = w;
-                    sumMl -= ml - left;
-                } else { ZsSeqRec w; w.x = zs_rec_x(st - es, ml, off); w.y = r.y; recs[f] = w; }   // first kept one: its literals count from es
-                break;
+        const uint32_t rs = min(bStart + (t << rangeLog), bEnd), re = min(bStart + (t << rangeLog) + R, bEnd);   // the range, cut at the block end
+        const uint2 *rp = recs + ((bStart + (t << rangeLog)) >> 2);
+        // reach before me / with me: maximum of the ranges' last match ends; the low bits name the range that holds it (the earliest of equals)
+        uint32_t total;
+        const uint32_t key = ns ? ((le << 9) | (511u - t)) : 0u;
+        const uint32_t incl = block_scan_max<NT, 1>(key, sWave, tid, &total);
+        uint32_t excl = (uint32_t)__shfl_up((int)incl, 1);
+        if (lane == 0) { excl = 0; for (uint32_t k = 0; k < (tid >> 6); k++) excl = max(excl, sWave[k]); }
+        const uint32_t own = max(excl >> 9, bStart), reach = max(incl >> 9, bStart), reachAll = max(total >> 9, bStart);
+        const uint32_t definer = 511u - (excl & 511u);                           // valid if excl != 0
+#if defined(ZS_STITCH_STOP) && ZS_STITCH_STOP == 2
+        if (bN) return;                                                          // timing aid: the first scan only
+#endif
+        // first record that counts: records end in ascending order
+        uint32_t f = 0, fStart = 0, fEnd = 0, fOff = 0;
+        if (ns && own >= rs) {
+            if (le <= own) f = ns;
+            else {
+                uint32_t lo = 0, hi = ns - 1;                                    // the first record that ends above own is in [lo, hi]
+                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; const uint32_t x = rp[mid].x; if ((x & 0x1FFFFu) + (x >> 17) > own) hi = mid; else lo = mid + 1; }
+                f = lo;
+                uint2 rec = rp[f];
+                uint32_t st = rec.x & 0x1FFFFu, en = st + (rec.x >> 17);
+                if (st < own && en - own < ZS_MINMATCH) { f++; if (f < ns) { rec = rp[f]; st = rec.x & 0x1FFFFu; en = st + (rec.x >> 17); } }   // too little left of a straddling one (the next starts above own)
+                fStart = max(st, own); fEnd = en; fOff = rec.y & 0x1FFFFu;
             }
         }
-        const uint32_t kept = ns - f;
-        const uint32_t lastEnd = kept ? le : es;
-        ZsRangeHdr h; h.nseq = kept; h.first = f; h.trailing = te - lastEnd; h.litSum = (lastEnd - es) - sumMl;
-        hdrAll[(size_t)slot * ZS_WALK_RANGES + rg] = h;
+        const bool keptAny = f < ns;
+        if (mine) sKept[t] = keptAny;
+        __syncthreads();
+        // joined to the match that defines the reach: starts there, same offset, and that match (its range's last record) counts itself
+        const bool joined = keptAny && excl != 0 && own >= rs && fStart == own && fOff == res[definer].z && sKept[definer] != 0;
+        const uint32_t fOut = f + (joined ? 1u : 0u), cnt = ns - fOut;
+        const uint32_t es = joined ? fEnd : max(rs, own), te = max(re, reach), lastEnd = cnt ? le : es;
+        // what was joined to my last record: the nearest range behind me that ends a chain says where (one that only passes a chain on does not)
+        const bool stopper = ns && le > own && !(joined && cnt == 0);
+        uint32_t total2;
+        const uint32_t key2 = stopper ? (((512u - t) << 18) | (joined ? fEnd : own)) : 0u;
+        const uint32_t sfx = block_scan_max<NT, -1>(key2, sWave, tid, &total2);
+        uint32_t sfxEx = (uint32_t)__shfl_down((int)sfx, 1);
+        if (lane == 63) { sfxEx = 0; for (uint32_t k = (tid >> 6) + 1; k < NT / 64; k++) sfxEx = max(sfxEx, sWave[k]); }
+        const uint32_t chainEnd = sfxEx ? (sfxEx & 0x3FFFFu) : reachAll;
+        if (mine) { sCnt[t] = cnt; sTrail[t] = te - lastEnd; sFOut[t] = fOut; sNs[t] = ns; sOwn[t] = own; sEs[t] = es; sChain[t] = chainEnd; }
+        __syncthreads();
+        const uint32_t gi = t & (G - 1u);
+        if (mine) {                                                              // literals left over in front of my territory, inside my output range
+            uint32_t pend = 0;
+            for (uint32_t i = gi; i > 0; i--) { pend += sTrail[t - gi + i - 1]; if (sCnt[t - gi + i - 1]) break; }
+            sPend[t] = pend;
+        }
+        __syncthreads();
+#if defined(ZS_STITCH_STOP) && ZS_STITCH_STOP == 1
+        if (bN) return;                                                          // timing aid: no packing
+#endif
+        // pack, a lane a record: wavefront w takes the output ranges 16 w .. 16 w + 15 in turn; lane d of a round the d-th record of the output
+        // range = record fOut + (d - records of the walk ranges before) of its walk range: loads of consecutive lanes run along a walk range's
+        // slots, stores along the output range's.  (A thread packing its own range's records one by one - 8 scattered bytes a lane and
+        // store - took 0.26 ms of this kernel's 0.32: the stores queued at issue.)
+        const uint32_t wave = tid >> 6;
+        for (uint32_t go = 0; go < ZS_WALK_RANGES / (NT / 64); go++) {
+            const uint32_t g = wave * (ZS_WALK_RANGES / (NT / 64)) + go, j0 = g << gLog;
+            uint32_t c[4] = { 0, 0, 0, 0 }, total = 0;
+            for (uint32_t i = 0; i < G; i++) { c[i] = sCnt[j0 + i]; total += c[i]; }
+            ZsSeqRec *out = seqAll + ((size_t)slot * ZS_WALK_RANGES + g) * ZS_SEQ_PER_RANGE;
+            uint32_t lits = 0;
+            for (uint32_t d0 = 0; d0 < total; d0 += 64) {
+                const uint32_t d = d0 + lane;
+                if (d < total) {
+                    uint32_t j = 0, pre = 0;
+                    if (d >= c[0]) { j = 1; pre = c[0]; if (G > 2) { if (d >= pre + c[1]) { j = 2; pre += c[1]; if (d >= pre + c[2]) { j = 3; pre += c[2]; } } } }
+                    const uint32_t jr = j0 + j, k = sFOut[jr] + (d - pre);
+                    const uint2 rec = recs[(jr << (rangeLog - 2)) + k];
+                    uint32_t st = rec.x & 0x1FFFFu, ml = rec.x >> 17, ll = rec.y >> 17;
+                    const uint32_t off = rec.y & 0x1FFFFu, en = st + ml;
+                    if (d == pre) {                                              // the walk range's first record that counts: a straddling one is cut; its literals start at the territory
+                        const uint32_t ownj = sOwn[jr];
+                        if (st < ownj) { st = ownj; ml = en - st; }
+                        ll = st - sEs[jr] + sPend[jr];
+                    }
+                    if (k + 1 == sNs[jr]) ml = sChain[jr] - st;                  // its last: with what was joined to it
+                    ZsSeqRec w; w.x = zs_rec_x(ll, ml, off); w.y = zs_rec_y(off, st);
+                    out[d] = w;
+                    lits += ll;
+                }
+            }
+            #pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) lits += (uint32_t)__shfl_xor((int)lits, o);
+            if (lane == 0) {
+                ZsRangeHdr h; h.nseq = total; h.litSum = lits; h.trailing = 0; h.first = 0;
+                for (uint32_t i = G; i > 0; i--) { h.trailing += sTrail[j0 + i - 1]; if (sCnt[j0 + i - 1]) break; }
+                hdrAll[(size_t)slot * ZS_WALK_RANGES + g] = h;
+            }
+        }
     }
 }

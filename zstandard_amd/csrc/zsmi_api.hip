@@ -118,10 +118,11 @@ struct zsmi_ctx {
     uint32_t maxBlocksInFlight = 16384;   // ZSMI_BLOCKS_IN_FLIGHT: 64 KiB blocks per sub-batch (scratch ~0.6 MiB a block, reserved for what a call needs); 2 GiB of 128 KiB chunks: 8192: 86.5, 16384: 88.2, 32768: 89.4 GiB/s
     // compress workspace: plan (shared) + one scratch set per internal stream ("lane")
     DevBuf dBlocks, dChunks, dUnits;     // dUnits: small units (<= 64 KiB) first, then big ones, each in chunk order
-    struct Scratch { DevBuf dDist, dDistHi, dDistMask, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
+    struct Scratch { DevBuf dDist, dDistHi, dDistMask, dRecs, dRes, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
     static const int kMaxLanes = 8;
     Scratch lanes[kMaxLanes];
     int nLanes = 1;
+    int stopAfterWalk = 0;                 // ZSMI_STOP_AFTER_WALK (debug-hooks build, tools/walk_check.py): the entropy kernels are not launched
     int stopLit = 0, stopSeq = 0;          // timing aids of a -DZSMI_DEBUG_HOOKS build (ZSMI_STOP_LIT / ZSMI_STOP_SEQ): end a kernel after a stage; always 0 in the product
     hipEvent_t evStart = nullptr;
     PinBuf hBlocks, hChunks, hUnits;
@@ -176,12 +177,14 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
         ok &= hipFuncSetAttribute((const void *)k_lz_candidates<ZS_TABLE_LOG_SMALL, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZS_CAND_LDS(ZS_TABLE_LOG_SMALL, 2)) == hipSuccess;
         ok &= hipFuncSetAttribute((const void *)k_lz_candidates<ZS_TABLE_LOG_BIG, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZS_CAND_LDS(ZS_TABLE_LOG_BIG, 1)) == hipSuccess;
         ok &= hipFuncSetAttribute((const void *)k_lz_candidates<ZS_TABLE_LOG_BIG, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ZS_CAND_LDS(ZS_TABLE_LOG_BIG, 2)) == hipSuccess;
-        ok &= hipFuncSetAttribute((const void *)k_lz_walk<64>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_BLOCK_MAX)) == hipSuccess;
-        ok &= hipFuncSetAttribute((const void *)k_lz_walk<128>, hipFuncAttributeMaxDynamicSharedMemorySize, ZS_WALK_LDS(ZS_UNIT_MAX)) == hipSuccess;
         // k_lz_walk addresses its (dynamic) LDS from 0: that holds as long as the kernel has no static LDS in front of it
-        hipFuncAttributes fa;
-        ok &= hipFuncGetAttributes(&fa, (const void *)k_lz_walk<64>) == hipSuccess && fa.sharedSizeBytes == 0;
-        ok &= hipFuncGetAttributes(&fa, (const void *)k_lz_walk<128>) == hipSuccess && fa.sharedSizeBytes == 0;
+        auto walkOk = [](const void *fn, size_t lds) {
+            hipFuncAttributes fa;
+            return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess && hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.sharedSizeBytes == 0;
+        };
+        ok &= walkOk((const void *)ZS_WALK_KERNEL(4, 8, false), ZS_WALK_LDS(ZS_BLOCK_MAX)) && walkOk((const void *)ZS_WALK_KERNEL(4, 8, true), ZS_WALK_LDS(ZS_UNIT_MAX));
+        ok &= walkOk((const void *)ZS_WALK_KERNEL(4, 4, false), ZS_WALK_LDS(ZS_BLOCK_MAX)) && walkOk((const void *)ZS_WALK_KERNEL(4, 4, true), ZS_WALK_LDS(ZS_UNIT_MAX));
+        ok &= walkOk((const void *)ZS_WALK_KERNEL(8, 8, false), ZS_WALK_LDS(ZS_BLOCK_MAX)) && walkOk((const void *)ZS_WALK_KERNEL(8, 8, true), ZS_WALK_LDS(ZS_UNIT_MAX));
         if (!ok) { (void)hipGetLastError(); if (c->ownStream) (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
     }
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
@@ -189,6 +192,7 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     if (const char *e = getenv("ZSMI_ITEMS_IN_FLIGHT")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->maxItemsInFlight = (uint32_t)v; }
 #ifdef ZSMI_DEBUG_HOOKS
     if (const char *e = getenv("ZSMI_STOP_LIT")) c->stopLit = atoi(e);
+    if (const char *e = getenv("ZSMI_STOP_AFTER_WALK")) c->stopAfterWalk = atoi(e);
     if (const char *e = getenv("ZSMI_STOP_SEQ")) c->stopSeq = atoi(e);
 #endif
     if (const char *e = getenv("ZSMI_LANES")) { long v = atol(e); if (v >= 1 && v <= zsmi_ctx::kMaxLanes) c->nLanes = (int)v; }
@@ -208,7 +212,7 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
     for (int i = 0; i < zsmi_ctx::kMaxLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
         if (L.stream) (void)hipStreamSynchronize(L.stream);
-        for (DevBuf *b : { &L.dDist, &L.dDistHi, &L.dDistMask, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dLitSec, &L.dSeqSec, &L.dMetas }) b->release();
+        for (DevBuf *b : { &L.dDist, &L.dDistHi, &L.dDistMask, &L.dRecs, &L.dRes, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dLitSec, &L.dSeqSec, &L.dMetas }) b->release();
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
@@ -259,8 +263,10 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
     if (!c) return ZSMI_error_init_missing;
     if (n == 0) return 0;
     if (hipSetDevice(c->device) != hipSuccess) return ZSMI_error_GENERIC;
-    const int look = level <= 2 ? 4 : 8;             // level <= 2: short table only ("fast"); level >= 3: short + long table ("double")
+    // level <= 2: short table only ("fast"), walk ranges of 512 bytes; level >= 3: short + long table ("double"), ranges of 256 bytes;
+    // level >= 4 scores 8 candidates a step instead of 4 (paramsForLevel in oracle/zso_encoder.c)
     const bool useLong = level >= 3;
+    const int walkLog = level <= 2 ? 9 : 8;
     // plan: chunks -> blocks.  The device-side plan is reused when the chunk layout repeats (steady-state batches).
     std::vector<uint64_t> key((size_t)n * 3 + 1);
     key[0] = n;
@@ -320,7 +326,7 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
     if (cap < maxChunkBlocks) cap = maxChunkBlocks;
     for (int i = 0; i < nLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
-        if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2 + 256) || !L.dDistHi.reserve((size_t)cap * (ZS_BLOCK_MAX / 8) + 256) || !L.dDistMask.reserve((size_t)cap * (ZS_BLOCK_MAX / 8) + 256) || !L.dSeqs.reserve((size_t)cap * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
+        if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2 + 256) || !L.dDistHi.reserve((size_t)cap * (ZS_BLOCK_MAX / 8) + 256) || !L.dDistMask.reserve((size_t)cap * (ZS_BLOCK_MAX / 8) + 256) || !L.dRecs.reserve(((size_t)cap * (ZS_BLOCK_MAX / 4) + 64) * sizeof(uint2)) || !L.dRes.reserve((size_t)cap * ZS_RES_PER_BLOCK * sizeof(uint4) + ((size_t)8 << 20)) || !L.dSeqs.reserve((size_t)cap * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
             !L.dHdrs.reserve((size_t)cap * ZS_WALK_RANGES * sizeof(ZsRangeHdr)) || !L.dLits.reserve((size_t)cap * (ZS_BLOCK_MAX + 64)) ||
             !L.dStreams.reserve((size_t)cap * 4 * ZS_STREAM_STRIDE) || !L.dLitSec.reserve((size_t)cap * ZS_LITSEC_STRIDE) ||
             !L.dSeqSec.reserve((size_t)cap * ZS_SEQSEC_STRIDE) || !L.dMetas.reserve((size_t)cap * sizeof(ZsBlockMeta))) return ZSMI_error_memory_allocation;
@@ -343,10 +349,13 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         if (ns) { if (useLong) CAND_LAUNCH("k_lz_candidates", ZS_TABLE_LOG_SMALL, 2, ns, dUS); else CAND_LAUNCH("k_lz_candidates", ZS_TABLE_LOG_SMALL, 1, ns, dUS); }
         if (nbig) { if (useLong) CAND_LAUNCH("k_lz_candidates_big", ZS_TABLE_LOG_BIG, 2, nbig, dUB); else CAND_LAUNCH("k_lz_candidates_big", ZS_TABLE_LOG_BIG, 1, nbig, dUB); }
         #undef CAND_LAUNCH
-        if (ns) LAUNCH_ON(c, st, "k_lz_walk", (k_lz_walk<64>), dim3(ns), dim3(512), ZS_WALK_LDS(ZS_BLOCK_MAX), (const uint8_t *)dSrc, dUS, block0, (const uint16_t *)L.dDist.p,
-                          (const uint8_t *)L.dDistHi.p, (const uint8_t *)L.dDistMask.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
-        if (nbig) LAUNCH_ON(c, st, "k_lz_walk_big", (k_lz_walk<128>), dim3(nbig), dim3(1024), ZS_WALK_LDS(ZS_UNIT_MAX), (const uint8_t *)dSrc, dUB, block0, (const uint16_t *)L.dDist.p,
-                            (const uint8_t *)L.dDistHi.p, (const uint8_t *)L.dDistMask.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, look);
+        #define WALK_LAUNCH(name, LOOK, REPW, BIG, cnt, du) LAUNCH_ON(c, st, name, (ZS_WALK_KERNEL(LOOK, REPW, BIG)), dim3(cnt), dim3((BIG) ? ZS_WALK_NT_BIG : ZS_WALK_NT), ZS_WALK_LDS((BIG) ? ZS_UNIT_MAX : ZS_BLOCK_MAX), \
+                          (const uint8_t *)dSrc, du, block0, (const uint16_t *)L.dDist.p, (const uint8_t *)L.dDistHi.p, (uint2 *)L.dRecs.p, cap * (ZS_BLOCK_MAX / 4), (uint4 *)L.dRes.p, walkLog)
+        if (ns) { if (level <= 2) WALK_LAUNCH("k_lz_walk", 4, 8, false, ns, dUS); else if (level == 3) WALK_LAUNCH("k_lz_walk", 4, 4, false, ns, dUS); else WALK_LAUNCH("k_lz_walk", 8, 8, false, ns, dUS); }
+        if (nbig) { if (level <= 2) WALK_LAUNCH("k_lz_walk_big", 4, 8, true, nbig, dUB); else if (level == 3) WALK_LAUNCH("k_lz_walk_big", 4, 4, true, nbig, dUB); else WALK_LAUNCH("k_lz_walk_big", 8, 8, true, nbig, dUB); }
+        #undef WALK_LAUNCH
+        LAUNCH_ON(c, st, "k_lz_stitch", k_lz_stitch, dim3(nb), dim3(256), 0, dB, (const uint2 *)L.dRecs.p, (const uint4 *)L.dRes.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, walkLog);
+        if (c->stopAfterWalk) { chunk0 = chunk1; continue; }
         // sequences first: the literals kernel assembles the frames of one-block chunks as its workgroups finish, and reads the sequence
         // sections then.  (The two side by side on two streams was measured slower: both want the whole LDS.)
         LAUNCH_ON(c, st, "k_encode_sequences", (k_encode_sequences<ZS_SEQ_GROUP>), dim3((nb + ZS_SEQ_GROUP - 1) / ZS_SEQ_GROUP), dim3(64 * ZS_SEQ_GROUP), 0, dB, nb, (ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
@@ -649,7 +658,7 @@ extern "C" int zsmi_dbg_copyScratch(zsmi_ctx *c, int which, void *hostDst, size_
     if (!c) return -1;
     (void)hipStreamSynchronize(c->stream);
     zsmi_ctx::Scratch &L0 = c->lanes[0];
-    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : which == 4 ? &L0.dDistHi : which == 6 ? &L0.dDistMask : which == 5 ? &c->dLitScratch : &L0.dMetas;
+    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : which == 4 ? &L0.dDistHi : which == 6 ? &L0.dDistMask : which == 7 ? &L0.dRecs : which == 8 ? &L0.dRes : which == 5 ? &c->dLitScratch : &L0.dMetas;
     if (bytes > b->cap) return -2;
     return hipMemcpy(hostDst, b->p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }

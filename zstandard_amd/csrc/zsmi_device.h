@@ -8,18 +8,17 @@
 #define ZS_UNIT_MAX    131072u    // bytes per LZ unit (match window): two consecutive blocks of a chunk
 #define ZS_TABLE_LOG_SMALL 13     // slots of each candidate table, units <= 64 KiB
 #define ZS_TABLE_LOG_BIG   14     // units <= 128 KiB
-#define ZS_WALK_LOG    10
-#define ZS_WALK_SIZE   (1u << ZS_WALK_LOG)   // the walk cuts the block in ranges of 1 KiB
-#define ZS_WALK_RANGES 64u        // per block
-#define ZS_CROSS_MAX   16384u     // a match may pass its walk range's end by this much (never the block's end)
+#define ZS_WALK_LOG_MIN 8         // the walk cuts a block in ranges of 256 bytes (512 at levels <= 2: the launch says which)
+#define ZS_OUT_LOG     10         // the walk kernel hands the sequences on in output ranges of 1 KiB
+#define ZS_WALK_RANGES 64u        // output ranges per block
+#define ZS_RES_PER_BLOCK 256u     // walk-range results per block (ranges of >= 256 bytes)
+#define ZS_CROSS_MAX   1024u      // a match may pass its walk range's end by this much (never the block's end)
 #define ZS_MINMATCH    5u         // shortest match kept
 #define ZS_REPMIN      4u         // shortest match at one of the walker's two recent offsets
-#define ZS_REPWIN      8u         // positions of a walk step's window tried for recent-offset matches (one per lane of a walker)
-#define ZS_WINDOW      64u        // positions looked at per walk step
-#define ZS_FCAP        8u         // forward bytes compared when scoring a candidate
-#define ZS_BCAP        8u         // backward bytes compared when scoring a candidate
-#define ZS_LCAP        16u        // forward bytes a walker lane compares in its one round of loads; longer matches are extended
-#define ZS_SEQ_PER_RANGE 256u     // record slots per walk range: its matches start inside it and are >= 4 bytes long
+#define ZS_WINDOW      32u        // positions looked at per walk step
+#define ZS_FCAP        8u         // forward bytes compared when scoring a candidate (the match taken is measured to its end)
+#define ZS_BCAP        4u         // backward bytes compared when scoring a candidate
+#define ZS_SEQ_PER_RANGE 256u     // record slots per output range: its matches start inside it and are >= 4 bytes long
 #define ZS_HUF_MAXBITS 11u
 
 // one 64 KiB block of one chunk
@@ -39,16 +38,17 @@ struct ZsUnitDesc {
 };
 
 // one sequence as the walk kernel leaves it (per range) / as the entropy kernels consume it: two 32-bit words
-//   x: bits 0-10 literals in front of it inside its range's territory (< 1024), bits 11-25 match length (<= 1024 + ZS_CROSS_MAX + ZS_BCAP),
-//      bit 26 bit 16 of the offset, bits 27-28 recent-offset code (written by the sequences kernel)
+//   x: bits 0-10 literals in front of it inside its output range's territory (<= 1024), bits 11-27 match length (<= 65536: matches found
+//      piecewise are joined), bit 28 bit 16 of the offset, bits 29-30 recent-offset code (written by the sequences kernel)
 //   y: bits 0-15 low 16 bits of the offset, bits 16-31 block position of the match start
 struct ZsSeqRec { uint32_t x, y; };
 __device__ __forceinline__ uint32_t zs_rec_ll(uint32_t x) { return x & 0x7FFu; }
-__device__ __forceinline__ uint32_t zs_rec_ml(uint32_t x) { return (x >> 11) & 0x7FFFu; }
-__device__ __forceinline__ uint32_t zs_rec_rep(uint32_t x) { return (x >> 27) & 3u; }
-__device__ __forceinline__ uint32_t zs_rec_off(uint32_t x, uint32_t y) { return (y & 0xFFFFu) | (((x >> 26) & 1u) << 16); }
+__device__ __forceinline__ uint32_t zs_rec_ml(uint32_t x) { return (x >> 11) & 0x1FFFFu; }
+__device__ __forceinline__ uint32_t zs_rec_rep(uint32_t x) { return (x >> 29) & 3u; }
+__device__ __forceinline__ uint32_t zs_rec_with_rep(uint32_t x, uint32_t rep) { return (x & 0x1FFFFFFFu) | (rep << 29); }
+__device__ __forceinline__ uint32_t zs_rec_off(uint32_t x, uint32_t y) { return (y & 0xFFFFu) | (((x >> 28) & 1u) << 16); }
 __device__ __forceinline__ uint32_t zs_rec_pos(uint32_t y) { return y >> 16; }
-__device__ __forceinline__ uint32_t zs_rec_x(uint32_t ll, uint32_t ml, uint32_t off) { return ll | (ml << 11) | ((off >> 16) << 26); }
+__device__ __forceinline__ uint32_t zs_rec_x(uint32_t ll, uint32_t ml, uint32_t off) { return ll | (ml << 11) | ((off >> 16) << 28); }
 __device__ __forceinline__ uint32_t zs_rec_y(uint32_t off, uint32_t pos) { return (off & 0xFFFFu) | (pos << 16); }
 
 // a walk range after the stitch: its records [first, first + nseq) count; litSum: literal bytes in front of those matches inside the
