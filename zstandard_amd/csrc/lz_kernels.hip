@@ -27,7 +27,7 @@
 //           (prefetched 2 .. 4 groups ahead) -- and leaves an operand word per position (tag << 17 | slot index) in an LDS ring;
 //   owner,  interval i: group i - 1: operand -> entry, exchange, distance (same tag and an earlier position) written over the operand;
 //   merger, interval i: group i - 2, half of its steps (the other table's merger takes the other half): long distance, else short
-//           -> dist[] (low 16 bits), distHi (bit 16, big units), distMask.  (ZS_CAND_MERGERS 0: the hashers merge.)
+//           -> dist[] (low 16 bits), distHi (bit 16, big units).
 // One barrier per interval.  The operand ring holds 3 groups per table; a step's 64 words are ZS_CAND_ROW = 65 words apart, which
 // spreads both the hashers' writes (8 consecutive positions a lane) and the owners' reads (64 consecutive) over all banks and keeps
 // every address of the form base + constant.
@@ -39,10 +39,7 @@
 #ifndef ZS_CAND_DEPTH
 #define ZS_CAND_DEPTH 2            // a register set holds the source loads of this many groups (two sets: 2 .. 4 groups in flight; 4: 0.64 vs 0.52 ms, the unrolled body grows)
 #endif
-#ifndef ZS_CAND_MERGERS
-#define ZS_CAND_MERGERS 1            // 1: a third wavefront per table merges and stores (0: the hashers do)
-#endif
-#define ZS_CAND_WAVES(NT) ((2 + ZS_CAND_MERGERS) * (NT))
+#define ZS_CAND_WAVES(NT) (3 * (NT))
 #define ZS_CAND_ROW 65u            // words per step in the operand ring (64 + 1 of padding)
 #define ZS_CAND_LDS(TLOG, NT) ((size_t)(NT) * (4u << (TLOG)) + 3u * (NT) * ZS_CAND_G * ZS_CAND_ROW * 4u + (NT) * 256u)   // tables, operand ring, a dummy word per owner lane
 #define ZS_SLOT_EMPTY 0xFFFFFFFFu
@@ -56,7 +53,7 @@ __device__ __forceinline__ uint32_t zs_hash_long(uint32_t lo, uint32_t hi)
 template <int TLOG, int NT>
 __global__ void __launch_bounds__(64 * ZS_CAND_WAVES(NT))
 k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units, uint32_t block0,
-                uint16_t *__restrict__ distAll, uint8_t *__restrict__ distHiAll, uint8_t *__restrict__ distMaskAll)
+                uint16_t *__restrict__ distAll, uint8_t *__restrict__ distHiAll)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t candLds[];
     constexpr bool BIG = TLOG > ZS_TABLE_LOG_SMALL;
@@ -75,38 +72,32 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     const size_t slot = (size_t)(ud.firstBlock - block0);
     uint16_t *dist = distAll + slot * ZS_BLOCK_MAX;
     uint8_t *distHi = distHiAll + slot * (ZS_BLOCK_MAX / 8);
-    uint8_t *distMask = distMaskAll + slot * (ZS_BLOCK_MAX / 8);     // bit p: position p has a candidate
     const uint32_t hashable = (n >= 8) ? n - 7 : 0;                   // positions [0, hashable) have 8 bytes
     const uint32_t nGroups = (hashable + GP - 1) / GP;
     if (nGroups == 0) return;
     // a position that is not inserted (behind the hashable ones) exchanges with a word of its owner lane's own behind the ring;
     // index relative to the owner's table, < 2^16
     const uint32_t dummyBase = ((uint32_t)(NT - tab) << TLOG) + RING + tab * 64u;
-    // merge of a group (both tables' distances -> dist / distMask / distHi): this wavefront's H steps of it
+    // merge of a group (both tables' distances -> dist / distHi): this wavefront's H steps of it
     auto mergeRead = [&](uint32_t g, uint32_t (&mS)[H], uint32_t (&mL)[H]) {
         const uint32_t *xb = opnd + (size_t)(g % 3u) * NT * GR + (NT > 1 ? tab * H : 0u) * ROW + lane;
         #pragma unroll
         for (uint32_t uu = 0; uu < H; uu++) { mS[uu] = xb[uu * ROW]; mL[uu] = (NT > 1) ? xb[GR + uu * ROW] : 0u; }
     };
     auto mergeStore = [&](uint32_t g, const uint32_t (&mS)[H], const uint32_t (&mL)[H]) {
-        // candidate bits (and bit 16 of the distances): lane uu keeps step uu's word, so each plane takes one store of H * 8
-        // contiguous bytes.  (What is stored for positions behind the hashable ones is never read: the walk stops at them.)
+        // bit 16 of the distances (big units): lane uu keeps step uu's word, so the plane takes one store of H * 8 contiguous bytes.
+        // (What is stored for positions behind the hashable ones is never used: the walk cuts them off its window.)
         const uint32_t sbase = g * GP + ((NT > 1) ? tab * H * 64u : 0u);
-        uint64_t pmMine = 0, hiMine = 0;
+        uint64_t hiMine = 0;
         #pragma unroll
         for (uint32_t uu = 0; uu < H; uu++) {
             const uint32_t dm = (NT > 1) ? (mL[uu] ? mL[uu] : mS[uu]) : mS[uu];
             if (BIG) { const uint64_t hi = __ballot((dm >> 16) != 0); if (lane == uu) hiMine = hi; }
-            const uint64_t pm = __ballot(dm != 0);
-            if (lane == uu) pmMine = pm;
             dist[sbase + uu * 64 + lane] = (uint16_t)dm;
         }
-        if (lane < H) {
-            *reinterpret_cast<uint64_t *>(distMask + ((sbase + lane * 64) >> 3)) = pmMine;
-            if (BIG) *reinterpret_cast<uint64_t *>(distHi + ((sbase + lane * 64) >> 3)) = hiMine;
-        }
+        if (BIG && lane < H) *reinterpret_cast<uint64_t *>(distHi + ((sbase + lane * 64) >> 3)) = hiMine;
     };
-    if (ZS_CAND_MERGERS && wave >= 2 * NT) {
+    if (wave >= 2 * NT) {
         // ---------------- merger: interval i merges group i - 2 ----------------
         __syncthreads(); __syncthreads();
         for (uint32_t i = 2; i <= nGroups + 1; i++) {
@@ -181,9 +172,6 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
         auto iter = [&](auto wholeTag, uint32_t i, const uint32_t (&w)[4]) {
             constexpr bool WHOLE = decltype(wholeTag)::value;            // group i lies wholly inside the hashable positions
             const uint32_t ringSlot = i % 3u;
-            // distances of group i - 2 (both tables): reads issued first, they travel under the hashing
-            uint32_t mS[H], mL[H];
-            if (!ZS_CAND_MERGERS && i >= 2) mergeRead(i - 2, mS, mL);
             if (i < nGroups) {
                 uint32_t *ob = opnd + ((size_t)ringSlot * NT + tab) * GR + wbase;
                 const uint32_t pbase = i * GP + lane * 8u;
@@ -199,16 +187,11 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
                     ob[u] = (WHOLE || pbase + u < hashable) ? (r & (0xFFFE0000u | ((1u << TLOG) - 1u))) : ((r & 0xFFFE0000u) | (dummyBase + l0 + u));
                 }
             }
-            if (!ZS_CAND_MERGERS && i >= 2) mergeStore(i - 2, mS, mL);
             __syncthreads();
         };
         auto step = [&](uint32_t i, const uint32_t (&w)[4]) {
             if (i > nGroups + 1) return;
-#ifdef ZS_CAND_NOWHOLE
-            iter(std::false_type{}, i, w);
-#else
             if ((i + 1) * GP + 8u <= n) iter(std::true_type{}, i, w); else iter(std::false_type{}, i, w);
-#endif
         };
         loadM(0, bufA);
         for (uint32_t g0 = 0; g0 <= nGroups + 1; g0 += 2 * M) {
@@ -246,19 +229,15 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
 // Last, the records that count are packed, 1 KiB of source (an OUTPUT RANGE = 1024 / R walk ranges) at a time, into the layout the
 // entropy kernels read: seqAll[block][64 output ranges][256 records] + hdrAll (nseq, trailing, litSum, first = 0).
 // ---------------------------------------------------------------------------------------------
-#ifndef ZS_WALK_NT
-#define ZS_WALK_NT 512             // threads per unit <= 64 KiB: 128 walkers for its 256 walk ranges of 256 bytes
-#endif
-#ifndef ZS_WALK_NT_BIG
-#define ZS_WALK_NT_BIG 1024        // threads per unit <= 128 KiB
+#ifndef ZS_WALK_LPW
+#define ZS_WALK_LPW 2               // lanes per walker = aligned groups of 8 positions a step looks at (oracle: WINDOW_GROUPS)
 #endif
 #ifndef ZS_WALK_MINW
 #define ZS_WALK_MINW 1             // waves per SIMD the small-unit kernel is compiled for (register budget)
 #endif
-#ifndef ZS_WALK_LPW
-#define ZS_WALK_LPW 2               // lanes per walker = aligned groups of 8 positions a step looks at (oracle: WINDOW_GROUPS)
-#endif
-#define ZS_WALK_KERNEL(LOOK, REPW, BIG) k_lz_walk<ZS_WALK_LPW, LOOK, REPW, BIG, ((BIG) ? ZS_WALK_NT_BIG : ZS_WALK_NT)>
+// threads per unit: a walker per walk range (64 KiB in ranges of 256 bytes: 256 walkers of 2 lanes; ranges of 512 bytes at levels <= 2: half of that)
+#define ZS_WALK_THREADS(BIG, WLOG) ((((BIG) ? ZS_UNIT_MAX : ZS_BLOCK_MAX) >> (WLOG)) * ZS_WALK_LPW)
+#define ZS_WALK_KERNEL(LOOK, REPW, BIG, WLOG) k_lz_walk<ZS_WALK_LPW, LOOK, REPW, BIG, ZS_WALK_THREADS(BIG, WLOG)>
 #define ZS_WALK_FRONT 16u          // LDS bytes in front of the unit (backward reads near position 0)
 #define ZS_WALK_TAIL  144u         // zero bytes behind the unit (forward reads near the end)
 // exchange buffer (16 bytes a lane) + source + queue head + a byte a lane (BIG: bit 16 of the distances)
@@ -389,7 +368,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
     {
         // whole 16-byte pieces: the loads of a thread are issued together (a load behind a branch, followed by its LDS
         // store, would wait out one memory round trip per piece); then the partial piece and the zero tail
-        constexpr uint32_t PER = CAP / 16 / NT;                                  // pieces per thread
+        constexpr uint32_t PER = (CAP / 16 + NT - 1) / NT;                       // pieces per thread
         const uint32_t nFull = n & ~15u;
         uint4 v[PER];
         #pragma unroll

@@ -118,7 +118,7 @@ struct zsmi_ctx {
     uint32_t maxBlocksInFlight = 16384;   // ZSMI_BLOCKS_IN_FLIGHT: 64 KiB blocks per sub-batch (scratch ~0.6 MiB a block, reserved for what a call needs); 2 GiB of 128 KiB chunks: 8192: 86.5, 16384: 88.2, 32768: 89.4 GiB/s
     // compress workspace: plan (shared) + one scratch set per internal stream ("lane")
     DevBuf dBlocks, dChunks, dUnits;     // dUnits: small units (<= 64 KiB) first, then big ones, each in chunk order
-    struct Scratch { DevBuf dDist, dDistHi, dDistMask, dRecs, dRes, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
+    struct Scratch { DevBuf dDist, dDistHi, dRecs, dRes, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
     static const int kMaxLanes = 8;
     Scratch lanes[kMaxLanes];
     int nLanes = 1;
@@ -182,9 +182,9 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
             hipFuncAttributes fa;
             return hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) == hipSuccess && hipFuncGetAttributes(&fa, fn) == hipSuccess && fa.sharedSizeBytes == 0;
         };
-        ok &= walkOk((const void *)ZS_WALK_KERNEL(4, 8, false), ZS_WALK_LDS(ZS_BLOCK_MAX)) && walkOk((const void *)ZS_WALK_KERNEL(4, 8, true), ZS_WALK_LDS(ZS_UNIT_MAX));
-        ok &= walkOk((const void *)ZS_WALK_KERNEL(4, 4, false), ZS_WALK_LDS(ZS_BLOCK_MAX)) && walkOk((const void *)ZS_WALK_KERNEL(4, 4, true), ZS_WALK_LDS(ZS_UNIT_MAX));
-        ok &= walkOk((const void *)ZS_WALK_KERNEL(8, 8, false), ZS_WALK_LDS(ZS_BLOCK_MAX)) && walkOk((const void *)ZS_WALK_KERNEL(8, 8, true), ZS_WALK_LDS(ZS_UNIT_MAX));
+        ok &= walkOk((const void *)ZS_WALK_KERNEL(4, 8, false, 9), ZS_WALK_LDS(ZS_BLOCK_MAX)) && walkOk((const void *)ZS_WALK_KERNEL(4, 8, true, 9), ZS_WALK_LDS(ZS_UNIT_MAX));
+        ok &= walkOk((const void *)ZS_WALK_KERNEL(4, 4, false, 8), ZS_WALK_LDS(ZS_BLOCK_MAX)) && walkOk((const void *)ZS_WALK_KERNEL(4, 4, true, 8), ZS_WALK_LDS(ZS_UNIT_MAX));
+        ok &= walkOk((const void *)ZS_WALK_KERNEL(8, 8, false, 8), ZS_WALK_LDS(ZS_BLOCK_MAX)) && walkOk((const void *)ZS_WALK_KERNEL(8, 8, true, 8), ZS_WALK_LDS(ZS_UNIT_MAX));
         if (!ok) { (void)hipGetLastError(); if (c->ownStream) (void)hipStreamDestroy(c->stream); delete c; return nullptr; }
     }
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
@@ -212,7 +212,7 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
     for (int i = 0; i < zsmi_ctx::kMaxLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
         if (L.stream) (void)hipStreamSynchronize(L.stream);
-        for (DevBuf *b : { &L.dDist, &L.dDistHi, &L.dDistMask, &L.dRecs, &L.dRes, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dLitSec, &L.dSeqSec, &L.dMetas }) b->release();
+        for (DevBuf *b : { &L.dDist, &L.dDistHi, &L.dRecs, &L.dRes, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dLitSec, &L.dSeqSec, &L.dMetas }) b->release();
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
@@ -326,7 +326,7 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
     if (cap < maxChunkBlocks) cap = maxChunkBlocks;
     for (int i = 0; i < nLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
-        if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2 + 256) || !L.dDistHi.reserve((size_t)cap * (ZS_BLOCK_MAX / 8) + 256) || !L.dDistMask.reserve((size_t)cap * (ZS_BLOCK_MAX / 8) + 256) || !L.dRecs.reserve(((size_t)cap * (ZS_BLOCK_MAX / 4) + 64) * sizeof(uint2)) || !L.dRes.reserve((size_t)cap * ZS_RES_PER_BLOCK * sizeof(uint4) + ((size_t)8 << 20)) || !L.dSeqs.reserve((size_t)cap * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
+        if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2 + 256) || !L.dDistHi.reserve((size_t)cap * (ZS_BLOCK_MAX / 8) + 256) || !L.dRecs.reserve(((size_t)cap * (ZS_BLOCK_MAX / 4) + 64) * sizeof(uint2)) || !L.dRes.reserve((size_t)cap * ZS_RES_PER_BLOCK * sizeof(uint4) + ((size_t)8 << 20)) || !L.dSeqs.reserve((size_t)cap * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
             !L.dHdrs.reserve((size_t)cap * ZS_WALK_RANGES * sizeof(ZsRangeHdr)) || !L.dLits.reserve((size_t)cap * (ZS_BLOCK_MAX + 64)) ||
             !L.dStreams.reserve((size_t)cap * 4 * ZS_STREAM_STRIDE) || !L.dLitSec.reserve((size_t)cap * ZS_LITSEC_STRIDE) ||
             !L.dSeqSec.reserve((size_t)cap * ZS_SEQSEC_STRIDE) || !L.dMetas.reserve((size_t)cap * sizeof(ZsBlockMeta))) return ZSMI_error_memory_allocation;
@@ -345,14 +345,14 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         const uint32_t s0 = c->smallBefore[chunk0], ns = c->smallBefore[chunk1] - s0, b0 = c->bigBefore[chunk0], nbig = c->bigBefore[chunk1] - b0;
         const ZsUnitDesc *dUS = (const ZsUnitDesc *)c->dUnits.p + s0, *dUB = (const ZsUnitDesc *)c->dUnits.p + c->planSmall + b0;
         #define CAND_LAUNCH(name, TL, NT, cnt, du) LAUNCH_ON(c, st, name, (k_lz_candidates<TL, NT>), dim3(cnt), dim3(64 * ZS_CAND_WAVES(NT)), ZS_CAND_LDS(TL, NT), (const uint8_t *)dSrc, du, block0, \
-                          (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, (uint8_t *)L.dDistMask.p)
+                          (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p)
         if (ns) { if (useLong) CAND_LAUNCH("k_lz_candidates", ZS_TABLE_LOG_SMALL, 2, ns, dUS); else CAND_LAUNCH("k_lz_candidates", ZS_TABLE_LOG_SMALL, 1, ns, dUS); }
         if (nbig) { if (useLong) CAND_LAUNCH("k_lz_candidates_big", ZS_TABLE_LOG_BIG, 2, nbig, dUB); else CAND_LAUNCH("k_lz_candidates_big", ZS_TABLE_LOG_BIG, 1, nbig, dUB); }
         #undef CAND_LAUNCH
-        #define WALK_LAUNCH(name, LOOK, REPW, BIG, cnt, du) LAUNCH_ON(c, st, name, (ZS_WALK_KERNEL(LOOK, REPW, BIG)), dim3(cnt), dim3((BIG) ? ZS_WALK_NT_BIG : ZS_WALK_NT), ZS_WALK_LDS((BIG) ? ZS_UNIT_MAX : ZS_BLOCK_MAX), \
-                          (const uint8_t *)dSrc, du, block0, (const uint16_t *)L.dDist.p, (const uint8_t *)L.dDistHi.p, (uint2 *)L.dRecs.p, cap * (ZS_BLOCK_MAX / 4), (uint4 *)L.dRes.p, walkLog)
-        if (ns) { if (level <= 2) WALK_LAUNCH("k_lz_walk", 4, 8, false, ns, dUS); else if (level == 3) WALK_LAUNCH("k_lz_walk", 4, 4, false, ns, dUS); else WALK_LAUNCH("k_lz_walk", 8, 8, false, ns, dUS); }
-        if (nbig) { if (level <= 2) WALK_LAUNCH("k_lz_walk_big", 4, 8, true, nbig, dUB); else if (level == 3) WALK_LAUNCH("k_lz_walk_big", 4, 4, true, nbig, dUB); else WALK_LAUNCH("k_lz_walk_big", 8, 8, true, nbig, dUB); }
+        #define WALK_LAUNCH(name, LOOK, REPW, BIG, WLOG, cnt, du) LAUNCH_ON(c, st, name, (ZS_WALK_KERNEL(LOOK, REPW, BIG, WLOG)), dim3(cnt), dim3(ZS_WALK_THREADS(BIG, WLOG)), ZS_WALK_LDS((BIG) ? ZS_UNIT_MAX : ZS_BLOCK_MAX), \
+                          (const uint8_t *)dSrc, du, block0, (const uint16_t *)L.dDist.p, (const uint8_t *)L.dDistHi.p, (uint2 *)L.dRecs.p, cap * (ZS_BLOCK_MAX / 4), (uint4 *)L.dRes.p, WLOG)
+        if (ns) { if (level <= 2) WALK_LAUNCH("k_lz_walk", 4, 8, false, 9, ns, dUS); else if (level == 3) WALK_LAUNCH("k_lz_walk", 4, 4, false, 8, ns, dUS); else WALK_LAUNCH("k_lz_walk", 8, 8, false, 8, ns, dUS); }
+        if (nbig) { if (level <= 2) WALK_LAUNCH("k_lz_walk_big", 4, 8, true, 9, nbig, dUB); else if (level == 3) WALK_LAUNCH("k_lz_walk_big", 4, 4, true, 8, nbig, dUB); else WALK_LAUNCH("k_lz_walk_big", 8, 8, true, 8, nbig, dUB); }
         #undef WALK_LAUNCH
         LAUNCH_ON(c, st, "k_lz_stitch", k_lz_stitch, dim3(nb), dim3(256), 0, dB, (const uint2 *)L.dRecs.p, (const uint4 *)L.dRes.p, (ZsSeqRec *)L.dSeqs.p, (ZsRangeHdr *)L.dHdrs.p, walkLog);
         if (c->stopAfterWalk) { chunk0 = chunk1; continue; }
@@ -658,7 +658,7 @@ extern "C" int zsmi_dbg_copyScratch(zsmi_ctx *c, int which, void *hostDst, size_
     if (!c) return -1;
     (void)hipStreamSynchronize(c->stream);
     zsmi_ctx::Scratch &L0 = c->lanes[0];
-    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : which == 4 ? &L0.dDistHi : which == 6 ? &L0.dDistMask : which == 7 ? &L0.dRecs : which == 8 ? &L0.dRes : which == 5 ? &c->dLitScratch : &L0.dMetas;
+    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : which == 4 ? &L0.dDistHi : which == 7 ? &L0.dRecs : which == 8 ? &L0.dRes : which == 5 ? &c->dLitScratch : &L0.dMetas;
     if (bytes > b->cap) return -2;
     return hipMemcpy(hostDst, b->p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
