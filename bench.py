@@ -72,6 +72,79 @@ def load_corpus(path, nbytes, rank):
     return np.tile(data, reps)[:nbytes]
 
 
+
+def throughput_by_class(bc, args, torch):
+    """GiB/s and ratio of the compress path at this level / chunk size per data class: every class of tests/_corpus.py (1 MiB generated,
+    tiled to the headline's batch size) plus all-zero, uniform-random and period-1000 inputs.  Same timing as the headline (device-resident input, events
+    excluded), fewer steps; not part of `value`."""
+    import _corpus as C
+    cs = args.chunk_size
+    n = args.chunks                                  # the headline's batch size
+    nbytes = n * cs
+    classes = dict(C.corpus(1 << 20))
+    rng = np.random.default_rng(7)
+    classes["zeros"] = bytes(1 << 20)
+    classes["random"] = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
+    per = rng.integers(0, 256, 1000, dtype=np.uint8).tobytes()
+    classes["period1000"] = None
+    offs = np.arange(n, dtype=np.uint64) * cs; sizes = np.full(n, cs, dtype=np.uint32)
+    bound = int(bc.L.zsmi_compressBound(cs)); stride = (bound + 255) // 256 * 256
+    doffs = np.arange(n, dtype=np.uint64) * stride
+    d_dst = torch.empty(n * stride, dtype=torch.uint8, device="cuda"); d_sizes = torch.zeros(n, dtype=torch.int32, device="cuda")
+    out = {}
+    for name, data in classes.items():
+        if name == "period1000":
+            host = np.frombuffer((per * (nbytes // 1000 + 1))[:nbytes], dtype=np.uint8)
+        else:
+            one = np.frombuffer(data, dtype=np.uint8)
+            host = np.tile(one, (nbytes + len(one) - 1) // len(one))[:nbytes]
+        d_src = torch.from_numpy(host.copy()).cuda()
+        step = lambda: bc.compress_device(d_src.data_ptr(), offs, sizes, d_dst.data_ptr(), doffs, d_sizes.data_ptr(), args.level)
+        step(); torch.cuda.synchronize()
+        k = 5
+        t0 = time.perf_counter()
+        for _ in range(k):
+            step()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        csz = d_sizes.cpu().numpy().astype(np.uint32)
+        assert (csz < 0xFFFFFF88).all(), name
+        out[name] = {"GiB/s": round(nbytes * k / dt / (1 << 30), 1), "ratio": round(nbytes / float(csz.astype(np.uint64).sum()), 3)}
+        del d_src
+    return {"per_class": out, "note": "%d x %d B chunks per class (1 MiB of the class tiled to %d MiB; period1000: one random 1000-byte string repeated), level %d, %d steps after one warm-up"
+            % (n, cs, nbytes >> 20, args.level, 5)}
+
+
+def libzstd_frames_decode(bc, args, torch, host, nf, fs):
+    """BASELINE config 4's "pre-built zstd frames": the same slices compressed by UPSTREAM libzstd (level 3, one frame a slice, built on the
+    host cores), decoded by the HIP decoder; whole output verified.  None when libzstd cannot be loaded."""
+    import _oracle as O
+    Z = O.libzstd()
+    if not Z:
+        return None
+    L = O.lib(); vp = ctypes.c_void_p
+    bound = int(Z.ZSTD_compressBound(fs)); stride = (bound + 255) // 256 * 256
+    zb = np.empty(nf * stride, dtype=np.uint8); zs = np.zeros(nf, dtype=np.uint32)
+    offs = np.arange(nf, dtype=np.uint64) * fs; sizes = np.full(nf, fs, dtype=np.uint32); foffs = np.arange(nf, dtype=np.uint64) * stride
+    rc = L.zso_libzstdCompressBatch(zb.ctypes.data_as(vp), foffs.ctypes.data_as(vp), zs.ctypes.data_as(vp), host.ctypes.data_as(vp),
+                                    offs.ctypes.data_as(vp), sizes.ctypes.data_as(vp), nf, 3, usable_cores())
+    assert rc == 0
+    d_frames = torch.from_numpy(zb).cuda(); d_src = torch.from_numpy(host[:nf * fs]).cuda()
+    d_out = torch.empty(nf * fs, dtype=torch.uint8, device="cuda"); d_osz = torch.zeros(nf, dtype=torch.int32, device="cuda")
+    step = lambda: bc.decompress_device(d_frames.data_ptr(), foffs, zs, d_out.data_ptr(), offs, sizes, d_osz.data_ptr())
+    step(); torch.cuda.synchronize()
+    k = max(2, args.steps // 4)
+    t0 = time.perf_counter()
+    for _ in range(k):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    assert (d_osz.cpu().numpy() == fs).all(), "a libzstd frame failed to decode"
+    assert torch.equal(d_out, d_src), "decoded bytes differ from the input"
+    return {"value": round(nf * fs * k / dt / (1 << 30), 3), "unit": "GiB/s", "frames": nf, "steps": k,
+            "label": "frames built by upstream libzstd %d ZSTD_compress level 3 from the same %d B slices (BASELINE config 4: pre-built zstd frames); whole output verified" % (Z.ZSTD_versionNumber(), fs)}
+
+
 def decode_leg(bc, args, rank, world, distributed, barrier, torch, dist):
     """BASELINE config 4 shape: nf frames of ~32 KiB (level-3 output of this codec's encoder, built on the device), decoded
     per step; timed like the compress leg (barrier + synchronize on both sides, max over ranks); the whole output is compared
@@ -122,9 +195,21 @@ def decode_leg(bc, args, rank, world, distributed, barrier, torch, dist):
     roof = {"bound": "hbm", "kernel": name, "achieved": round(per_launch / (secs / launches) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(per_launch / (secs / launches) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(per_launch),
             "avg_launch_ms": round(secs / launches * 1e3, 4), "kernels_ms_per_step": {k: round(v[0] / args.steps * 1e3, 4) for k, v in kt_all.items()}}
+    try:                                            # HBM bytes per launch of the dominant kernel from the committed PMC passes, scaled to this launch size
+        tjf = json.load(open(os.path.join(ROOT, "profiles", "r3_decode_traffic.json")))
+        if tjf.get("kernel_source_sha256") == source_fingerprint() and name in tjf["kernels"]:
+            roof["traffic"] = int(tjf["kernels"][name]["hbm_bytes"] * nf / tjf["kernels"][name]["frames_per_launch"])
+        else:
+            roof["traffic_note"] = "profiles/r3_decode_traffic.json was measured at other kernel sources (%s): not reported" % tjf.get("kernel_source_sha256")
+    except Exception as e:
+        roof["traffic_note"] = "no traffic file: %s" % type(e).__name__
     out = {"metric": f"GiB/s decompress (output bytes), frames of {fs} B", "value": round(nf * fs * world * args.steps / elapsed / (1 << 30), 3), "unit": "GiB/s",
            "frames_per_gpu_per_step": nf, "ms_per_step": round(elapsed / args.steps * 1e3, 3), "verified": "whole output equals the input (torch.equal) after the timed region",
            "roofline": roof}
+    if not args.no_extras:
+        zl = libzstd_frames_decode(bc, args, torch, host, nf, fs)
+        if zl:
+            out["libzstd_frames"] = zl
     if not args.no_cpu_baseline:
         cores = usable_cores(); m = min(nf, 4096)
         fr = d_frames[:m * stride].cpu().numpy(); L = O.lib(); vp = ctypes.c_void_p
@@ -241,6 +326,17 @@ def main():
     torch.cuda.synchronize()
     ktimes_all = bc.kernel_times()
     bc.enable_timing(False)
+    # sustained clocks: the same step back to back for >= 2 s, outside the headline's timed region
+    sustained = None
+    if not args.no_extras:
+        t1 = time.perf_counter(); k = 0
+        while time.perf_counter() - t1 < 2.0:
+            for _ in range(50):
+                step()
+            torch.cuda.synchronize(); k += 50
+        dt = time.perf_counter() - t1
+        sustained = {"value": round(nbytes * k / dt / (1 << 30), 3), "unit": "GiB/s per GPU", "steps": k, "seconds": round(dt, 2),
+                     "note": "the headline's step looped for >= 2 s (synchronised every 50 steps), this rank only"}
 
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -302,9 +398,9 @@ def main():
             # The file names the kernel sources it was measured at: other sources -> null.
             traffic = None; traffic_note = None
             try:
-                tjf = json.load(open(os.path.join(ROOT, "profiles", "r2_traffic.json")))
+                tjf = json.load(open(os.path.join(ROOT, "profiles", "r3_traffic.json")))
                 if tjf.get("kernel_source_sha256") != source_fingerprint():
-                    traffic_note = "profiles/r2_traffic.json was measured at other kernel sources (%s): not reported" % tjf.get("kernel_source_sha256")
+                    traffic_note = "profiles/r3_traffic.json was measured at other kernel sources (%s): not reported" % tjf.get("kernel_source_sha256")
                 else:
                     tj = tjf["kernels"].get(name)
                     if tj:
@@ -355,8 +451,12 @@ def main():
                "ratio": round(ratio, 4), "ratio_vs_libzstd_same_level": ratio_vs_zstd,
                "hbm_read_roofline_frac": round(total_in * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
                "roofline": roofline, "cpu_baseline": cpu, "datagen_s": round(gen_s, 2)}
+        if sustained:
+            out["sustained"] = sustained
         if decode:
             out["decode"] = decode
+        if not args.no_extras:
+            out["throughput_by_class"] = throughput_by_class(bc, args, torch)
         Z = O.libzstd()
         if Z and not args.no_extras:
             # the ratio contract per data class (tests/_corpus.py), HIP encoder vs upstream libzstd at this level and chunk size
