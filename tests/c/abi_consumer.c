@@ -5,11 +5,62 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <pthread.h>
+#include <time.h>
 
 #define CHECK(c) do { if (!(c)) { fprintf(stderr, "FAILED line %d: %s\n", __LINE__, #c); return 1; } } while (0)
 
 static uint64_t rng_state = 88172645463325252ull;
 static uint32_t rnd(void) { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return (uint32_t)(rng_state >> 16); }
+
+/* ---- the one-shot calls from several threads at once (the reference's static API is re-entrant: ZStdDecompress.cs:2174-2191) ---- */
+typedef struct {
+    int id; const unsigned char *src; size_t n; const unsigned char *frame; size_t csize;      /* shared, read only */
+    const unsigned char *golden; size_t goldenSize; const unsigned char *goldenWant; size_t goldenWantSize;
+    int failed;
+} Job;
+static void *worker(void *arg)
+{
+    Job *j = (Job *)arg;
+    size_t const piece = 20000 + 1000 * (size_t)j->id, off = 30000 * (size_t)j->id;
+    unsigned char *buf = (unsigned char *)malloc(zsmi_compressBound(j->n)), *back = (unsigned char *)malloc(j->n);
+    int it;
+    j->failed = 1;
+    if (!buf || !back) return NULL;
+    for (it = 0; it < 6; it++) {
+        size_t r;
+        /* my own slice: compress, decompress, compare */
+        size_t const c = zsmi_compress(buf, zsmi_compressBound(piece), j->src + off, piece, 1 + (j->id + it) % 4);
+        if (zsmi_isError(c)) return NULL;
+        r = zsmi_decompress(back, piece, buf, c);
+        if (r != piece || memcmp(back, j->src + off, piece) != 0) return NULL;
+        /* the shared frame, made on one thread */
+        r = zsmi_decompress(back, j->n, j->frame, j->csize);
+        if (r != j->n || memcmp(back, j->src, j->n) != 0) return NULL;
+        /* the reference's golden vector, when the caller gave it */
+        if (j->golden) {
+            r = zsmi_decompress(back, j->goldenWantSize, j->golden, j->goldenSize);
+            if (r != j->goldenWantSize || memcmp(back, j->goldenWant, r) != 0) return NULL;
+        }
+        /* an error on one thread is that call's result alone */
+        r = zsmi_decompress(back, 10, j->frame, j->csize);
+        if (!zsmi_isError(r) || zsmi_getErrorCode(r) != ZSMI_error_dstSize_tooSmall) return NULL;
+    }
+    free(buf); free(back);
+    j->failed = 0;
+    return NULL;
+}
+static unsigned char *slurp(const char *path, size_t *size)
+{
+    FILE *f = fopen(path, "rb"); unsigned char *p; long n;
+    if (!f) return NULL;
+    fseek(f, 0, SEEK_END); n = ftell(f); fseek(f, 0, SEEK_SET);
+    p = (unsigned char *)malloc((size_t)n + 1);
+    if (p && fread(p, 1, (size_t)n, f) != (size_t)n) { free(p); p = NULL; }
+    fclose(f); *size = (size_t)n;
+    return p;
+}
+static double now_ms(void) { struct timespec t; clock_gettime(CLOCK_MONOTONIC, &t); return t.tv_sec * 1e3 + t.tv_nsec * 1e-6; }
 
 int main(int argc, char **argv)
 {
@@ -57,7 +108,27 @@ int main(int argc, char **argv)
     CHECK(zsmi_decompressBatchHost(ctx, arena, dofs, dsz, 4, back, so, caps, osz) == 0);
     CHECK(osz[2] == (uint32_t)-ZSMI_error_dstSize_tooSmall && osz[0] == 70000 && osz[3] == 100000);
     zsmi_freeCtx(ctx);
-    printf("abi_consumer ok: %zu -> %zu bytes, %s\n", n, csize, zsmi_versionString());
-    (void)argc; (void)argv;
+
+    /* 8 threads, mixed one-shot calls; argv[1] / argv[2]: the reference's golden frame and its content (tests/golden/csharp_alphabet.*) */
+    {
+        enum { NTHREADS = 8 };
+        pthread_t th[NTHREADS]; Job jobs[NTHREADS];
+        size_t gsize = 0, wsize = 0; int t;
+        unsigned char *golden = argc > 2 ? slurp(argv[1], &gsize) : NULL, *want = argc > 2 ? slurp(argv[2], &wsize) : NULL;
+        CHECK(argc <= 2 || (golden && want));
+        for (t = 0; t < NTHREADS; t++) {
+            Job jb = { t, src, n, frame, csize, golden, gsize, want, wsize, 1 };
+            jobs[t] = jb;
+            CHECK(pthread_create(&th[t], NULL, worker, &jobs[t]) == 0);
+        }
+        for (t = 0; t < NTHREADS; t++) pthread_join(th[t], NULL);
+        for (t = 0; t < NTHREADS; t++) CHECK(!jobs[t].failed);
+        if (golden) {                                          /* latency of one small one-shot call (a 484-byte frame), warm */
+            double t0, best = 1e9; int k;
+            for (k = 0; k < 20; k++) { t0 = now_ms(); CHECK(zsmi_decompress(back, wsize, golden, gsize) == wsize); if (now_ms() - t0 < best) best = now_ms() - t0; }
+            printf("one-shot zsmi_decompress of the %zu-byte golden frame: %.3f ms (best of 20, host buffers, everything included)\n", gsize, best);
+        }
+    }
+    printf("abi_consumer ok: %zu -> %zu bytes, 8 threads of mixed one-shot calls, %s\n", n, csize, zsmi_versionString());
     return 0;
 }

@@ -125,7 +125,10 @@ def test_decode_damaged_own_frames_match_oracle(codec):
             assert sz > ERR
         else:
             assert sz == len(want) and got == want
-    assert nerr > 40                                                             # a fair share of the damage is caught (the rest decodes to other bytes: both decoders agree on them)
+    # 104 of the 320 damaged frames are rejected by oracle D for these seeds and this round's encoder (the rest decode to other bytes: both
+    # decoders agree on them).  The count is a property of the frames (oracle E) and of D's acceptance rules: whoever changes either re-pins it
+    # knowingly (round 2 loosened a bound here without saying why; the X4 last-symbol rule, HufDecompress.cs:369-385, had made D accept more).
+    assert nerr == 104
 
 
 def test_decode_truncations(codec):

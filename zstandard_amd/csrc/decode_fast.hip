@@ -73,8 +73,10 @@ __device__ __forceinline__ uint32_t zs_mlExtraBits(uint32_t s) { return s < 32 ?
 template <int F>
 __global__ void __launch_bounds__(64 * F, ZS_PREP_MINWG)
 k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems,
-           ZsFastDesc *__restrict__ descs, uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ seqTabs, uint32_t cap)
+           ZsFastDesc *__restrict__ descs, uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ seqTabs, uint32_t cap, uint32_t maxBlocks)
 {
+    // (maxBlocks: block slots the call reserved per item, 1 or 2 - frames of more compressed blocks are left to the general kernel;
+    //  descriptors always have both)
     // the general decoder's LDS image without its Huffman table and with one sequence table instead of three (4.4 of 15.5 KiB)
     __shared__ __attribute__((aligned(16))) unsigned char LSraw[F][(ZS_DLDS_PREP + 15) & ~15u];
     const uint32_t item = blockIdx.x * F + (threadIdx.x >> 6);
@@ -110,7 +112,7 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
         uint32_t b0 = fhs;                                          // offset of the next block header in the item
         bool fail = false;
         #pragma unroll 1
-        for (uint32_t blk = 0; blk < 2 && !fail; blk++) {
+        for (uint32_t blk = 0; blk < maxBlocks && !fail; blk++) {
             fail = true;
             const size_t slot = (size_t)blk * cap + item;
             ZsFastDesc *dp = descs + slot;
@@ -122,7 +124,7 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
             if (btype != 2 || cSize >= (1u << 17) || cSize < 3) break;
             if ((uint64_t)b0 + 3 + cSize + tail > srcSize) break;
             if (lastBlock && (uint64_t)b0 + 3 + cSize + tail != srcSize) break;
-            if (!lastBlock && blk == 1) break;                       // more than two blocks: general kernel
+            if (!lastBlock && blk + 1 == maxBlocks) break;           // more blocks than slots: general kernel
             b0 += 3;                                                // block payload offset in the item
             const uint8_t *bs = src + b0;
             // ---- literals section header (:683-821) ----

@@ -12,6 +12,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -133,7 +135,7 @@ struct zsmi_ctx {
     // decompress workspace
     DevBuf dItems, dLitScratch, dFastDesc, dHufTabs, dSeqTabs, dSeqOut;     // decode: items, literal scratch, fast-path tables and sequences
     bool decodeFast = true;              // ZSMI_DEC_FAST=0: general kernel only
-    uint32_t maxItemsInFlight = 65536;   // ZSMI_ITEMS_IN_FLIGHT: items per decode launch (scratch: 263 KiB an item, reserved for what a call needs).
+    uint32_t maxItemsInFlight = 65536;   // ZSMI_ITEMS_IN_FLIGHT: items per decode launch (scratch: ~263 KiB per item and block slot, one slot unless an item can hold two 64 KiB blocks; cut down to half the free device memory).
                                          // Every decode kernel is a long dependent chain per item: a launch is one to three rounds of workgroups and its
                                          // last round is mostly tail, so big launches pay (16384 frames of 32 KiB: 82 GiB/s, 57344: 104 GiB/s)
     PinBuf hItems;
@@ -390,13 +392,28 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
     ZsDecItem *hi = (ZsDecItem *)c->hItems.p;
     for (uint32_t i = 0; i < n; i++) { hi[i].srcOff = srcOffsets[i]; hi[i].dstOff = dstOffsets[i]; hi[i].srcSize = srcSizes[i]; hi[i].dstCap = dstCaps[i]; }
     if (hipMemcpyAsync(c->dItems.p, hi, sizeof(ZsDecItem) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
-    const uint32_t cap = std::min<uint32_t>(n, c->maxItemsInFlight);
     const bool useDict = dDict != nullptr && dictSize != 0;
     const bool fast = c->decodeFast && !useDict;                  // frames that name a dictionary go to the general kernel
-    // the fast path keeps two block slots per item (frames of one or two blocks): slot = block index * cap + item
-    if (!c->dLitScratch.reserve((size_t)cap * (fast ? 2 : 1) * ((1u << 17) + 64))) return ZSMI_error_memory_allocation;
-    if (fast && (!c->dFastDesc.reserve((size_t)cap * 2 * sizeof(ZsFastDesc)) || !c->dHufTabs.reserve((size_t)cap * 2 * ZS_FAST_HUFTAB_BYTES) ||
-                 !c->dSeqTabs.reserve((size_t)cap * 2 * ZS_FAST_SEQTAB_BYTES) || !c->dSeqOut.reserve((size_t)cap * 2 * ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)))) return ZSMI_error_memory_allocation;
+    // The fast path keeps its per-block scratch in slot = block index * cap + item.  The second slot (the second block of two-block
+    // frames: this codec's frames of 64 KiB < content <= 128 KiB) is reserved only when some item can hold more than one 64 KiB block;
+    // an item that has two smaller blocks then goes to the general kernel.  Scratch per item in flight: the general kernel's literal
+    // buffer 128 KiB; fast path: + Huffman and sequence tables + 16384 sequences of 8 bytes = ~263 KiB per slot.  The items in flight are
+    // cut down where that would take more than half of the device memory that is free (a shared or smaller device).
+    uint32_t maxBlocks = 1;
+    for (uint32_t i = 0; i < n && maxBlocks == 1; i++) if (dstCaps[i] > ZS_BLOCK_MAX) maxBlocks = 2;
+    const size_t perItem = ((size_t)(1u << 17) + 64) * (fast ? maxBlocks : 1) + (fast ? 2 * sizeof(ZsFastDesc) + (size_t)maxBlocks * (ZS_FAST_HUFTAB_BYTES + ZS_FAST_SEQTAB_BYTES + (size_t)ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)) : 0);
+    uint32_t cap = std::min<uint32_t>(n, c->maxItemsInFlight);
+    {
+        size_t freeB = 0, totalB = 0;
+        const size_t have = c->dLitScratch.cap + c->dFastDesc.cap + c->dHufTabs.cap + c->dSeqTabs.cap + c->dSeqOut.cap;     // what the context holds already counts as available
+        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+            const size_t budget = (freeB + have) / 2;
+            if ((size_t)cap * perItem > budget) cap = (uint32_t)std::max<size_t>(256, budget / perItem);
+        }
+    }
+    if (!c->dLitScratch.reserve((size_t)cap * (fast ? maxBlocks : 1) * ((1u << 17) + 64))) return ZSMI_error_memory_allocation;
+    if (fast && (!c->dFastDesc.reserve((size_t)cap * 2 * sizeof(ZsFastDesc)) || !c->dHufTabs.reserve((size_t)cap * maxBlocks * ZS_FAST_HUFTAB_BYTES) ||
+                 !c->dSeqTabs.reserve((size_t)cap * maxBlocks * ZS_FAST_SEQTAB_BYTES) || !c->dSeqOut.reserve((size_t)cap * maxBlocks * ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)))) return ZSMI_error_memory_allocation;
     for (uint32_t i0 = 0; i0 < n; i0 += cap) {
         const uint32_t cnt = std::min(cap, n - i0);
         const ZsDecItem *dI = (const ZsDecItem *)c->dItems.p + i0;
@@ -407,8 +424,8 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
             ZsFastDesc *dD = (ZsFastDesc *)c->dFastDesc.p;
             const uint32_t groups = (cnt + ZS_FAST_GROUP - 1) / ZS_FAST_GROUP;
             LAUNCH(c, "k_dec_prep", (k_dec_prep<ZS_DEC_GROUP>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc, dI, cnt, dD,
-                   (uint8_t *)c->dHufTabs.p, (uint8_t *)c->dSeqTabs.p, cap);
-            for (uint32_t blk = 0; blk < 2; blk++) {                  // block index 1: the second block of two-block frames (a wavefront without one leaves at once)
+                   (uint8_t *)c->dHufTabs.p, (uint8_t *)c->dSeqTabs.p, cap, maxBlocks);
+            for (uint32_t blk = 0; blk < maxBlocks; blk++) {          // block index 1: the second block of two-block frames (a wavefront without one leaves at once)
                 LAUNCH(c, "k_dec_huffman", k_dec_huffman, dim3(groups), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, blk, cap);
                 LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, blk, cap);
                 // the 2.5 KiB table class: fuller wavefronts (16 items) win when a launch is several rounds of workgroups, emptier ones (4) when it
@@ -598,17 +615,62 @@ extern "C" int zsmi_decompressBatchHost_usingDict(zsmi_ctx *c, const void *src, 
 }
 
 // ---------------------------------------------------------------------------------------------
-// one-shot calls (the reference's public API shape): a process-wide context, serialised
+// one-shot calls (the reference's public API shape).  The reference's static calls are re-entrant: a fresh DCtx per call
+// (ZStdDecompress.cs:2174-2180).  Here a call borrows a context from a per-device pool (created on demand, at most
+// ZSMI_ONESHOT_CONTEXTS = 8 per device; further callers wait), so concurrent callers run side by side instead of queueing behind
+// one mutex, and a context's device buffers are reused from call to call.  The pool is emptied when the library is unloaded.
 // ---------------------------------------------------------------------------------------------
-static std::mutex g_mu;
-static zsmi_ctx *g_ctx = nullptr;
-static zsmi_ctx *defaultCtx() { if (!g_ctx) g_ctx = zsmi_createCtx(-1, nullptr); return g_ctx; }
+namespace {
+struct OneShotPool {
+    static const int kMax = 8;
+    std::mutex mu;
+    std::condition_variable cv;
+    struct PerDevice { std::vector<zsmi_ctx *> idle; int created = 0; };
+    std::map<int, PerDevice> dev;
+    zsmi_ctx *acquire()
+    {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess) return nullptr;
+        std::unique_lock<std::mutex> lk(mu);
+        PerDevice &p = dev[d];
+        for (;;) {
+            if (!p.idle.empty()) { zsmi_ctx *c = p.idle.back(); p.idle.pop_back(); return c; }
+            if (p.created < kMax) {
+                p.created++;
+                lk.unlock();
+                zsmi_ctx *c = zsmi_createCtx(d, nullptr);
+                if (!c) { lk.lock(); p.created--; cv.notify_one(); }
+                return c;
+            }
+            cv.wait(lk);
+        }
+    }
+    void release(zsmi_ctx *c)
+    {
+        { std::lock_guard<std::mutex> lk(mu); dev[c->device].idle.push_back(c); }
+        cv.notify_one();
+    }
+    ~OneShotPool()
+    {
+        // library unload / process exit: the HIP runtime was loaded before this library and is still there; if it does not answer any
+        // more (a process torn down the hard way), the contexts are left to it
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) return;
+        for (auto &kv : dev) for (zsmi_ctx *c : kv.second.idle) zsmi_freeCtx(c);
+    }
+};
+OneShotPool g_pool;
+struct Borrowed {
+    zsmi_ctx *c;
+    Borrowed() : c(g_pool.acquire()) {}
+    ~Borrowed() { if (c) g_pool.release(c); }
+};
+}
 
 extern "C" size_t zsmi_compress(void *dst, size_t dstCapacity, const void *src, size_t srcSize, int level)
 {
     if (srcSize > 0xFFFFFFFFull) return ZSMI_ERR(ZSMI_error_srcSize_wrong);
-    std::lock_guard<std::mutex> lk(g_mu);
-    zsmi_ctx *c = defaultCtx();
+    Borrowed b; zsmi_ctx *c = b.c;
     if (!c) return ZSMI_ERR(ZSMI_error_GENERIC);
     const size_t bound = zsmi_compressBound(srcSize);
     std::vector<uint8_t> tmp;
@@ -625,8 +687,7 @@ extern "C" size_t zsmi_compress(void *dst, size_t dstCapacity, const void *src, 
 extern "C" size_t zsmi_decompress(void *dst, size_t dstCapacity, const void *src, size_t srcSize)
 {
     if (srcSize > 0xFFFFFFFFull) return ZSMI_ERR(ZSMI_error_srcSize_wrong);
-    std::lock_guard<std::mutex> lk(g_mu);
-    zsmi_ctx *c = defaultCtx();
+    Borrowed b; zsmi_ctx *c = b.c;
     if (!c) return ZSMI_ERR(ZSMI_error_GENERIC);
     const uint64_t so = 0, dof = 0; const uint32_t ss = (uint32_t)srcSize; uint32_t ds = 0;
     const uint32_t cap = (uint32_t)std::min<size_t>(dstCapacity, 0xFFFFFF00u);
@@ -639,8 +700,7 @@ extern "C" size_t zsmi_decompress(void *dst, size_t dstCapacity, const void *src
 extern "C" size_t zsmi_decompress_usingDict(void *dst, size_t dstCapacity, const void *src, size_t srcSize, const void *dict, size_t dictSize)
 {
     if (srcSize > 0xFFFFFFFFull) return ZSMI_ERR(ZSMI_error_srcSize_wrong);
-    std::lock_guard<std::mutex> lk(g_mu);
-    zsmi_ctx *c = defaultCtx();
+    Borrowed b; zsmi_ctx *c = b.c;
     if (!c) return ZSMI_ERR(ZSMI_error_GENERIC);
     const uint64_t so = 0, dof = 0; const uint32_t ss = (uint32_t)srcSize; uint32_t ds = 0;
     const uint32_t cap = (uint32_t)std::min<size_t>(dstCapacity, 0xFFFFFF00u);
