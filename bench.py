@@ -145,6 +145,30 @@ def libzstd_frames_decode(bc, args, torch, host, nf, fs):
             "label": "frames built by upstream libzstd %d ZSTD_compress level 3 from the same %d B slices (BASELINE config 4: pre-built zstd frames); whole output verified" % (Z.ZSTD_versionNumber(), fs)}
 
 
+
+def io_inclusive_leg(torch, dist, rank, world, all_sizes, root_src, compress_shard, device, barrier, reps=3):
+    """SURVEY 8e end to end, the job that starts and ends on rank 0: scatter the shards (one grouped batch of sends), every rank compresses
+    and packs its shard, all-gather of the frame sizes, gather of the frames to rank 0 (one grouped batch of receives).
+    compress_shard(shard tensor, chunk sizes of the shard) -> (frames packed back to back: uint8 tensor on `device`, frame sizes: np.uint32).
+    Returns on every rank (best wall time of reps - 1 repetitions after one warm-up, seconds of this rank's compress + pack, frames on rank 0, offsets, sizes)."""
+    from zstandard_amd.sharding import scatter_chunks, gather_frames
+    best = None; mine = None; out_all = goffs = gsz = None
+    for it in range(reps):
+        barrier(); t1 = time.perf_counter()
+        shard, (b0, e0) = scatter_chunks(root_src, all_sizes, root=0, device=device)
+        t2 = time.perf_counter()
+        packed, fsz = compress_shard(shard, all_sizes[b0:e0])
+        t3 = time.perf_counter()
+        out_all, goffs, gsz = gather_frames(packed, fsz, all_sizes, root=0)
+        barrier(); dt = time.perf_counter() - t1
+        if it:
+            if best is None or dt < best:
+                best, mine = dt, t3 - t2
+    secs = [None] * world
+    dist.all_gather_object(secs, (rank, float(mine), int(np.asarray(all_sizes[b0:e0], dtype=np.uint64).sum())))
+    return best, secs, out_all, goffs, gsz
+
+
 def decode_leg(bc, args, rank, world, distributed, barrier, torch, dist):
     """BASELINE config 4 shape: nf frames of ~32 KiB (level-3 output of this codec's encoder, built on the device), decoded
     per step; timed like the compress leg (barrier + synchronize on both sides, max over ranks); the whole output is compared
@@ -245,8 +269,8 @@ def main():
     ap.add_argument("--level", type=int, default=3)
     ap.add_argument("--corpus", type=str, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--with-io", action="store_true", help="also time the job that starts and ends on rank 0: scatter shards, compress, pack, gather frames "
-                    "(SURVEY 8e steps 1-4); reported as io_inclusive, never as value")
+    ap.add_argument("--with-io", action="store_true", help="with --force-dist on one GPU: also time the job that starts and ends on rank 0: scatter shards, compress, pack, "
+                    "gather frames (SURVEY 8e steps 1-4); with more than one rank that leg always runs; reported as io_inclusive, never as value")
     ap.add_argument("--force-dist", action="store_true", help="initialise torch.distributed (RCCL) even for one rank: exercises the N > 1 code path on a 1-GPU box")
     ap.add_argument("--decode-frames", type=int, default=57344, help="frames of --decode-frame-size bytes decoded per step of the decode leg (0: no decode leg)")
     ap.add_argument("--decode-frame-size", type=int, default=32768)
@@ -344,34 +368,32 @@ def main():
         elapsed = float(t.item())
 
     io_inclusive = None
-    if args.with_io and distributed:
-        # the whole job from rank 0's input to rank 0's frames; inputs and outputs stay in HBM (no PCIe leg)
-        from zstandard_amd.sharding import scatter_chunks, gather_frames
+    if distributed and (world > 1 or args.with_io):
+        # the whole job from rank 0's input to rank 0's frames; inputs and outputs stay in HBM (no PCIe leg).  Default whenever there is
+        # more than one rank: this is the path north_star names (RCCL scatter of input shards, gather of frames)
         all_sizes = np.full(n * world, cs, dtype=np.uint32)
         g_src = torch.cat([d_src] * world) if rank == 0 else None          # root holds world x the per-GPU batch
         d_packed = torch.empty(n * stride, dtype=torch.uint8, device="cuda")
         d_poffs = torch.zeros(n + 1, dtype=torch.int64, device="cuda")
-        best = None
-        for it in range(3):
-            barrier(); t1 = time.perf_counter()
-            shard, (b0, e0) = scatter_chunks(g_src, all_sizes, root=0, device="cuda")
+
+        def compress_shard(shard, shard_sizes):
             bc.compress_device(shard.data_ptr(), offs, sizes, d_dst.data_ptr(), doffs, d_sizes.data_ptr(), args.level)
             bc.pack_device(d_dst.data_ptr(), doffs, d_sizes.data_ptr(), n, d_packed.data_ptr(), d_poffs.data_ptr())
             torch.cuda.synchronize()
-            fsz = d_sizes.cpu().numpy().astype(np.uint32)
-            out_all, goffs, gsz = gather_frames(d_packed, fsz, all_sizes, root=0)
-            barrier(); dt = time.perf_counter() - t1
-            if it:
-                best = dt if best is None else min(best, dt)
-        ok = None
+            return d_packed, d_sizes.cpu().numpy().astype(np.uint32)
+        best, secs, out_all, goffs, gsz = io_inclusive_leg(torch, dist, rank, world, all_sizes, g_src, compress_shard, "cuda", barrier)
         if rank == 0:
             import _oracle as O
-            hostf = out_all.cpu().numpy(); ok = True
-            for i in (0, len(gsz) // 2, len(gsz) - 1):
-                f = hostf[int(goffs[i]):int(goffs[i]) + int(gsz[i])].tobytes()
-                ok = ok and O.decompress(f, cs) == host[(i % n) * cs:(i % n + 1) * cs].tobytes()
-        io_inclusive = {"value": round(n * world * cs / best / (1 << 30), 3), "unit": "GiB/s", "ms": round(best * 1e3, 3), "frames_decode": ok,
-                        "note": "rank 0 input -> scatter (grouped send/recv) -> compress -> pack -> all-gather sizes -> gather frames to rank 0; device memory only"}
+            hostf = out_all.cpu().numpy(); ok = True; checked = 0
+            for r in range(world):                                             # frames of every rank's shard decode to the chunks they were made from
+                for i in (r * n, r * n + n // 2, r * n + n - 1):
+                    f = hostf[int(goffs[i]):int(goffs[i]) + int(gsz[i])].tobytes()
+                    ok = ok and O.decompress(f, cs) == host[(i % n) * cs:(i % n + 1) * cs].tobytes(); checked += 1
+            io_inclusive = {"value": round(n * world * cs / best / (1 << 30), 3), "unit": "GiB/s", "ms": round(best * 1e3, 3), "ranks": world,
+                            "backend": dist.get_backend(), "frames_decode": ok, "frames_checked": checked,
+                            "per_rank_compress_pack_GiB/s": [round(b / t / (1 << 30), 1) for (_, t, b) in sorted(secs)],
+                            "note": "rank 0 input -> scatter (grouped send/recv) -> compress -> pack -> all-gather sizes -> gather frames to rank 0; device memory only; "
+                                    "a sample of every rank's frames decoded on rank 0 with oracle D after the timed region"}
 
     decode = decode_leg(bc, args, rank, world, distributed, barrier, torch, dist if distributed else None) if args.decode_frames else None
 
