@@ -66,13 +66,15 @@ typedef uint64_t U64;
 #define OffFSELog 8
 
 /* level <= 2 ("fast"): the short table only, walk ranges of 512 bytes, recent offsets tried on 8 positions;
- * level 3 ("double"): short + long table, ranges of 256 bytes, recent offsets tried on 4 positions;
+ * level 3 ("double"): short + long table, ranges of 256 bytes, recent offsets tried on 4 positions, a step's window is 2 aligned groups
+ * of 8 positions (levels <= 2: 4 groups);
  * level >= 4: as 3 with LOOK 8 and recent offsets on 8 positions. */
-typedef struct { int useLong; int look; int walkLog; int repWin; } EParams;
+typedef struct { int useLong; int look; int walkLog; int repWin; int windowGroups; } EParams;
 static EParams paramsForLevel(int level)
 {
     EParams p;
     p.useLong = level >= 3; p.look = (level <= 3) ? 4 : 8; p.walkLog = (level <= 2) ? 9 : 8; p.repWin = (level == 3) ? 4 : 8;
+    p.windowGroups = (level <= 2) ? 4 : 2;      /* = lanes of a GPU walker: a range of 512 bytes gets 4 lanes, one of 256 bytes 2 (the same threads per byte) */
     return p;
 }
 
@@ -567,15 +569,13 @@ static U32 matchLen(const BYTE *src, U32 a, U32 b, U32 limit)   /* common prefix
 
 /* stage 2 : one walk range [start, end), walked by one walker on the GPU; matches may run on to `limit` (> end: the
  * next ranges' territory, given back by the stitch below).
- * Each step looks at the positions from ip to the end of the second aligned group of 8 (9 .. 16 positions: what the GPU walker's two
- * lanes load of the candidate distances, 16 bytes each).  A position holds a candidate if (in this order of preference)
+ * Each step looks at the positions from ip to the end of the windowGroups-th aligned group of 8 (2 groups: 9 .. 16 positions; 4 groups:
+ * 25 .. 32: what the GPU walker's lanes load of the candidate distances, 16 bytes each).  A position holds a candidate if (in this order of preference)
  * one of the walker's two recent offsets repeats 4 bytes there (only the first repWin positions of the window are
  * tried, and only while ip lies at least that offset inside the unit) or stage 1 left a distance.  The first LOOK such
  * positions are scored: forward match length (the score counts at most FCAP bytes), backward extension into the
  * pending literals (at most BCAP bytes), offset cost (none for a recent offset), literals skipped.  The best one (the
  * earliest among equals) becomes a sequence with its full forward length. */
-#define WINDOW_GROUPS 2u           /* = lanes of a GPU walker (ZS_WALK_LPW): each loads one group's candidate distances, 16 bytes */
-#define WINDOW (8u * WINDOW_GROUPS)
 #define FCAP 8u
 #define BCAP 4u
 #define REPMIN 4u
@@ -583,11 +583,11 @@ static U32 walkRange(Work *w, const BYTE *src, U32 n, U32 start, U32 end, U32 li
 {
     U32 ip = start, anchor = start, nseq = 0, rep0 = 0, rep1 = 0;
     U32 const hashable = (n >= 8) ? n - 7 : 0;
-    U32 const look = (U32)prm->look, repWin = (U32)prm->repWin;
+    U32 const look = (U32)prm->look, repWin = (U32)prm->repWin, window = 8u * (U32)prm->windowGroups;
     U32 const scanEnd = (end < hashable) ? end : hashable;     /* candidates start below this */
     while (ip < scanEnd) {
         int bestGain = 0, have = 0; U32 bestQ = 0, bestFwd = 0, bestBack = 0, bestOff = 0, q, seen = 0;
-        U32 const wend = ((ip & ~7u) + WINDOW < scanEnd) ? (ip & ~7u) + WINDOW : scanEnd;   /* WINDOW_GROUPS aligned groups of 8 positions: 9 .. 16 positions */
+        U32 const wend = ((ip & ~7u) + window < scanEnd) ? (ip & ~7u) + window : scanEnd;   /* windowGroups aligned groups of 8 positions */
         int const try0 = rep0 && ip >= rep0, try1 = rep1 && ip >= rep1;
         for (q = ip; q < wend && seen < look; q++) {
             U32 off = 0, fwd, back = 0; int isRep = 0, gain;

@@ -229,15 +229,14 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
 // Last, the records that count are packed, 1 KiB of source (an OUTPUT RANGE = 1024 / R walk ranges) at a time, into the layout the
 // entropy kernels read: seqAll[block][64 output ranges][256 records] + hdrAll (nseq, trailing, litSum, first = 0).
 // ---------------------------------------------------------------------------------------------
-#ifndef ZS_WALK_LPW
-#define ZS_WALK_LPW 2               // lanes per walker = aligned groups of 8 positions a step looks at (oracle: WINDOW_GROUPS)
-#endif
 #ifndef ZS_WALK_MINW
 #define ZS_WALK_MINW 1             // waves per SIMD the small-unit kernel is compiled for (register budget)
 #endif
-// threads per unit: a walker per walk range (64 KiB in ranges of 256 bytes: 256 walkers of 2 lanes; ranges of 512 bytes at levels <= 2: half of that)
-#define ZS_WALK_THREADS(BIG, WLOG) ((((BIG) ? ZS_UNIT_MAX : ZS_BLOCK_MAX) >> (WLOG)) * ZS_WALK_LPW)
-#define ZS_WALK_KERNEL(LOOK, REPW, BIG, WLOG) k_lz_walk<ZS_WALK_LPW, LOOK, REPW, BIG, ZS_WALK_THREADS(BIG, WLOG)>
+// lanes per walker = aligned groups of 8 positions a step looks at (oracle: windowGroups): 2 for walk ranges of 256 bytes, 4 for ranges of 512
+// bytes (levels <= 2) - either way a walker per walk range and 512 threads per 64 KiB
+#define ZS_WALK_LPW(WLOG) ((WLOG) >= 9 ? 4 : 2)
+#define ZS_WALK_THREADS(BIG, WLOG) ((((BIG) ? ZS_UNIT_MAX : ZS_BLOCK_MAX) >> (WLOG)) * ZS_WALK_LPW(WLOG))
+#define ZS_WALK_KERNEL(LOOK, REPW, BIG, WLOG) k_lz_walk<ZS_WALK_LPW(WLOG), LOOK, REPW, BIG, ZS_WALK_THREADS(BIG, WLOG)>
 #define ZS_WALK_FRONT 16u          // LDS bytes in front of the unit (backward reads near position 0)
 #define ZS_WALK_TAIL  144u         // zero bytes behind the unit (forward reads near the end)
 // exchange buffer (16 bytes a lane) + source + queue head + a byte a lane (BIG: bit 16 of the distances)
