@@ -487,3 +487,34 @@ def test_decode_literal_spread_across_windows(codec):
     for i, (f, c, (sz, got)) in enumerate(zip(frames, chunks, res)):
         assert O.decompress(f, len(c)) == c
         assert sz == len(c) and got == c, (i, len(c), sz)
+
+
+def _long_match_inputs():
+    """data whose matches are far longer than a walk range: found piecewise by consecutive walkers, joined by the stitch"""
+    rng = np.random.default_rng(5)
+    per = rng.integers(0, 256, 1000, dtype=np.uint8).tobytes()
+    z = bytearray(300000)
+    for i in rng.integers(0, len(z), 100):
+        z[int(i)] = 1 + int(rng.integers(0, 255))
+    base = rng.integers(32, 127, 40000, dtype=np.uint8).tobytes()
+    return {
+        "period1000_64k": (per * 66)[:65536], "period1000_128k": (per * 132)[:131072], "period1000_300k": (per * 301)[:300000],
+        "zeros_noise_300k": bytes(z), "zeros_noise_64k": bytes(z[:65536]),
+        "repeat_40k_x3": base * 3, "repeat_shifted": base[:30000] + b"x" + base[:30000] + b"yz" + base[5:29000],
+        "period7_100k": (b"abcdefg" * 15000)[:100000], "period300_edge": (bytes(rng.integers(0, 256, 300, dtype=np.uint8)) * 500)[:131071],
+    }
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 3, 4])
+def test_long_matches_are_joined_as_in_the_oracle(codec, level):
+    """period-1000 data, zeros with sparse noise, long repeats: HIP == oracle E byte for byte, frames decode; the joined matches keep the
+    sequence count small (a 64 KiB block of period-1000 data is a handful of sequences, not one per walk range)"""
+    inputs = _long_match_inputs()
+    names = sorted(inputs)
+    frames = _compress_many(codec, [inputs[k] for k in names], level)
+    for k, f in zip(names, frames):
+        data = inputs[k]
+        assert f == O.compress(data, level), k
+        assert O.decompress(f, len(data)) == data, k
+    assert len(frames[names.index("period1000_64k")]) < 1400                   # 1000 literal bytes + one long match (round 2's parse: 1.14 x libzstd here)
