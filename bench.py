@@ -476,7 +476,8 @@ def main():
                           "chunk_bytes": cs, "level": args.level, "parallelism": f"chunks sharded over {world} GPU(s), no collective in the data path"},
                "ratio": round(ratio, 4), "ratio_vs_libzstd_same_level": ratio_vs_zstd,
                "hbm_read_roofline_frac": round(total_in * args.steps / elapsed / 1e9 / HBM_PEAK_GBS, 5),
-               "roofline": roofline, "cpu_baseline": cpu, "datagen_s": round(gen_s, 2)}
+               "roofline": roofline, "cpu_baseline": cpu, "datagen_s": round(gen_s, 2),
+               "library": bc.L.zsmi_versionString().decode()}
         if sustained:
             out["sustained"] = sustained
         if decode:

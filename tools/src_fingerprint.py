@@ -1,21 +1,15 @@
 #!/usr/bin/env python3
-"""sha256 over the kernel sources (zstandard_amd/csrc) with comments and white space removed: profiles/*_traffic.json carries the
-fingerprint of the code it was measured at, bench.py reports the traffic only when HEAD's kernels have the same one."""
-import hashlib, os, re, sys
+"""sha256 over the kernel sources (zstandard_amd/csrc) with comments and white space removed: the library carries the fingerprint it was built
+from (zsmi_versionString), profiles/*_traffic.json the one it was measured at, bench.py reports the traffic only when they agree."""
+import os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
 
 
 def fingerprint(root=ROOT):
-    h = hashlib.sha256()
-    d = os.path.join(root, "zstandard_amd", "csrc")
-    for f in sorted(os.listdir(d)):
-        text = open(os.path.join(d, f), "r", errors="replace").read()
-        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-        text = re.sub(r"//[^\n]*", "", text)
-        text = re.sub(r"\s+", "", text)
-        h.update(f.encode()); h.update(text.encode())
-    return h.hexdigest()[:16]
+    from zstandard_amd import _lib
+    return _lib.source_fingerprint()
 
 
 if __name__ == "__main__":

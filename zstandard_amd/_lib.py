@@ -10,13 +10,42 @@ LIB_PATH = os.environ.get("ZSMI_LIB_FILE") or os.path.join(_HERE, "lib", "libzsm
 CSRC = os.path.join(_HERE, "csrc")
 
 
+def source_fingerprint():
+    """sha256 over the kernel sources (comments and white space do not count): the library carries the one it was built from
+    (zsmi_versionString), profiles/*_traffic.json the one it was measured at"""
+    import hashlib, re
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "zsmi.h")]:
+        text = open(os.path.join(CSRC, f), "r", errors="replace").read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        text = re.sub(r"//[^\n]*", "", text)
+        text = re.sub(r"\s+", "", text)
+        h.update(f.encode()); h.update(text.encode())
+    return h.hexdigest()[:16]
+
+
+def built_fingerprint(path=None):
+    """the fingerprint inside a built library (None: no library, or one from before the fingerprint existed)"""
+    path = path or LIB_PATH
+    if not os.path.exists(path):
+        return None
+    import re
+    m = re.search(rb"sources ([0-9a-f]{16}|unknown)\)", open(path, "rb").read())
+    return m.group(1).decode() if m else None
+
+
 def build(force=False):
-    srcs = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(_HERE, "..", "include", "zsmi.h")]
-    if not force and os.path.exists(LIB_PATH) and all(os.path.getmtime(s) <= os.path.getmtime(LIB_PATH) for s in srcs):
+    """hipcc --offload-arch=gfx950 -> the in-tree library.  Rebuilds when the library is missing or was built from other sources than the
+    tree holds (the fingerprint inside it differs: a library that travelled with the snapshot is checked, not trusted; file times say
+    nothing after a copy)."""
+    fp = source_fingerprint()
+    if not force and not os.environ.get("ZSMI_LIB_FILE") and os.path.exists(LIB_PATH) and built_fingerprint() == fp:
         return LIB_PATH
+    if os.environ.get("ZSMI_LIB_FILE") and os.path.exists(LIB_PATH) and not force:
+        return LIB_PATH                                                # a variant build named by hand: left alone
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", "-o", LIB_PATH, os.path.join(CSRC, "zsmi_api.hip")]
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", '-DZSMI_SOURCE_FP="%s"' % fp, "-o", LIB_PATH, os.path.join(CSRC, "zsmi_api.hip")]
     cmd += os.environ.get("ZSMI_HIPCC_FLAGS", "").split()          # kernel-shape experiments (-DZS_CAND_G=4 ...)
     if DEBUG:
         cmd.append("-DZSMI_DEBUG_HOOKS")

@@ -49,7 +49,12 @@ extern "C" const char *zsmi_getErrorName(size_t code)
     default: return "Unspecified error code";
     }
 }
-extern "C" const char *zsmi_versionString(void) { return "zsmi 0.1 (gfx950 HIP kernels; zstd frame format, decoder semantics of epam/Zstandard = zstd v1.3.4)"; }
+// ZSMI_SOURCE_FP: fingerprint of zstandard_amd/csrc the library was built from (zstandard_amd/_lib.py passes it; a library that ships with the
+// sources is rebuilt when they differ, so a measurement can name the code it ran)
+#ifndef ZSMI_SOURCE_FP
+#define ZSMI_SOURCE_FP "unknown"
+#endif
+extern "C" const char *zsmi_versionString(void) { return "zsmi 0.3 (gfx950 HIP kernels; zstd frame format, decoder semantics of epam/Zstandard = zstd v1.3.4; sources " ZSMI_SOURCE_FP ")"; }
 
 extern "C" size_t zsmi_compressBound(size_t srcSize)
 {
