@@ -22,16 +22,17 @@ typedef struct {
     int estOff;       /* 1: the estimate counts the offset's cost */
     int initRep;      /* 1: a range starts with rep0 = the distance of the nearest candidate position below its start */
     int bcap, fcap;   /* backward cap, forward score cap */
+    int repMode;      /* 0: recent offsets tried on the first repwin positions; 1: only where stage 1 left a candidate; 2: no probe: a candidate whose distance IS a recent offset scores as one */
     int walign;       /* 1: the window ends at an aligned group of 8: (ip & ~7) + window */
     int estRun;       /* 1: the estimate adds the run of candidate positions that follows (cap FCAP) */
 } WP;
-static WP P = { 10, 16384, 0, 0, 64, 8, 0, 0, 0, 0, 0, 8, 5, 4, 5, 1, 1, 0, 8, 8, 0, 0 };
+static WP P = { 10, 16384, 0, 0, 64, 8, 0, 0, 0, 0, 0, 8, 5, 4, 5, 1, 1, 0, 8, 8, 0, 0, 0 };
 static BYTE wlLong[UNIT_MAX];
 static struct { unsigned long long steps, emptySteps, scored, emitted, kept, extBytes, ranges, merged; } S;
 void wl_set(const char *k, int v)
 {
 #define K(name) if (!strcmp(k, #name)) { P.name = v; return; }
-    K(walkLog) K(crossMax) K(look) K(merge) K(window) K(repwin) K(longEven) K(carryRep) K(skipFirst) K(lazyMax) K(approx) K(estLong) K(estShort) K(estRep) K(estSkip) K(useBack) K(estOff) K(initRep) K(bcap) K(fcap) K(walign) K(estRun)
+    K(walkLog) K(crossMax) K(look) K(merge) K(window) K(repwin) K(longEven) K(carryRep) K(skipFirst) K(lazyMax) K(approx) K(estLong) K(estShort) K(estRep) K(estSkip) K(useBack) K(estOff) K(initRep) K(bcap) K(fcap) K(repMode) K(walign) K(estRun)
 #undef K
     fprintf(stderr, "unknown %s\n", k); abort();
 }
@@ -110,12 +111,13 @@ static U32 wlWalk(Work *w, const BYTE *src, U32 n, U32 start, U32 end, U32 limit
         } else
         for (q = ip; q < wend && seen < look; q++) {
             U32 off = 0, fwd, back = 0; int isRep = 0, gain;
-            if (q < ip + (U32)P.repwin && q + 4 <= limit) {
+            if (P.repMode == 0 || (P.repMode == 1 && w->dist[q])) if (q < ip + (U32)P.repwin && q + 4 <= limit) {
                 if (rep0 && ip >= rep0 && rd32(src + q) == rd32(src + q - rep0)) { off = rep0; isRep = 1; }
                 else if (rep1 && ip >= rep1 && rd32(src + q) == rd32(src + q - rep1)) { off = rep1; isRep = 1; }
             }
             if (!off) off = w->dist[q];
             if (!off) continue;
+            if (P.repMode == 2 && (off == rep0 || off == rep1)) isRep = 1;
             seen++; S.scored++;
             fwd = matchLen(src, q, q - off, limit);
             if (fwd < (isRep ? REPMIN : MINMATCH)) continue;

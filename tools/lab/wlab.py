@@ -36,7 +36,7 @@ zs = {}
 for name, data in cor.items():
     zs[name] = sum(len(O.zstd_compress(data[i:i + cs], level)) for i in range(0, len(data), cs))
 print("%-24s" % "set" + "".join("%8s" % k[:7] for k in cor) + "   worst | steps/KiB scored/KiB seq/KiB kept/KiB merged/KiB")
-DEFAULTS = dict(walkLog=10, crossMax=16384, look=0, merge=0, window=64, repwin=8, longEven=0, carryRep=0, skipFirst=0, approx=0, estLong=8, estShort=5, estRep=4, estSkip=5, useBack=1, estOff=1, estRun=0, initRep=0, bcap=8, fcap=8, walign=0)
+DEFAULTS = dict(walkLog=10, crossMax=16384, look=0, merge=0, window=64, repwin=8, longEven=0, carryRep=0, skipFirst=0, approx=0, estLong=8, estShort=5, estRep=4, estSkip=5, useBack=1, estOff=1, estRun=0, initRep=0, bcap=8, fcap=8, walign=0, repMode=0)
 out = ctypes.create_string_buffer(cs + 4096)
 for spec in a.sets or ["base:"]:
     nm, _, kv = spec.partition(":")
