@@ -405,6 +405,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
         const uint32_t nRanges = (n + R - 1) >> rangeLog;
         bool active = false, more = true;                                        // walking a range / the queue may hold more
         uint32_t r = 0, ip = 0, anchor = 0, scanEnd = 0, limit = 0, rep0 = 0, rep1 = 0, nseq = 0, lastOff = 0, recBase = 0, blockBase = 0;
+        uint2 heldRec = make_uint2(0, 0);                                        // the odd record waiting for its pair
         const uint32_t perBlockLog = 16u - rangeLog;                             // walk ranges per block
         auto resIndex = [&](uint32_t rr) { return (rr >> perBlockLog) * ZS_RES_PER_BLOCK + (rr & ((1u << perBlockLog) - 1u)); };
         // distances of the group (ip >> 3) + sub, requested as soon as ip is known: 16 bytes a lane straight into the lane's slot of the
@@ -569,9 +570,17 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
             // the record leaves (the walker's first lane, a step that took a match); the next step's distances are requested (walkers with a
             // step to come): the memory system takes a wavefront's small requests one by one, and the kernel's time follows their number
             // (every lane loading and storing every step, walkers at rest included: 4 requests a walker step, 0.95 ms; profiles/r3_walk_*)
-            if (took && sub == 0) recs[recBase + nseq - 1] = make_uint2((bq - bback - blockBase) | ((bback + bfwd) << 17), boff | (recLl << 17));    // start: position in its block; offset, literals
+            // (records leave in pairs, 16 aligned bytes: half the write requests; a range's odd last one alone)
+            if (took) {
+                const uint2 rec = make_uint2((bq - bback - blockBase) | ((bback + bfwd) << 17), boff | (recLl << 17));    // start: position in its block; offset, literals
+                if (nseq & 1u) heldRec = rec;
+                else if (sub == 0) *reinterpret_cast<uint4 *>(recs + recBase + nseq - 2) = make_uint4(heldRec.x, heldRec.y, rec.x, rec.y);
+            }
             if (active && ip >= scanEnd) {
-                if (sub == 0) res[resIndex(r)] = make_uint4(nseq, nseq ? anchor - blockBase : 0u, lastOff, 0u);
+                if (sub == 0) {
+                    if (nseq & 1u) recs[recBase + nseq - 1] = heldRec;
+                    res[resIndex(r)] = make_uint4(nseq, nseq ? anchor - blockBase : 0u, lastOff, 0u);
+                }
                 active = false;
             }
             if (active) loadGroup(ip);
