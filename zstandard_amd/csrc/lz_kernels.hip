@@ -641,12 +641,24 @@ k_lz_stitch(const ZsBlockDesc *__restrict__ blocks, const uint2 *__restrict__ re
         if (ns && own >= rs) {
             if (le <= own) f = ns;
             else {
-                uint32_t lo = 0, hi = ns - 1;                                    // the first record that ends above own is in [lo, hi]
-                while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; const uint32_t x = rp[mid].x; if ((x & 0x1FFFFu) + (x >> 17) > own) hi = mid; else lo = mid + 1; }
-                f = lo;
-                uint2 rec = rp[f];
-                uint32_t st = rec.x & 0x1FFFFu, en = st + (rec.x >> 17);
-                if (st < own && en - own < ZS_MINMATCH) { f++; if (f < ns) { rec = rp[f]; st = rec.x & 0x1FFFFu; en = st + (rec.x >> 17); } }   // too little left of a straddling one (the next starts above own)
+                // the first record that ends above own.  The match that crosses into a range mostly covers none or one of its records: the
+                // first two come with one 16-byte load (the slots are 16-byte aligned), a search over the rest only if both end at or below own
+                const uint4 r01 = *reinterpret_cast<const uint4 *>(rp);          // (a second record that is not there reads as whatever: only looked at if ns > 1)
+                auto endOf = [](uint32_t x) { return (x & 0x1FFFFu) + (x >> 17); };
+                uint2 rec = make_uint2(r01.x, r01.y), nxt = make_uint2(r01.z, r01.w);
+                bool haveNxt = ns > 1;
+                if (endOf(r01.x) > own) f = 0;
+                else if (ns > 1 && endOf(r01.z) > own) { f = 1; rec = nxt; haveNxt = false; }
+                else {
+                    uint32_t lo = 2, hi = ns - 1;                                // (le > own: the last record ends above own, ns > 2 here)
+                    while (lo < hi) { const uint32_t mid = (lo + hi) >> 1; if (endOf(rp[mid].x) > own) hi = mid; else lo = mid + 1; }
+                    f = lo; rec = rp[f]; haveNxt = false;
+                }
+                uint32_t st = rec.x & 0x1FFFFu, en = endOf(rec.x);
+                if (st < own && en - own < ZS_MINMATCH) {                        // too little left of a straddling one (the next starts above own)
+                    f++;
+                    if (f < ns) { rec = haveNxt ? nxt : rp[f]; st = rec.x & 0x1FFFFu; en = endOf(rec.x); }
+                }
                 fStart = max(st, own); fEnd = en; fOff = rec.y & 0x1FFFFu;
             }
         }
