@@ -385,8 +385,12 @@ def main():
             bc.pack_device(d_dst.data_ptr(), doffs, d_sizes.data_ptr(), n, d_packed.data_ptr(), d_poffs.data_ptr())
             torch.cuda.synchronize()
             return d_packed, d_sizes.cpu().numpy().astype(np.uint32)
-        best, secs, out_all, goffs, gsz = io_inclusive_leg(torch, dist, rank, world, all_sizes, g_src, compress_shard, "cuda", barrier)
-        if rank == 0:
+        try:
+            best, secs, out_all, goffs, gsz = io_inclusive_leg(torch, dist, rank, world, all_sizes, g_src, compress_shard, "cuda", barrier)
+        except Exception as e:                                             # the headline does not depend on this leg: say what happened and go on
+            best = None
+            io_inclusive = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+        if rank == 0 and best is not None:
             import _oracle as O
             hostf = out_all.cpu().numpy(); ok = True; checked = 0
             for r in range(world):                                             # frames of every rank's shard decode to the chunks they were made from
