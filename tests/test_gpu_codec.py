@@ -518,3 +518,21 @@ def test_long_matches_are_joined_as_in_the_oracle(codec, level):
         assert f == O.compress(data, level), k
         assert O.decompress(f, len(data)) == data, k
     assert len(frames[names.index("period1000_64k")]) < 1400                   # 1000 literal bytes + one long match (round 2's parse: 1.14 x libzstd here)
+
+
+@pytest.mark.parametrize("level", [1, 3])
+def test_units_of_one_repeated_byte_skip_the_parse(codec, level):
+    """k_lz_candidates and k_lz_walk leave a unit of one repeated byte alone (its blocks are RLE blocks whatever the parse says):
+    the frames are oracle E's for such units, for units that miss the condition by one byte anywhere, and for their neighbours in the batch"""
+    rng = np.random.default_rng(11)
+    text = D.zipf_log(70000, seed_lo=21).tobytes()
+    chunks = [b"\x00" * 65536, b"\xff" * 65536, b"a" * 131072, b"a" * 65536 + b"b" * 65536, b"q" * 65520, b"q" * 65521, b"z" * 16, b"z" * 15,
+              b"\x00" * 65535 + b"\x01", b"\x01" + b"\x00" * 65535, b"\x00" * 32768 + b"\x01" + b"\x00" * 32767, b"\x00" * 131071 + b"\x01",
+              b"\x00" * 65536 + b"\x01" + b"\x00" * 65535, text, b"k" * 200000, b"k" * 196608]
+    for _ in range(8):                                                            # one differing byte at a random place
+        c = bytearray(b"\x07" * 65536); c[int(rng.integers(0, 65536))] = 8; chunks.append(bytes(c))
+    frames = _compress_many(codec, chunks, level)
+    for i, (c, f) in enumerate(zip(chunks, frames)):
+        assert f == O.compress(c, level), i
+        assert O.decompress(f, len(c)) == c, i
+    assert len(frames[0]) < 16 and len(frames[2]) < 24

@@ -76,6 +76,28 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     const uint32_t hashable = (n >= 8) ? n - 7 : 0;                   // positions [0, hashable) have 8 bytes
     const uint32_t nGroups = (hashable + GP - 1) / GP;
     if (nGroups == 0) return;
+    // A unit of one repeated byte needs no candidates: the walk kernel tests for exactly this (same condition) and skips its walk, the
+    // blocks become RLE blocks.  Ordinary data fails the test on its first 16 bytes.
+    if (n >= 16 && (n & 15u) == 0) {
+        uint4 f;
+        __builtin_memcpy(&f, s, 16);
+        const uint32_t splat = (f.x & 0xFFu) * 0x01010101u;
+        if (((f.x ^ splat) | (f.y ^ splat) | (f.z ^ splat) | (f.w ^ splat)) == 0) {     // (the same for every thread)
+            if (threadIdx.x == 0) candLds[0] = 0;
+            __syncthreads();
+            uint32_t mixed = 0;
+            for (uint32_t i = threadIdx.x * 16u; i < n && !mixed; i += ZS_CAND_WAVES(NT) * 64u * 16u) {
+                uint4 v;
+                __builtin_memcpy(&v, s + i, 16);
+                mixed = (v.x ^ splat) | (v.y ^ splat) | (v.z ^ splat) | (v.w ^ splat);
+            }
+            if (mixed) candLds[0] = 1u;
+            __syncthreads();
+            const bool uniform = candLds[0] == 0;
+            __syncthreads();                                             // (the word belongs to a table the owners clear next)
+            if (uniform) return;
+        }
+    }
     // a position that is not inserted (behind the hashable ones) exchanges with a word of its owner lane's own behind the ring;
     // index relative to the owner's table, < 2^16
     const uint32_t dummyBase = ((uint32_t)(NT - tab) << TLOG) + RING + tab * 64u;
@@ -363,14 +385,17 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
 #endif
 
     // ---- stage the unit ----
+    uint32_t mixed = 0;                                                          // some byte of the unit differs from its first byte
     if (tid < ZS_WALK_FRONT / 4) reinterpret_cast<uint32_t *>(walkLds + SRC - ZS_WALK_FRONT)[tid] = 0;
-    if (tid == 0) *queue = 0;
+    if (tid == 0) { queue[0] = 0; queue[1] = 0; }
+    __syncthreads();
     {
         // whole 16-byte pieces: the loads of a thread are issued together (a load behind a branch, followed by its LDS
         // store, would wait out one memory round trip per piece); then the partial piece and the zero tail
         constexpr uint32_t PER = (CAP / 16 + NT - 1) / NT;                       // pieces per thread
         const uint32_t nFull = n & ~15u;
         uint4 v[PER];
+        const uint32_t splat = (n ? (uint32_t)s[0] : 0u) * 0x01010101u;
         #pragma unroll
         for (uint32_t k = 0; k < PER; k++) {
             const uint32_t i = (tid + k * NT) * 16;
@@ -382,7 +407,10 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
         for (uint32_t k = 0; k < PER; k++) {
             const uint32_t i = (tid + k * NT) * 16;
             if (i + 16 <= nFull) *reinterpret_cast<uint4 *>(ls + i) = v[k];
+            // (clamped pieces hold piece 0: comparing them too is harmless)
+            mixed |= (v[k].x ^ splat) | (v[k].y ^ splat) | (v[k].z ^ splat) | (v[k].w ^ splat);
         }
+        if (n != nFull || n < 16) mixed = 1;                                     // (a ragged unit is walked as any other: the check is a short cut, not a decision)
         for (uint32_t i = nFull + tid * 16; i < n + ZS_WALK_TAIL; i += NT * 16) {
             uint4 w = make_uint4(0, 0, 0, 0);
             if (i < n) {
@@ -397,7 +425,15 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
     if (n) return;                                                               // timing aid: staging only
 #endif
     const uint32_t hashable = (n >= 8) ? n - 7 : 0;
+    // A unit of one repeated byte becomes RLE blocks whatever the parse says (the literals kernel decides that from the bytes, as
+    // zso_encoder.c:833-836 does before parsing): its walk -- the slowest there is, every match running to the crossing limit -- is skipped.
+    if (mixed) queue[1] = 1u;                                                    // (no __syncthreads_or: hipcc gives it static LDS of its own, which moves the dynamic part this kernel addresses by hand)
     __syncthreads();
+    if (queue[1] == 0) {
+        const uint32_t nRanges = (n + R - 1) >> rangeLog, perBlockLog = 16u - rangeLog;
+        for (uint32_t r = tid; r < nRanges; r += NT) res[(r >> perBlockLog) * ZS_RES_PER_BLOCK + (r & ((1u << perBlockLog) - 1u))] = make_uint4(0, 0, 0, 0);
+        return;
+    }
     WPROF_STAMP(0)
 
     // ---- the walk ----
