@@ -10,7 +10,8 @@ from zstandard_amd import BatchCodec
 import _data as D, _oracle as O
 
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=57344); ap.add_argument("--chunk", type=int, default=32768)
-ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2); a = ap.parse_args()
+ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--times-only", action="store_true", help="per-kernel times, no output check, no CPU leg (timing-aid builds: ZSMI_LIB_FILE)"); a = ap.parse_args()
 n, cs = a.frames, a.chunk
 host = D.zipf_log(n * cs, threads=32)
 bc = BatchCodec(0, torch.cuda.current_stream().cuda_stream)
@@ -28,6 +29,9 @@ torch.cuda.synchronize(); bc.enable_timing(True); t0 = time.perf_counter()
 for _ in range(a.steps): step()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 kt = bc.kernel_times()
+if a.times_only:
+    print(os.environ.get("ZSMI_LIB_FILE", "library"), {k: round(v[0] / a.steps * 1e3, 3) for k, v in kt.items()}, "step %.3f ms" % (dt / a.steps * 1e3))
+    sys.exit(0)
 assert (d_osz.cpu().numpy() == cs).all()
 assert torch.equal(d_out, d_src), "decoded bytes differ from the input"
 comp = int(fsz.astype(np.uint64).sum())

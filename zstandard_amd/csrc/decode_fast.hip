@@ -457,30 +457,103 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
 // execTileT in decode_kernels.hip: matches whose source ends before the tile's first output byte side by side, then the matches
 // that read this tile's own output in groups none of whose members reads what the group writes.
 // ---------------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, uint32_t off, uint8_t *dstBase, uint32_t tileStart)
+// Between a store and a later load of the same bytes by the SAME wavefront: with ZS_EXEC_FENCE the wavefront waits until its stores are
+// acknowledged (a workgroup-scope fence: s_waitcnt vmcnt(0)); without, only the compiler is kept from reordering, and the order is the
+// memory pipeline's (a wavefront's vector-memory instructions reach the L1 / L2 in issue order).
+#ifndef ZS_EXEC_NOFENCE
+#define ZS_EXEC_ORDER() wave_mem_sync()
+#else
+#define ZS_EXEC_ORDER() wave_sync()
+#endif
+__device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, uint32_t off, uint8_t *dstBase, uint32_t tileStart, uint32_t safeEnd, uint32_t *lds3)
 {
+    // The kernel is bound by the NUMBER of vector-memory instructions its wavefronts issue (tools/probe/vmem_rate.hip: ~7 ns of CU time per
+    // instruction with a few lanes active, ~19 ns with all 64; profiles/r3_c_decode_pmc_summary.csv: the texture addresser busy all the
+    // kernel's time), so every piece below is an instruction only if some lane needs it, and short matches share the first load.
     const uint32_t lane = (uint32_t)zs_lane();
-    const uint32_t msrc = mdst - off;
+    uint32_t msrc = mdst - off;
+#ifndef ZS_EXEC_NOREDIRECT
+    // A match that reads this tile's own output waits for the matches that write it: a memory round trip per level of that dependence
+    // (measured on the bench frames: 24 such matches a tile, 8.7 rounds).  Most of those sources lie INSIDE the destination of one earlier
+    // match of the tile, whose bytes are a copy themselves: the reader takes them from that match's source instead (and so on: every lane
+    // follows the current sources of the others, a few rounds of pointer jumping over the 64 sequences in LDS).  What is left reads across
+    // a sequence border (12 matches a tile, 2 levels).  Matches with overlapping source and destination neither move nor are read through.
+    {
+        uint32_t *dstArr = lds3, *endArr = lds3 + 64, *srcArr = lds3 + 128;
+        const bool periodic = off < ml;
+        dstArr[lane] = ml ? mdst : 0xFFFFFFFFu;                          // ascending over the lanes; lanes without a sequence behind every position
+        endArr[lane] = (ml && !periodic) ? mdst + ml : 0u;               // 0: not to be read through
+        bool act = ml && !periodic && msrc >= tileStart;
+        #pragma unroll 1
+        for (uint32_t round = 0; round < 4 && __ballot(act); round++) {
+            srcArr[lane] = msrc;
+            wave_sync();
+            if (act) {
+                uint32_t pos = 0;
+                #pragma unroll
+                for (uint32_t step = 32; step >= 1; step >>= 1) if (dstArr[pos + step] <= msrc) pos += step;
+                const uint32_t d0 = dstArr[pos];
+                act = d0 <= msrc && msrc + ml <= endArr[pos];            // inside that match (pos < lane: its destination starts in front of this source)
+                if (act) { msrc = srcArr[pos] + (msrc - d0); act = msrc >= tileStart; }
+            }
+            wave_sync();
+        }
+    }
+#endif
+    const uint32_t effOff = mdst - msrc;                                 // (>= off: the same bytes from further back)
     const bool indep = ml && (msrc + ml <= tileStart);
-    auto copyShort = [&]() {                                            // <= 32 bytes, source and destination do not overlap
-        if (ml >= 8) {
-            uint64_t v[4]; const uint32_t lastAt = ml - 8;
-            #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) v[k] = zs_load64(dstBase + msrc + min(8 * k, lastAt));
-            #pragma unroll
-            for (uint32_t k = 0; k < 4; k++) if (8 * k < ml) __builtin_memcpy(dstBase + mdst + min(8 * k, lastAt), &v[k], 8);
-        } else if (ml >= 4) {
-            const uint32_t x0 = zs_load32(dstBase + msrc), x1 = zs_load32(dstBase + msrc + ml - 4);
-            __builtin_memcpy(dstBase + mdst, &x0, 4); __builtin_memcpy(dstBase + mdst + ml - 4, &x1, 4);
-        } else for (uint32_t j = 0; j < ml; j++) dstBase[mdst + j] = dstBase[msrc + j];
+    // matches of <= 32 bytes whose source and destination do not overlap, a lane each: 8-byte pieces k = 0..3 at min(8 k, ml - 8) (the last one
+    // ends with the match); below 8 bytes one 8-byte load (if it stays inside the item's buffer) and two overlapping 4-byte stores
+    auto copyShort = [&](bool mine) {
+        const bool wide = mine && (ml >= 8 || msrc + 8 <= safeEnd);
+        const uint32_t lastAt = (ml >= 8) ? ml - 8 : 0u;
+        uint64_t v0 = 0, v1 = 0, v2 = 0, v3 = 0;
+        if (wide) v0 = zs_load64(dstBase + msrc);
+        if (mine && ml > 8) v1 = zs_load64(dstBase + msrc + min(8u, lastAt));
+        if (mine && ml > 16) v2 = zs_load64(dstBase + msrc + min(16u, lastAt));
+        if (mine && ml > 24) v3 = zs_load64(dstBase + msrc + lastAt);
+        if (mine && ml >= 8) __builtin_memcpy(dstBase + mdst, &v0, 8);
+        if (mine && ml > 8) __builtin_memcpy(dstBase + mdst + min(8u, lastAt), &v1, 8);
+        if (mine && ml > 16) __builtin_memcpy(dstBase + mdst + min(16u, lastAt), &v2, 8);
+        if (mine && ml > 24) __builtin_memcpy(dstBase + mdst + lastAt, &v3, 8);
+        if (wide && ml < 8) {
+            if (ml >= 4) {
+                const uint32_t a = (uint32_t)v0, b = (uint32_t)(v0 >> (8u * (ml - 4u)));
+                __builtin_memcpy(dstBase + mdst, &a, 4); __builtin_memcpy(dstBase + mdst + ml - 4, &b, 4);
+            } else for (uint32_t j = 0; j < ml; j++) dstBase[mdst + j] = (uint8_t)(v0 >> (8u * j));
+        }
+        if (mine && !wide) for (uint32_t j = 0; j < ml; j++) dstBase[mdst + j] = dstBase[msrc + j];    // (a short match at the very end of the buffer)
     };
-    if (indep && ml <= 32) copyShort();
+    // one match of > 32 bytes by the whole wavefront, 8 bytes a lane.  Without overlap: pieces at min(8 j, ml - 8).  With overlap (offset < length:
+    // the source is the period of `off` bytes in front of the destination, ZStdDecompress.cs:1335-1352 copies it byte by byte): a piece is 8 bytes
+    // of that period from phase (8 j) % off, wrapped once - two loads - when the period is >= 8 bytes; a shorter period goes byte by byte.
+    auto copyLong = [&](uint32_t m2, uint32_t o2, uint32_t s2, uint32_t d2) {
+        if (o2 >= m2) {
+            for (uint32_t j = lane * 8u; j < m2; j += 512u) { const uint32_t jj = min(j, m2 - 8u); const uint64_t v = zs_load64(dstBase + s2 + jj); __builtin_memcpy(dstBase + d2 + jj, &v, 8); }
+        } else if (o2 >= 8u) {
+            for (uint32_t j = lane * 8u; j < m2; j += 512u) {
+                const uint32_t jj = min(j, m2 - 8u), ph = jj % o2, room = o2 - ph;     // room: bytes of the period from the phase on
+                uint64_t v = zs_load64(dstBase + s2 + ph);                              // (reads into the destination when room < 8: those bytes are replaced)
+                if (room < 8u) { const uint64_t h = zs_load64(dstBase + s2); v = (v & ((1ull << (8u * room)) - 1ull)) | (h << (8u * room)); }
+                __builtin_memcpy(dstBase + d2 + jj, &v, 8);
+            }
+        } else { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + (j % o2)]; }
+    };
+#if defined(ZS_EXEC_STOP) && ZS_EXEC_STOP == 5
+    return;                                                              // timing aid: records and scans of the match pass only
+#endif
+    if (__ballot(indep && ml <= 32)) copyShort(indep && ml <= 32);
+#if defined(ZS_EXEC_STOP) && ZS_EXEC_STOP == 6
+    return;                                                              // timing aid: + short matches from before the tile
+#endif
     for (uint64_t lm = __ballot(indep && ml > 32); lm; lm &= lm - 1) {
         const int t = __builtin_ctzll(lm);
-        const uint32_t m2 = wave_get(ml, t), s2 = wave_get(msrc, t), d2 = wave_get(mdst, t);
-        for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j];
+        copyLong(wave_get(ml, t), 0xFFFFFFFFu, wave_get(msrc, t), wave_get(mdst, t));
     }
-    wave_mem_sync();
+    ZS_EXEC_ORDER();
+#if defined(ZS_EXEC_STOP) && ZS_EXEC_STOP == 3
+    return;                                                              // timing aid: no matches that read their own tile
+#endif
     for (uint64_t rem = __ballot(ml && !indep); rem; ) {
         const int g0 = __builtin_ctzll(rem);
         const uint32_t lo = wave_get(mdst, g0);
@@ -488,14 +561,15 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
         const uint64_t grp = viol ? (rem & ((1ull << __builtin_ctzll(viol)) - 1ull)) : rem;
         const bool in = (grp >> lane) & 1ull;
         const bool self = in && (off < ml);                              // only lane g0 can be
-        if (in && !self && ml <= 32) copyShort();
+        if (__ballot(in && !self && ml <= 32)) copyShort(in && !self && ml <= 32);
+#if defined(ZS_EXEC_STOP) && ZS_EXEC_STOP == 4
+        if (0)                                                           // timing aid: groups without their long / overlapping matches
+#endif
         for (uint64_t lm = __ballot(in && (self || ml > 32)); lm; lm &= lm - 1) {
             const int t = __builtin_ctzll(lm);
-            const uint32_t m2 = wave_get(ml, t), o2 = wave_get(off, t), s2 = wave_get(msrc, t), d2 = wave_get(mdst, t);
-            if (o2 >= m2) { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j]; }
-            else { for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + (j % o2)]; }      // period = offset
+            copyLong(wave_get(ml, t), wave_get(effOff, t), wave_get(msrc, t), wave_get(mdst, t));
         }
-        wave_mem_sync();
+        ZS_EXEC_ORDER();
         rem &= ~grp;
     }
 }
@@ -707,6 +781,9 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
             wave_mem_sync();                                              // pass A's records are read back below
             // ---- the literals: window by window a bit per output byte, toggled at the ends of every match (clipped to the window), prefix xor =
             //      inside a match; then 16 output bytes a lane and round: the next popcount(literal bits) literals, spread by v_perm ----
+#if defined(ZS_EXEC_STOP) && ZS_EXEC_STOP == 1
+            if (0)                                                        // timing aid: pass A only
+#endif
             for (uint32_t w0 = blockStart; w0 < blockEnd; w0 += ZS_EXEC_WINDOW) {
                 const uint32_t w1 = min(w0 + ZS_EXEC_WINDOW, blockEnd);
                 uint32_t pos = blockStart, matchBefore = 0;
@@ -768,11 +845,14 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
             wave_mem_sync();                                              // the matches read literals
             // ---- pass B: the matches, tile by tile ----
             uint32_t pos = blockStart;
+#if defined(ZS_EXEC_STOP) && (ZS_EXEC_STOP == 1 || ZS_EXEC_STOP == 2)
+            if (0)                                                        // timing aid: no matches
+#endif
             for (uint32_t t0 = 0; t0 < d.nbSeq; t0 += 64) {
                 const uint64_t r = (t0 + lane < d.nbSeq) ? seqs[t0 + lane] : 0ull;
                 const uint32_t tot = (uint32_t)r & 0x3FFFFu, ml = (uint32_t)(r >> 18) & 0x1FFFFu, off = (uint32_t)(r >> 35);
                 const uint32_t incl = wave_incl_scan(tot);
-                execTileMatchesFast(pos + incl - ml, ml, off, dstBase, pos);
+                execTileMatchesFast(pos + incl - ml, ml, off, dstBase, pos, (uint32_t)oend, &tiles[w][0][0]);
                 pos += wave_last(incl);
             }
             op = blockEnd;
