@@ -472,6 +472,7 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
     // kernel's time), so every piece below is an instruction only if some lane needs it, and short matches share the first load.
     const uint32_t lane = (uint32_t)zs_lane();
     uint32_t msrc = mdst - off;
+    lds3[lane] = ml ? mdst : 0xFFFFFFFFu;                                // the tile's match destinations, ascending over the lanes; lanes without a sequence behind every position
 #ifndef ZS_EXEC_NOREDIRECT
     // A match that reads this tile's own output waits for the matches that write it: a memory round trip per level of that dependence
     // (measured on the bench frames: 24 such matches a tile, 8.7 rounds).  Most of those sources lie INSIDE the destination of one earlier
@@ -481,7 +482,6 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
     {
         uint32_t *dstArr = lds3, *endArr = lds3 + 64, *srcArr = lds3 + 128;
         const bool periodic = off < ml;
-        dstArr[lane] = ml ? mdst : 0xFFFFFFFFu;                          // ascending over the lanes; lanes without a sequence behind every position
         endArr[lane] = (ml && !periodic) ? mdst + ml : 0u;               // 0: not to be read through
         bool act = ml && !periodic && msrc >= tileStart;
         #pragma unroll 1
@@ -500,6 +500,7 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
         }
     }
 #endif
+    wave_sync();
     const uint32_t effOff = mdst - msrc;                                 // (>= off: the same bytes from further back)
     const bool indep = ml && (msrc + ml <= tileStart);
     // matches of <= 32 bytes whose source and destination do not overlap, a lane each: 8-byte pieces k = 0..3 at min(8 k, ml - 8) (the last one
@@ -553,6 +554,47 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
     ZS_EXEC_ORDER();
 #if defined(ZS_EXEC_STOP) && ZS_EXEC_STOP == 3
     return;                                                              // timing aid: no matches that read their own tile
+#endif
+#ifndef ZS_EXEC_NOLEVELS
+    // The matches left read this tile's output across a sequence border.  Each waits for exactly the earlier matches of the tile whose
+    // destination its source touches - a run of lanes [a, b], found in the sorted destinations - and only while those are pending: a round
+    // copies every pending match none of whose run is pending (the first pending one always is such), so the rounds are the levels of the
+    // dependence (2.1 a tile on the bench frames; taking the pending matches in order until one reads behind the first: 4.2).
+    {
+        uint32_t *dstArr = lds3, *fullEnd = lds3 + 128;
+        uint64_t pend = __ballot(ml && !indep);
+        if (pend) {
+            fullEnd[lane] = mdst + ml;                                       // (the redirection's sources are no longer needed)
+            wave_sync();
+            uint64_t need = 0;
+            if ((pend >> lane) & 1ull) {
+                const uint32_t e = min(msrc + ml, mdst);                     // (an overlapping match reads its period only)
+                uint32_t c = 0;
+                #pragma unroll
+                for (uint32_t step = 32; step >= 1; step >>= 1) if (dstArr[c + step] <= msrc) c += step;
+                const uint32_t a = (msrc < dstArr[0]) ? 0u : ((msrc < fullEnd[c]) ? c : c + 1u);      // first lane whose match ends behind my source's start
+                if (a < lane && dstArr[a] < e) {
+                    const uint32_t d1 = dstArr[min(a + 1u, 63u)], d2 = dstArr[min(a + 2u, 63u)], d3 = dstArr[min(a + 3u, 63u)];
+                    uint32_t b = (d1 >= e) ? a : ((d2 >= e) ? a + 1u : ((d3 >= e) ? a + 2u : lane - 1u));   // last lane whose match starts in front of my source's end
+                    b = min(b, lane - 1u);
+                    need = ((2ull << b) - 1ull) & ~((1ull << a) - 1ull);
+                }
+            }
+            while (pend) {
+                const bool in = ((pend >> lane) & 1ull) && !(need & pend);
+                const uint64_t grp = __ballot(in);
+                const bool self = in && (off < ml);
+                if (__ballot(in && !self && ml <= 32)) copyShort(in && !self && ml <= 32);
+                for (uint64_t lm = __ballot(in && (self || ml > 32)); lm; lm &= lm - 1) {
+                    const int t = __builtin_ctzll(lm);
+                    copyLong(wave_get(ml, t), wave_get(effOff, t), wave_get(msrc, t), wave_get(mdst, t));
+                }
+                ZS_EXEC_ORDER();
+                pend &= ~grp;
+            }
+        }
+    }
+    return;
 #endif
     for (uint64_t rem = __ballot(ml && !indep); rem; ) {
         const int g0 = __builtin_ctzll(rem);
