@@ -405,7 +405,16 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
     const uint16_t *cells = S.cells[lane & (G - 1)];
     const uint32_t *win = S.win[lane & (G - 1)];
     ZsFastSeq *outp = seqOutAll + (slot0 + item) * ZS_FAST_MAXSEQ;
-    uint32_t sLL = 0, sOF = 0, sML = 0, t = 0;
+    // The loop below is bound by the instructions a step issues (a wavefront is alone on its SIMD: ~4.4 cycles an instruction, and the LDS
+    // holds no more items than these), so a step is written without branches and with the cell format taken apart by hand:
+    //   cell = (1 << (9 - nb) | next >> nb) << 6 | symbol, so with p = cell >> 6:  nb = clz32(p) - 22  and  next = (p << nb) - 512;
+    //   the states are kept + 512 (the table pointer - 512 cells), so a new state is (p << nb) + the nb stream bits;
+    //   extra bits of a length code (LL_bits / ML_bits, ZStdInternal.cs:158,173) = max((code - c0) >> 1, code >= c0, code >= c1 ? code - c2 : 0)
+    //   with (c0, c1, c2) = (16, 25, 19) for literal lengths and (32, 43, 36) for match lengths (arithmetic shift: below c0 all three are <= 0).
+    // One exit test a step: the position against a limit - with a window that does not reach the stream's start, where the next step could read
+    // below the window (a sequence reads < 12 bytes; 24 are kept); with one that does, below 0 = the stream ended before the sequences (:1582, :1594).
+    uint32_t sLL = 512, sOF = 512, sML = 512, t = 0;
+    const uint16_t *cellsB = cells - 512;
     bool started = false, done = !mine || !ok;
     #define FSEQ_NEED(nbits) do { if (b.avail < (nbits)) bc_refill(b, win, base); } while (0)
     for (;;) {
@@ -414,22 +423,23 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
         if (!done) stageOwnWindow<ZS_FAST_SEQWIN>(S.win[lane & (G - 1)], src, size, base);
         wave_sync();
         if (!done) {
-            if (!started) { FSEQ_NEED(llLog + ofLog + mlLog); sLL = bc_take(b, llLog); sOF = bc_take(b, ofLog); sML = bc_take(b, mlLog); started = true; }
-            while (t < nbSeq) {
-                // a sequence reads < 12 bytes of stream: stop for a refill while that much is still inside the window
-                if (b.bitPos > 0 && base > 0 && ((b.bitPos - 1) >> 3) < base + 24) break;
-                if (b.bitPos < 0) { ok = false; break; }                 // stream exhausted before all sequences (:1582, :1594)
+            if (!started) { FSEQ_NEED(llLog + ofLog + mlLog); sLL = 512 + bc_take(b, llLog); sOF = 512 + bc_take(b, ofLog); sML = 512 + bc_take(b, mlLog); started = true; }
+            const int32_t lim = (base > 0) ? 8 * (base + 24) : -1;
+            int32_t bp = b.bitPos;
+            while (t < nbSeq && bp > lim) {
                 // One LDS round trip a sequence: the three cells and the 8 stream bytes below the position are read together (no bit
-                // container carried from sequence to sequence: its refill was a second, dependent LDS read and a branch most steps took
-                // in some lane).  Bytes below the stream start read as zeros, as in bc_refill.
-                const int32_t bp = b.bitPos;
+                // container carried from sequence to sequence).  Bytes below the stream start read as zeros, as in bc_refill.
                 const int32_t bh = (bp - 1) >> 3;                        // bp == 0: -1, the 8 zero bytes in front of the stream
-                const uint32_t cLL = cells[sLL], cOF = cells[OFB + sOF], cML = cells[MLB + sML];
+                const uint32_t cLL = cellsB[sLL], cOF = cellsB[OFB + sOF], cML = cellsB[MLB + sML];
                 const uint64_t raw = win64(win, (uint32_t)(bh - base + 1));
-                uint32_t bLL, bML, bOF, nL, nM, nO, yLL, yML, yOF;
-                zs_fastcell_open(cLL, bLL, nL, yLL); zs_fastcell_open(cML, bML, nM, yML); zs_fastcell_open(cOF, bOF, nO, yOF);
+                const uint32_t yLL = cLL & 63u, yML = cML & 63u, yOF = cOF & 63u;
+                const uint32_t pL = cLL >> 6, pM = cML >> 6, pO = cOF >> 6;
+                const uint32_t nL = (uint32_t)__builtin_clz(pL) - 22u, nM = (uint32_t)__builtin_clz(pM) - 22u, nO = (uint32_t)__builtin_clz(pO) - 22u;
                 outp[t++] = zs_fastseq((uint32_t)bp, yLL, yML, yOF);
-                const uint32_t xbits = zs_llExtraBits(yLL) + zs_mlExtraBits(yML) + yOF;                     // skipped here, read by the execute kernel
+                const int32_t iL = (int32_t)yLL, iM = (int32_t)yML;
+                const int32_t xL = max(max((iL - 16) >> 1, (int32_t)(iL >= 16)), (iL >= 25) ? iL - 19 : 0);
+                const int32_t xM = max(max((iM - 32) >> 1, (int32_t)(iM >= 32)), (iM >= 43) ? iM - 36 : 0);
+                const uint32_t xbits = (uint32_t)xL + (uint32_t)xM + yOF;                                   // skipped here, read by the execute kernel
                 const uint32_t sbits = nL + nM + nO;
                 uint64_t c = raw << (7u - (uint32_t)((bp - 1) & 7));     // >= 57 valid bits from the top
                 const int32_t p2 = bp - (int32_t)xbits;
@@ -437,11 +447,13 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
                 else if (p2 <= 0) c = 0;
                 else c = win64(win, (uint32_t)(((p2 - 1) >> 3) - base + 1)) << (7u - (uint32_t)((p2 - 1) & 7));   // rare: very long offset + long lengths
                 const uint32_t x = __builtin_amdgcn_ubfe((uint32_t)(c >> 32), 32u - sbits, sbits);   // LL bits on top, then ML, then OF (:1547-1550)
-                b.bitPos = p2 - (int32_t)sbits;
-                sLL = bLL + __builtin_amdgcn_ubfe(x, nM + nO, nL);
-                sML = bML + __builtin_amdgcn_ubfe(x, nO, nM);
-                sOF = bOF + __builtin_amdgcn_ubfe(x, 0u, nO);
+                bp = p2 - (int32_t)sbits;
+                sLL = (pL << nL) + __builtin_amdgcn_ubfe(x, nM + nO, nL);
+                sML = (pM << nM) + __builtin_amdgcn_ubfe(x, nO, nM);
+                sOF = (pO << nO) + __builtin_amdgcn_ubfe(x, 0u, nO);
             }
+            b.bitPos = bp;
+            if (t < nbSeq && lim < 0) ok = false;                        // stream exhausted before all sequences
             if (t == nbSeq || !ok) done = true;
         }
         if (!__ballot(!done)) break;
@@ -460,6 +472,9 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
 // Between a store and a later load of the same bytes by the SAME wavefront: with ZS_EXEC_FENCE the wavefront waits until its stores are
 // acknowledged (a workgroup-scope fence: s_waitcnt vmcnt(0)); without, only the compiler is kept from reordering, and the order is the
 // memory pipeline's (a wavefront's vector-memory instructions reach the L1 / L2 in issue order).
+#ifndef ZS_EXEC_ROUNDS
+#define ZS_EXEC_ROUNDS 3                // rounds of pointer jumping a tile's matches get (what is left after them stays a dependent match)
+#endif
 #ifndef ZS_EXEC_NOFENCE
 #define ZS_EXEC_ORDER() wave_mem_sync()
 #else
@@ -485,7 +500,7 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
         endArr[lane] = (ml && !periodic) ? mdst + ml : 0u;               // 0: not to be read through
         bool act = ml && !periodic && msrc >= tileStart;
         #pragma unroll 1
-        for (uint32_t round = 0; round < 4 && __ballot(act); round++) {
+        for (uint32_t round = 0; round < ZS_EXEC_ROUNDS && __ballot(act); round++) {
             srcArr[lane] = msrc;
             wave_sync();
             if (act) {
