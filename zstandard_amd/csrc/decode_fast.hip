@@ -431,7 +431,8 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
                 // container carried from sequence to sequence).  Bytes below the stream start read as zeros, as in bc_refill.
                 const int32_t bh = (bp - 1) >> 3;                        // bp == 0: -1, the 8 zero bytes in front of the stream
                 const uint32_t cLL = cellsB[sLL], cOF = cellsB[OFB + sOF], cML = cellsB[MLB + sML];
-                const uint64_t raw = win64(win, (uint32_t)(bh - base + 1));
+                uint64_t raw = win64(win, (uint32_t)(bh - base + 1));
+                asm volatile("" : "+v"(raw));                            // (read here, beside the cells: left to itself hipcc moves the read behind the cells' arithmetic, a second LDS round trip a step)
                 const uint32_t yLL = cLL & 63u, yML = cML & 63u, yOF = cOF & 63u;
                 const uint32_t pL = cLL >> 6, pM = cML >> 6, pO = cOF >> 6;
                 const uint32_t nL = (uint32_t)__builtin_clz(pL) - 22u, nM = (uint32_t)__builtin_clz(pM) - 22u, nO = (uint32_t)__builtin_clz(pO) - 22u;
@@ -441,11 +442,10 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
                 const int32_t xM = max(max((iM - 32) >> 1, (int32_t)(iM >= 32)), (iM >= 43) ? iM - 36 : 0);
                 const uint32_t xbits = (uint32_t)xL + (uint32_t)xM + yOF;                                   // skipped here, read by the execute kernel
                 const uint32_t sbits = nL + nM + nO;
-                uint64_t c = raw << (7u - (uint32_t)((bp - 1) & 7));     // >= 57 valid bits from the top
+                uint64_t c = (raw << (7u - (uint32_t)((bp - 1) & 7))) << xbits;     // >= 57 valid bits from the top, the extra bits skipped
                 const int32_t p2 = bp - (int32_t)xbits;
-                if (xbits + sbits <= 57u) c <<= xbits;
-                else if (p2 <= 0) c = 0;
-                else c = win64(win, (uint32_t)(((p2 - 1) >> 3) - base + 1)) << (7u - (uint32_t)((p2 - 1) & 7));   // rare: very long offset + long lengths
+                if (xbits + sbits > 57u)                                 // rare (a very long offset + long lengths): read again at the state bits
+                    c = (p2 <= 0) ? 0ull : win64(win, (uint32_t)(((p2 - 1) >> 3) - base + 1)) << (7u - (uint32_t)((p2 - 1) & 7));
                 const uint32_t x = __builtin_amdgcn_ubfe((uint32_t)(c >> 32), 32u - sbits, sbits);   // LL bits on top, then ML, then OF (:1547-1550)
                 bp = p2 - (int32_t)sbits;
                 sLL = (pL << nL) + __builtin_amdgcn_ubfe(x, nM + nO, nL);
