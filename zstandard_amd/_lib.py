@@ -89,7 +89,7 @@ def lib():
     L.zsmi_packFramesDevice.restype = i32; L.zsmi_packFramesDevice.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     L.zsmi_enableKernelTiming.restype = i32; L.zsmi_enableKernelTiming.argtypes = [vp, i32]
     L.zsmi_getKernelTimes.restype = i32; L.zsmi_getKernelTimes.argtypes = [vp, ctypes.POINTER(KernelTime), i32]
-    if DEBUG:
+    if DEBUG or hasattr(L, "zsmi_dbg_copyScratch"):            # (a variant build named by ZSMI_LIB_FILE may carry the hooks too)
         L.zsmi_dbg_copyScratch.restype = i32; L.zsmi_dbg_copyScratch.argtypes = [vp, i32, vp, sz]
     _lib = L
     return L

@@ -68,7 +68,7 @@ __device__ __forceinline__ uint32_t zs_mlExtraBits(uint32_t s) { return s < 32 ?
 // k_dec_prep
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef ZS_PREP_MINWG
-#define ZS_PREP_MINWG 8                 // wavefronts per SIMD the prep kernel is compiled for (<= 64 VGPRs; measured per 57344 frames: 4: 2.01 ms, 5: 1.78, 6: 1.73, 8: 1.64 - latency-bound, spills and all)
+#define ZS_PREP_MINWG 4                 // wavefronts per SIMD the prep kernel is compiled for (128 VGPRs; per 57344 frames: 2: 0.96 ms, 3: 0.97, 4: 0.97, 5: 1.02, 6: 1.04, 8: 1.10 with ~450 spilled registers; the kernel is bound by the instructions it issues)
 #endif
 template <int F>
 __global__ void __launch_bounds__(64 * F, ZS_PREP_MINWG)
@@ -92,6 +92,10 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
     if (lane < 36) L.llTab[lane] = d_LL_base[lane] | ((uint32_t)d_LL_bits[lane] << 24);
     if (lane < 53) L.mlTab[lane] = d_ML_base[lane] | ((uint32_t)d_ML_bits[lane] << 24);
     wave_sync();
+#ifdef ZS_PREP_PROFILE
+    if (lane == 0) { for (int k = 0; k < 12; k++) L.pp[k] = 0; L.ppMark = __builtin_amdgcn_s_memtime(); }
+    const unsigned long long ppStart = __builtin_amdgcn_s_memtime();
+#endif
     bool ok = false; uint32_t nBlocks = 0;
     do {
         // ---- frame header (:389-499): one frame, no dictionary ----
@@ -111,6 +115,9 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
         const uint32_t hasContentSize = fcs != ~0ull, contentSize = (uint32_t)fcs;
         uint32_t b0 = fhs;                                          // offset of the next block header in the item
         bool fail = false;
+#if defined(ZS_PREP_STOP) && ZS_PREP_STOP == 1
+        break;                                                      // timing aid: the frame header only
+#endif
         #pragma unroll 1
         for (uint32_t blk = 0; blk < maxBlocks && !fail; blk++) {
             fail = true;
@@ -141,6 +148,9 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                     else { lhSize = 5; litSize = (lhc >> 4) & 0x3FFFF; litCSize = (lhc >> 22) + ((uint32_t)bs[4] << 10); }
                     if (litSize > (1u << 17) || litCSize + lhSize > cSize) break;
                     if (!single && (litSize == 0 || litCSize == 0)) break;
+#if defined(ZS_PREP_STOP) && ZS_PREP_STOP == 3
+                    break;                                          // timing aid: + block and literals headers, no tables
+#endif
                     uint16_t *ht = reinterpret_cast<uint16_t *>(hufTabs + slot * ZS_FAST_HUFTAB_BYTES);
                     const uint32_t h = readHufTableT<true>(L, bs + lhSize, litCSize, ht, ZS_FAST_HUFLOG);
                     if (isErr(h) || h >= litCSize || L.hufLog > ZS_FAST_HUFLOG) break;
@@ -173,6 +183,9 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                 }
             }
             if (litCSizeTot > cSize) break;
+#if defined(ZS_PREP_STOP) && ZS_PREP_STOP == 2
+            break;                                                  // timing aid: + block and literals headers, the Huffman table
+#endif
             // ---- sequence headers + tables (:1110-1180), then the tables leave for the sequences kernel.  st.fseEntropy stays 0: a
             //      table repeated from the block before (mode 3) is an error here and sends the item to the general kernel ----
             const uint8_t *ip = bs + litCSizeTot; uint32_t remaining = cSize - litCSizeTot, nbSeq = 0;
@@ -192,6 +205,13 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
         }
         ok = !fail;
     } while (0);
+#ifdef ZS_PREP_PROFILE
+    if (lane == 0) {          // phases 0-11, then the wavefront's whole time: behind the item's Huffman table (the two-level table ends at 1280 bytes)
+        unsigned long long *o = reinterpret_cast<unsigned long long *>(hufTabs + (size_t)item * ZS_FAST_HUFTAB_BYTES + 2048);
+        for (int k = 0; k < 12; k++) o[k] = L.pp[k];
+        o[12] = __builtin_amdgcn_s_memtime() - ppStart;
+    }
+#endif
     // an item is fast only as a whole; a block index it does not use reads as absent
     if (lane == 0) {
         if (!ok) { descs[item].fast = 0; descs[(size_t)cap + item].fast = 0; }

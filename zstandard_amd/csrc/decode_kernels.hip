@@ -88,6 +88,9 @@ struct DLds {
     uint32_t misc[16];
     uint32_t llTab[36], mlTab[53];      // base | extra bits << 24 of each LL / ML code (LL_base, LL_bits, ML_base, ML_bits)
     uint32_t pad16[1];
+#ifdef ZS_PREP_PROFILE
+    unsigned long long pp[12], ppMark;  // development aid (tools/prep_profile.py): s_memtime ticks per phase of k_dec_prep, this wavefront
+#endif
     // k_dec_prep allocates the struct up to here (ZS_DLDS_PREP bytes): it builds its three sequence tables one after the other
     // in LL and its Huffman table in global memory, and what it holds per item decides how many items a CU prepares at once
     SeqTab ML;
@@ -95,6 +98,11 @@ struct DLds {
     uint16_t huf[4096];                 // byte | nbBits << 8   (HufDecompress.cs:109-113)
 };
 #define ZS_DLDS_PREP (offsetof(DLds, ML))
+#ifdef ZS_PREP_PROFILE
+#define PPROF(L, k) do { if (zs_lane() == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); (L).pp[k] += now_ - (L).ppMark; (L).ppMark = now_; } } while (0)
+#else
+#define PPROF(L, k) do { } while (0)
+#endif
 __device__ __forceinline__ uint32_t ofBaseOf(uint32_t sym) { return sym == 0 ? 0u : (sym == 1 ? 1u : ((1u << sym) - 3u)); }   // OF_base :1088
 
 __device__ __forceinline__ uint32_t rd16(const uint8_t *p) { return (uint32_t)p[0] | ((uint32_t)p[1] << 8); }
@@ -291,9 +299,11 @@ __device__ __forceinline__ uint32_t readHufTableT(DLds &L, const uint8_t *src, u
 {
     const uint32_t lane = (uint32_t)zs_lane();
     if (!srcSize) return ZE(E_srcSize_wrong);
+    PPROF(L, 0);
     hw_stage(L.u.tb.hdrWin, src, min(srcSize, 256u));
     const uint32_t *hw = L.u.tb.hdrWin;
     uint32_t iSize = src[0], oSize = 0;
+    PPROF(L, 1);
     if (iSize >= 128) {                                                     // direct: 4 bits per weight (EntropyCommon.cs:215-225)
         oSize = iSize - 127; iSize = (oSize + 1) / 2;
         if (iSize + 1 > srcSize) return ZE(E_srcSize_wrong);
@@ -302,67 +312,76 @@ __device__ __forceinline__ uint32_t readHufTableT(DLds &L, const uint8_t *src, u
         wave_sync();
     } else {
         if (iSize + 1 > srcSize) return ZE(E_srcSize_wrong);
+        // FSE-compressed weights (FseDecompress.cs:233-332), table log <= 6, read from the staged window (offset 1): the counts are parsed by one
+        // lane, the decoding table (FseDecompress.cs:111-181: the same construction as a sequence table's) is built by all of them, the weights
+        // are decoded by one lane again - two interleaved states: their cells are read together, the stream bits come from a 64-bit container.
         if (lane == 0) {
-            // FSE-compressed weights (FseDecompress.cs:233-332), table log <= 6, read from the register window (offset 1)
+            uint32_t tableLog = 0, maxSV = 63;
+            const uint32_t nc = readNCount(L.u.tb.norm, &maxSV, &tableLog, hw, iSize, 1);       // the description starts at byte 1
+            uint32_t err = 0;
+            if (isErr(nc)) err = nc;
+            else if (tableLog > 6 || maxSV > 63) err = ZE(E_tableLog_tooLarge);
+            else if (iSize <= nc) err = ZE(E_corruption_detected);
+            L.misc[0] = err; L.misc[1] = nc; L.misc[2] = tableLog; L.misc[3] = maxSV;
+        }
+        wave_sync();
+        if (L.misc[0]) return L.misc[0];
+        PPROF(L, 2);
+        SeqSym *wc = reinterpret_cast<SeqSym *>(L.u.tb.wfse);
+        buildSeqTableWave(L, wc, &L.misc[5], L.misc[3], L.misc[2]);
+        PPROF(L, 3);
+        if (lane == 0) {
             uint32_t result = 0;
             do {
-                uint32_t tableLog, maxSV = 63;
-                const uint32_t nc = readNCount(L.u.tb.norm, &maxSV, &tableLog, hw, iSize, 1);       // the description starts at byte 1
-                if (isErr(nc)) { result = nc; break; }
-                if (tableLog > 6 || maxSV > 63) { result = ZE(E_tableLog_tooLarge); break; }
-                {   // FseDecompress.cs:111-181
-                    const uint32_t tableSize = 1u << tableLog, tableMask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
-                    uint32_t highThreshold = tableSize - 1, position = 0;
-                    for (uint32_t sy = 0; sy <= maxSV; sy++) {
-                        if (L.u.tb.norm[sy] == -1) { L.u.tb.wfse[highThreshold--].symbol = (uint8_t)sy; L.u.tb.symbolNext[sy] = 1; } else L.u.tb.symbolNext[sy] = (uint16_t)L.u.tb.norm[sy];
-                    }
-                    for (uint32_t sy = 0; sy <= maxSV; sy++)
-                        for (int i = 0; i < L.u.tb.norm[sy]; i++) { L.u.tb.wfse[position].symbol = (uint8_t)sy; position = (position + step) & tableMask; while (position > highThreshold) position = (position + step) & tableMask; }
-                    if (position != 0) { result = ZE(E_GENERIC); break; }
-                    for (uint32_t u = 0; u < tableSize; u++) {
-                        const uint32_t sy = L.u.tb.wfse[u].symbol; const uint32_t ns = L.u.tb.symbolNext[sy]++;
-                        L.u.tb.wfse[u].nbBits = (uint8_t)(tableLog - zs_highbit(ns));
-                        L.u.tb.wfse[u].newState = (uint16_t)((ns << L.u.tb.wfse[u].nbBits) - tableSize);
-                    }
-                }
+                const uint32_t nc = L.misc[1], tableLog = L.misc[2];
                 {   // two interleaved states, FseDecompress.cs:233-295; the stream is bytes [1 + nc, 1 + iSize) of the window
-                    if (iSize <= nc) { result = ZE(E_corruption_detected); break; }
                     const uint32_t s0 = 1 + nc, ssz = iSize - nc;
                     const uint32_t lastByte = rw_rd32(hw, s0 + ssz - 1) & 0xFFu;
                     if (lastByte == 0) { result = ZE(E_corruption_detected); break; }
                     int32_t bitPos = (int32_t)(ssz * 8 - (8 - zs_highbit(lastByte)));
-                    // n <= 6 bits below the cursor (bits below the stream start read as 0, BitStream.cs:412)
-                    auto readBits = [&](uint32_t n) -> uint32_t {
-                        uint32_t v = 0;
-                        if (n && bitPos > 0) {
-                            const int32_t bh = (bitPos - 1) >> 3;
-                            const uint32_t raw = (bh >= 3) ? rw_rd32(hw, s0 + (uint32_t)bh - 3) : (rw_rd32(hw, s0) << (8 * (3 - bh)));
-                            v = (raw << (7u - (uint32_t)((bitPos - 1) & 7))) >> (32 - n);
-                        }
-                        bitPos -= (int32_t)n;
+                    // container: the stream bits below the cursor from its top bit down, `avail` of them valid (bits below the stream's start are 0, BitStream.cs:412)
+                    uint64_t cont = 0; int32_t avail = 0;
+                    auto refill = [&]() {
+                        if (bitPos <= 0) { cont = 0; avail = 64; return; }
+                        const int32_t bh = (bitPos - 1) >> 3;
+                        uint64_t raw;
+                        if (bh >= 7) raw = (uint64_t)rw_rd32(hw, s0 + (uint32_t)bh - 7) | ((uint64_t)rw_rd32(hw, s0 + (uint32_t)bh - 3) << 32);
+                        else raw = ((uint64_t)rw_rd32(hw, s0) | ((uint64_t)rw_rd32(hw, s0 + 4) << 32)) << (8 * (7 - bh));
+                        const uint32_t sh = 7u - (uint32_t)((bitPos - 1) & 7);
+                        cont = raw << sh; avail = 64 - (int32_t)sh;
+                    };
+                    auto readBits = [&](uint32_t n) -> uint32_t {            // n <= 6
+                        if (avail < (int32_t)n) refill();
+                        const uint32_t v = n ? (uint32_t)(cont >> (64 - n)) : 0u;
+                        cont <<= n; avail -= (int32_t)n; bitPos -= (int32_t)n;
                         return v;
                     };
                     uint32_t s1 = readBits(tableLog), s2 = readBits(tableLog);
                     uint32_t op = 0; bool bad = false;
                     for (;;) {
                         if (op > 253) { bad = true; break; }
-                        L.u.tb.weights[op++] = L.u.tb.wfse[s1].symbol; { const uint32_t nb = L.u.tb.wfse[s1].nbBits; s1 = L.u.tb.wfse[s1].newState + readBits(nb); }
-                        if (bitPos < 0) { L.u.tb.weights[op++] = L.u.tb.wfse[s2].symbol; break; }
+                        const SeqSym c1 = wc[s1], c2 = wc[s2];
+                        L.u.tb.weights[op++] = c1.sym; s1 = c1.nextState + readBits(c1.nbBits);
+                        if (bitPos < 0) { L.u.tb.weights[op++] = c2.sym; break; }
                         if (op > 253) { bad = true; break; }
-                        L.u.tb.weights[op++] = L.u.tb.wfse[s2].symbol; { const uint32_t nb = L.u.tb.wfse[s2].nbBits; s2 = L.u.tb.wfse[s2].newState + readBits(nb); }
-                        if (bitPos < 0) { L.u.tb.weights[op++] = L.u.tb.wfse[s1].symbol; break; }
+                        L.u.tb.weights[op++] = c2.sym; s2 = c2.nextState + readBits(c2.nbBits);
+                        if (bitPos < 0) { L.u.tb.weights[op++] = wc[s1].sym; break; }
                     }
                     if (bad) { result = ZE(E_corruption_detected); break; }
                     result = op;                                             // number of weights
                 }
             } while (0);
             L.misc[0] = result;
+            PPROF(L, 4);
         }
         wave_sync();
         const uint32_t r = L.misc[0];
         if (isErr(r)) return r;
         oSize = r;
     }
+#if defined(ZS_PREP_STOP) && ZS_PREP_STOP == 4
+    return ZE(E_GENERIC);                                                   // timing aid: the weights only
+#endif
     // ---- from here on all lanes.  weights[0 .. oSize) are known; the last symbol's weight is implied ----
     uint32_t wgt[4]; uint32_t weightTotal = 0; bool bad = false;
     #pragma unroll
@@ -384,7 +403,7 @@ __device__ __forceinline__ uint32_t readHufTableT(DLds &L, const uint8_t *src, u
     for (uint32_t c = 0; c < 4; c++) if (64 * c + lane == oSize) wgt[c] = lastWeight;
     const uint32_t nbSymbols = oSize + 1;
     // symbols per weight, then the first cell of each weight (cells sorted by weight, then by symbol: HufDecompress.cs:148-176)
-    uint32_t rankStart[13];                                                  // uniform values
+    uint32_t rankStart[13], rankIdx[13], nSorted = 0;                         // uniform values; rankIdx: symbols (of a weight) in front, in cell order
     {
         uint32_t next = 0;
         #pragma unroll
@@ -394,8 +413,9 @@ __device__ __forceinline__ uint32_t readHufTableT(DLds &L, const uint8_t *src, u
             for (uint32_t c = 0; c < 4; c++) cnt += (uint32_t)__popcll(__ballot(wgt[c] == wv));
             if (wv == 1 && ((cnt < 2) || (cnt & 1))) bad = true;             // EntropyCommon.cs:262
             rankStart[wv] = next; next += cnt << (wv - 1);
+            rankIdx[wv] = nSorted; nSorted += cnt;
         }
-        rankStart[0] = 0;
+        rankStart[0] = 0; rankIdx[0] = 0;
     }
     if (bad) return ZE(E_corruption_detected);
     if (lane == 0) L.hufLog = tableLog;
@@ -404,17 +424,21 @@ __device__ __forceinline__ uint32_t readHufTableT(DLds &L, const uint8_t *src, u
     uint32_t before[13];
     #pragma unroll
     for (uint32_t wv = 0; wv <= 12; wv++) before[wv] = 0;
+    // TO_GLOBAL: the symbols in cell order (first cell, table entry) for the entry-by-entry fill below; scratch: the LL table's room
+    uint16_t *sStart = reinterpret_cast<uint16_t *>(L.LL.cells), *sEntry = sStart + 264;
+    if (TO_GLOBAL) { for (uint32_t i = lane; i < 264; i += 64) sStart[i] = 0xFFFFu; wave_sync(); }
     #pragma unroll
     for (uint32_t c = 0; c < 4; c++) {
-        uint32_t myStart = 0;
+        uint32_t myStart = 0, myRank = 0;
         #pragma unroll
         for (uint32_t wv = 1; wv <= 12; wv++) {
             const uint64_t m = __ballot(wgt[c] == wv);
-            if (wgt[c] == wv) myStart = rankStart[wv] + ((before[wv] + (uint32_t)__popcll(m & below)) << (wv - 1));
+            if (wgt[c] == wv) { const uint32_t k = before[wv] + (uint32_t)__popcll(m & below); myStart = rankStart[wv] + (k << (wv - 1)); myRank = rankIdx[wv] + k; }
             before[wv] += (uint32_t)__popcll(m);
         }
         if (wgt[c]) L.u.tb.symStart[64 * c + lane] = (uint16_t)myStart;
         L.u.tb.weights[64 * c + lane] = (uint8_t)wgt[c];
+        if (TO_GLOBAL && wgt[c]) { sStart[myRank] = (uint16_t)myStart; sEntry[myRank] = (uint16_t)((64 * c + lane) | ((tableLog + 1 - wgt[c]) << 8)); }
     }
     wave_sync();
 #ifdef ZS_DEC_ERRLINE
@@ -438,6 +462,11 @@ __device__ __forceinline__ uint32_t readHufTableT(DLds &L, const uint8_t *src, u
         if (mism) return 0xFF000000u | mism;
     }
 #endif
+#if defined(ZS_PREP_STOP) && ZS_PREP_STOP == 5
+    return ZE(E_GENERIC);                                                   // timing aid: + ranks and start cells
+#endif
+    PPROF(L, 5);
+    if (!TO_GLOBAL)
     for (uint32_t n = 0; n < nbSymbols; n++) {            // uniform loop; lanes fill one symbol's cells together
         const uint32_t w = L.u.tb.weights[n];
         if (!w) continue;
@@ -450,44 +479,49 @@ __device__ __forceinline__ uint32_t readHufTableT(DLds &L, const uint8_t *src, u
         // entries of P (tables of < 9 bits are spread out), a 9-bit prefix under which 10- and 11-bit codes sit points (bit 15)
         // to a 4-entry sub-table indexed by the next 2 bits.  1.25 KiB an item instead of the 4 KiB of a flat 2^11 table; more
         // than ZS_HUF2_SUBS such prefixes: the item is left to the general kernel.
+        // Filled entry by entry: lane l owns P[8 l .. 8 l + 7]; an entry finds its symbol in the cell-ordered list by binary search (its
+        // 8 searches side by side) and the lane stores its entries as one 16-byte piece.  (Symbol by symbol - the lanes filling one
+        // symbol's run - was ~150 rounds of an LDS read and a 2-byte scattered store: 44 % of the prep kernel's time.)
         const uint32_t extra = tableLog > 9 ? tableLog - 9 : 0u, rep = tableLog < 9 ? 9 - tableLog : 0u;
-        uint16_t *subOf = reinterpret_cast<uint16_t *>(L.LL.cells);                 // scratch: 512 entries, sub-table id + 1 of a prefix
-        for (uint32_t i = lane; i < 512; i += 64) subOf[i] = 0;
-        wave_sync();
-        for (uint32_t n = 0; n < nbSymbols; n++) {
-            const uint32_t w = L.u.tb.weights[n];
-            if (w && tableLog + 1 - w > 9 && lane == 0) subOf[L.u.tb.symStart[n] >> extra] = 1;
-        }
-        wave_sync();
-        {
-            uint32_t f[8], cnt = 0;
+        uint32_t r[8], flat[8];
+        #pragma unroll
+        for (uint32_t q = 0; q < 8; q++) { const uint32_t i = 8 * lane + q; flat[q] = tableLog >= 9 ? i << extra : i >> rep; r[q] = 0; }
+        #pragma unroll
+        for (uint32_t step = 128; step >= 1; step >>= 1) {
+            uint32_t probe[8];
             #pragma unroll
-            for (uint32_t q = 0; q < 8; q++) { f[q] = subOf[8 * lane + q]; cnt += f[q]; }
-            const uint32_t incl = wave_incl_scan(cnt);
-            if (wave_last(incl) > ZS_HUF2_SUBS) return ZE(E_tableLog_tooLarge);
-            uint32_t id = incl - cnt;
-            wave_sync();
+            for (uint32_t q = 0; q < 8; q++) probe[q] = sStart[r[q] + step];
             #pragma unroll
-            for (uint32_t q = 0; q < 8; q++) { if (f[q]) { subOf[8 * lane + q] = (uint16_t)(id + 1); id++; } }
+            for (uint32_t q = 0; q < 8; q++) if (probe[q] <= flat[q]) r[q] += step;
         }
-        wave_sync();
-        for (uint32_t n = 0; n < nbSymbols; n++) {        // uniform loop; lanes fill one symbol's entries together
-            const uint32_t w = L.u.tb.weights[n];
-            if (!w) continue;
-            const uint32_t nb = tableLog + 1 - w, length = (1u << w) >> 1, startAt = L.u.tb.symStart[n];
-            const uint16_t e = (uint16_t)(n | (nb << 8));
-            if (nb <= 9) {
-                const uint32_t lo = tableLog >= 9 ? startAt >> extra : startAt << rep, hi = tableLog >= 9 ? (startAt + length) >> extra : (startAt + length) << rep;
-                for (uint32_t u = lo + lane; u < hi; u += 64) hufGlobal[u] = e;
-            } else if (lane < 4) {
-                const uint32_t prefix = startAt >> extra, sub = (uint32_t)subOf[prefix] - 1u;
-                const uint32_t j = (prefix << extra) + (lane >> (2 - extra));              // the cell of the flat table this sub-table slot stands for
-                if (j >= startAt && j < startAt + length) hufGlobal[512 + sub * 4 + lane] = e;
+        uint32_t ent[8], cnt = 0;
+        #pragma unroll
+        for (uint32_t q = 0; q < 8; q++) { ent[q] = sEntry[r[q]]; cnt += (ent[q] >> 8) > 9u; }
+        const uint32_t incl = wave_incl_scan(cnt);
+        if (wave_last(incl) > ZS_HUF2_SUBS) return ZE(E_tableLog_tooLarge);
+        uint32_t id = incl - cnt;
+        #pragma unroll
+        for (uint32_t q = 0; q < 8; q++) {
+            if ((ent[q] >> 8) > 9u) {
+                // the sub-table: slot t stands for flat cell (prefix << extra) + (t >> (2 - extra)); the symbols under the prefix follow r[q]
+                uint32_t rr = r[q]; uint32_t se[4];
+                #pragma unroll
+                for (uint32_t t = 0; t < 4; t++) {
+                    const uint32_t j = flat[q] + (t >> (2 - extra));
+                    while (sStart[rr + 1] <= j) rr++;
+                    se[t] = sEntry[rr];
+                }
+                const uint64_t pack = (uint64_t)(se[0] | (se[1] << 16)) | ((uint64_t)(se[2] | (se[3] << 16)) << 32);
+                __builtin_memcpy(hufGlobal + 512 + id * 4, &pack, 8);
+                ent[q] = 0x8000u | id;
+                id++;
             }
         }
-        for (uint32_t i = lane; i < 512; i += 64) { const uint32_t sid = subOf[i]; if (sid) hufGlobal[i] = (uint16_t)(0x8000u | (sid - 1u)); }
+        const uint4 pk = make_uint4(ent[0] | (ent[1] << 16), ent[2] | (ent[3] << 16), ent[4] | (ent[5] << 16), ent[6] | (ent[7] << 16));
+        *reinterpret_cast<uint4 *>(hufGlobal + 8 * lane) = pk;
     }
     wave_sync();
+    PPROF(L, 6);
     return iSize + 1;
 }
 __device__ __forceinline__ uint32_t readHufTable(DLds &L, const uint8_t *src, uint32_t srcSize) { return readHufTableT<false>(L, src, srcSize, nullptr, 12); }
@@ -907,7 +941,9 @@ __device__ __forceinline__ uint32_t seqHeadersT(DLds &L, const DState &st, const
                 uint32_t *tl = (EMIT || t == 0) ? &L.LL.tableLog : (t == 1 ? &L.OF.tableLog : &L.ML.tableLog);
                 const int16_t *dn = t == 0 ? d_LL_defaultNorm : (t == 1 ? d_OF_defaultNorm : d_ML_defaultNorm);
                 const uint32_t dmax = t == 0 ? 35 : (t == 1 ? 28 : 52);
+                PPROF(L, 7);
                 hw_stage(L.u.tb.hdrWin, ip + consumed, (uint32_t)(iend - (ip + consumed)));           // this table's description, staged
+                PPROF(L, 8);
                 if (lane == 0) {                                   // parse (serial, small): what to build and how many bytes it took
                     uint32_t err = 0, adv = 0, bmax = 0, blog = 0;
                     const uint8_t *p = ip + consumed;
@@ -930,17 +966,20 @@ __device__ __forceinline__ uint32_t seqHeadersT(DLds &L, const DState &st, const
                     L.misc[0] = err; L.misc[1] = adv; L.misc[3] = bmax; L.misc[4] = blog;
                 }
                 wave_sync();
+                PPROF(L, 9);
                 if (L.misc[0]) return ZE(E_corruption_detected);
                 consumed += L.misc[1];
                 const uint32_t bmax = L.misc[3], blog = L.misc[4];
                 if (type == 0) { if (lane <= dmax) L.u.tb.norm[lane] = dn[lane]; wave_sync(); }
                 if (type == 0 || type == 2) buildSeqTableWave(L, cells, tl, bmax, blog);
                 wave_sync();
+                PPROF(L, 10);
                 if (EMIT) {
                     const uint32_t log = *tl, at = t == 0 ? 0u : (t == 1 ? 512u : 768u);
                     for (uint32_t i = lane; i < (1u << log); i += 64) { const SeqSym c = cells[i]; stab[at + i] = (uint16_t)zs_fastcell(c.nextState, c.nbBits, c.sym); }
                     if (lane == 0) logsOut[t] = log;
                     wave_sync();
+                    PPROF(L, 11);
                 }
             }
             ip += consumed;

@@ -723,7 +723,7 @@ extern "C" int zsmi_dbg_copyScratch(zsmi_ctx *c, int which, void *hostDst, size_
     if (!c) return -1;
     (void)hipStreamSynchronize(c->stream);
     zsmi_ctx::Scratch &L0 = c->lanes[0];
-    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : which == 4 ? &L0.dDistHi : which == 7 ? &L0.dRecs : which == 8 ? &L0.dRes : which == 5 ? &c->dLitScratch : &L0.dMetas;
+    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : which == 4 ? &L0.dDistHi : which == 7 ? &L0.dRecs : which == 8 ? &L0.dRes : which == 5 ? &c->dLitScratch : which == 9 ? &c->dHufTabs : &L0.dMetas;
     if (bytes > b->cap) return -2;
     return hipMemcpy(hostDst, b->p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
