@@ -11,6 +11,7 @@ import _data as D, _oracle as O
 
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=57344); ap.add_argument("--chunk", type=int, default=32768)
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
+ap.add_argument("--libzstd", action="store_true", help="frames built by upstream libzstd (level 3) on the host instead of this codec's encoder")
 ap.add_argument("--times-only", action="store_true", help="per-kernel times, no output check, no CPU leg (timing-aid builds: ZSMI_LIB_FILE)"); a = ap.parse_args()
 n, cs = a.frames, a.chunk
 host = D.zipf_log(n * cs, threads=32)
@@ -19,9 +20,17 @@ d_src = torch.from_numpy(host).cuda()
 bound = int(bc.L.zsmi_compressBound(cs)); stride = (bound + 255) // 256 * 256
 d_frames = torch.empty(n * stride, dtype=torch.uint8, device="cuda"); d_fsz = torch.zeros(n, dtype=torch.int32, device="cuda")
 offs = np.arange(n, dtype=np.uint64) * cs; sizes = np.full(n, cs, dtype=np.uint32); foffs = np.arange(n, dtype=np.uint64) * stride
-bc.compress_device(d_src.data_ptr(), offs, sizes, d_frames.data_ptr(), foffs, d_fsz.data_ptr(), 3)
-torch.cuda.synchronize()
-fsz = d_fsz.cpu().numpy().astype(np.uint32)
+if a.libzstd:
+    import ctypes
+    Zl = O.libzstd(); assert Zl, "no libzstd here"
+    zb = np.empty(n * stride, dtype=np.uint8); fsz = np.zeros(n, dtype=np.uint32); vp_ = ctypes.c_void_p
+    rc = O.lib().zso_libzstdCompressBatch(zb.ctypes.data_as(vp_), foffs.ctypes.data_as(vp_), fsz.ctypes.data_as(vp_), host.ctypes.data_as(vp_), offs.ctypes.data_as(vp_), sizes.ctypes.data_as(vp_), n, 3, 16)
+    assert rc == 0
+    d_frames = torch.from_numpy(zb).cuda()
+else:
+    bc.compress_device(d_src.data_ptr(), offs, sizes, d_frames.data_ptr(), foffs, d_fsz.data_ptr(), 3)
+    torch.cuda.synchronize()
+    fsz = d_fsz.cpu().numpy().astype(np.uint32)
 d_out = torch.empty(n * cs, dtype=torch.uint8, device="cuda"); d_osz = torch.zeros(n, dtype=torch.int32, device="cuda")
 def step(): bc.decompress_device(d_frames.data_ptr(), foffs, fsz, d_out.data_ptr(), offs, sizes, d_osz.data_ptr())
 for _ in range(a.warmup): step()

@@ -435,7 +435,10 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
                 LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, blk, cap);
                 // the 2.5 KiB table class: fuller wavefronts (16 items) win when a launch is several rounds of workgroups, emptier ones (4) when it
                 // is less than one (8192 frames of 128 KiB: 83 vs 77 GiB/s; 16384: 117 vs 128)
-                if (cnt >= ZS_FAST_SEQGROUP_MANY)
+                // (r3: and when 4 items a wavefront save a whole round of workgroups - 14 x 4 = 56 items a CU against 3 x 16 = 48 -: 57344 libzstd
+                //  frames of 32 KiB are 4 rounds instead of 5, 3.8 vs 5.2 ms; 16384 of 128 KiB are 2 rounds either way, 6.8 vs 5.6 ms)
+                const uint32_t rounds16 = (cnt + 48u * 256u - 1) / (48u * 256u), rounds4 = (cnt + 56u * 256u - 1) / (56u * 256u);
+                if (cnt >= ZS_FAST_SEQGROUP_MANY && rounds4 >= rounds16)
                     LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, ZS_FAST_SEQGROUP>), dim3((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, blk, cap);
                 else
                     LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, 4u>), dim3((cnt + 3) / 4), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, blk, cap);
