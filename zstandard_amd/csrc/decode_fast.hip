@@ -8,7 +8,7 @@
 //   k_dec_prep      one wavefront per item : headers, Huffman table, sequence tables (all lanes, same code as the general
 //                                            decoder) -> tables + a descriptor in global memory; decides fast / general
 //   k_dec_huffman   one wavefront per 16 items: lane 4g + k decodes Huffman stream k of item g (64 streams at once)
-//   k_dec_sequences one wavefront per 16 items: lane g decodes the sequences of item g (FSE states, recent offsets)
+//   k_dec_sequences one wavefront per 16 items: four lanes an item, one per FSE state (the three states of a sequence side by side)
 //   k_dec_execute   one wavefront per item : literal / match copies of the decoded sequences (execTile of the general decoder)
 //
 // Anything unusual -- another frame shape, a table the fast kernels do not hold (Huffman log 12, > 16384 sequences),
@@ -369,8 +369,8 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_dec_sequences : lane g = item g of the group.  Tables in LDS (2.5 KiB an item: 16-bit cells), bitstream windows in LDS.
-// The per-sequence code is decodeBlock's (:1473-1553); results go to global memory, 12 bytes a sequence.
+// LDS of k_dec_sequences: per item its three tables (16-bit cells) and a window of its bitstream.
+// The per-sequence code is decodeBlock's (:1473-1553); results go to global memory, 8 bytes a sequence (ZsFastSeq).
 // ---------------------------------------------------------------------------------------------------------------------
 #ifndef ZS_FAST_CELLPAD
 #define ZS_FAST_CELLPAD 0
@@ -382,27 +382,47 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
 template <bool LOG9, uint32_t G>
 struct SeqDecLds { uint16_t cells[G][(LOG9 ? 1280 : 768) + ZS_FAST_CELLPAD]; uint32_t win[G][(ZS_FAST_SEQWIN + 8) / 4 + 2]; };
 
+// ---------------------------------------------------------------------------------------------------------------------
+// k_dec_sequences : four lanes an item (lane 4 g + r: item g of the group; r = 0 the literal-length state, 1 the match-length state, 2 the
+// offset state, 3 idle).  Every lane opens ONE cell a step and the quad exchanges bit counts and symbols by data-parallel moves (quad_perm):
+// ~65 instructions a step where one lane an item (round 3's first form: three cells opened one after the other) took ~85 and round 2's
+// branchy form ~140 - and the kernel's time is the instructions it issues: a wavefront is alone on its SIMD (~4.4 cycles an instruction),
+// 16 items a wavefront either way, because the LDS holds no more.  The four lanes of an item carry the same stream position and sequence
+// count, so every branch is uniform inside a quad.  A step is written without branches and with the cell format taken apart by hand:
+//   cell = (1 << (9 - nb) | next >> nb) << 6 | symbol, so with p = cell >> 6:  nb = clz32(p) - 22  and  next = (p << nb) - 512;
+//   the states are kept + 512 (the table pointer - 512 cells), so a new state is (p << nb) + the nb stream bits;
+//   extra bits of a length code (LL_bits / ML_bits, ZStdInternal.cs:158,173) = max((code - c0) >> 1, code >= c0, code >= c1 ? code - c2 : 0)
+//   with (c0, c1, c2) = (16, 25, 19) for literal lengths and (32, 43, 36) for match lengths (arithmetic shift: below c0 all three are <= 0);
+//   an offset code is its own count.
+// One exit test a step: the position against a limit - with a window that does not reach the stream's start, where the next step could read
+// below the window (a sequence reads < 12 bytes; 24 are kept); with one that does, below 0 = the stream ended before the sequences (:1582, :1594).
+// One LDS round trip a step: the cell and the 8 stream bytes below the position are read together (no bit container carried from sequence
+// to sequence).  Bytes below the stream start read as zeros, as in bc_refill.
+// ---------------------------------------------------------------------------------------------------------------------
+#define ZS_QUAD(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true))      // (bound_ctrl: no "old" value to set up; a quad_perm reads valid lanes only)
 template <bool LOG9, uint32_t G>
 __global__ void __launch_bounds__(64)
 k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-                const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t blk, uint32_t cap)
+                  const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t blk, uint32_t cap)
 {
+    static_assert(G <= 16, "four lanes an item");
     __shared__ __attribute__((aligned(16))) SeqDecLds<LOG9, G> S;
     constexpr uint32_t LLC = LOG9 ? 512 : 256, OFB = LLC, MLB = LLC + 256;        // cells of the LL table; where OF and ML start
     const uint32_t lane = (uint32_t)zs_lane();
-    const uint32_t item = blockIdx.x * G + lane;
+    const uint32_t g = lane >> 2, r = lane & 3u;
+    const uint32_t item = blockIdx.x * G + g;
     bool mine = false; uint32_t nbSeq = 0, size = 0, llLog = 0, ofLog = 0, mlLog = 0;
     const uint8_t *src = srcAll;
     const size_t slot0 = (size_t)blk * cap;
-    if (lane < G && item < nItems) {
+    if (g < G && item < nItems) {
         const ZsFastDesc *d = descs + slot0 + item;
         if (descs[item].fast && d->fast && d->nbSeq && ((d->llLog > 8 || d->mlLog > 8) == LOG9)) { mine = true; nbSeq = d->nbSeq; size = d->seqSize; llLog = d->llLog; ofLog = d->ofLog; mlLog = d->mlLog; src = srcAll + items[item].srcOff + d->seqOff; }
     }
     if (!__ballot(mine)) return;
     for (uint32_t gg = 0; gg < G; gg++) {
-        if (!wave_get(mine ? 1u : 0u, (int)gg)) continue;
+        if (!wave_get(mine ? 1u : 0u, (int)(4 * gg))) continue;
         const uint32_t *st = reinterpret_cast<const uint32_t *>(seqTabs + (slot0 + blockIdx.x * G + gg) * ZS_FAST_SEQTAB_BYTES);
-        const uint32_t a = 1u << wave_get(llLog, (int)gg), o = 1u << wave_get(ofLog, (int)gg), m = 1u << wave_get(mlLog, (int)gg);
+        const uint32_t a = 1u << wave_get(llLog, (int)(4 * gg)), o = 1u << wave_get(ofLog, (int)(4 * gg)), m = 1u << wave_get(mlLog, (int)(4 * gg));
         {   // the three tables, two cells a dword: every load issued before the first LDS store (up to 4 + 2 + 4 dwords per lane)
             uint32_t va[4], vo[2], vm[4];
             uint32_t *cw = reinterpret_cast<uint32_t *>(S.cells[gg]);
@@ -422,55 +442,66 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
     }
     BitC b; b.c = 0; b.avail = 0; b.bitPos = 0;
     bool ok = !mine || bc_init(b, src, size);
-    const uint16_t *cells = S.cells[lane & (G - 1)];
-    const uint32_t *win = S.win[lane & (G - 1)];
+    const uint32_t gi = min(g, G - 1u);
+    uint32_t *winW = S.win[gi];
+    const uint32_t *win = winW;
     ZsFastSeq *outp = seqOutAll + (slot0 + item) * ZS_FAST_MAXSEQ;
-    // The loop below is bound by the instructions a step issues (a wavefront is alone on its SIMD: ~4.4 cycles an instruction, and the LDS
-    // holds no more items than these), so a step is written without branches and with the cell format taken apart by hand:
-    //   cell = (1 << (9 - nb) | next >> nb) << 6 | symbol, so with p = cell >> 6:  nb = clz32(p) - 22  and  next = (p << nb) - 512;
-    //   the states are kept + 512 (the table pointer - 512 cells), so a new state is (p << nb) + the nb stream bits;
-    //   extra bits of a length code (LL_bits / ML_bits, ZStdInternal.cs:158,173) = max((code - c0) >> 1, code >= c0, code >= c1 ? code - c2 : 0)
-    //   with (c0, c1, c2) = (16, 25, 19) for literal lengths and (32, 43, 36) for match lengths (arithmetic shift: below c0 all three are <= 0).
-    // One exit test a step: the position against a limit - with a window that does not reach the stream's start, where the next step could read
-    // below the window (a sequence reads < 12 bytes; 24 are kept); with one that does, below 0 = the stream ended before the sequences (:1582, :1594).
-    uint32_t sLL = 512, sOF = 512, sML = 512, t = 0;
-    const uint16_t *cellsB = cells - 512;
+    // what a lane's role fixes: its table, the constants of its code's extra-bit count (see k_dec_sequences; an offset code IS its count),
+    // where its state bits sit below the other states' (LL on top, then ML, then OF, :1547-1550)
+    const uint16_t *cellsB = S.cells[gi] + (r == 1 ? MLB : (r == 2 ? OFB : 0u)) - 512;
+    const int32_t c0 = (r == 1) ? 32 : 16, c1 = (r == 1) ? 43 : 25, c2 = (r == 1) ? 36 : 19;
+    const uint32_t lenMask = (r < 2) ? 0xFFFFFFFFu : 0u, ofMask = (r == 2) ? 63u : 0u, nbMask = (r < 3) ? 0xFu : 0u;
+    const uint32_t aboveM = (r == 0) ? 0xFFu : 0u, aboveO = (r < 2) ? 0xFFu : 0u;       // counts of the states whose bits lie below mine
+    uint32_t st1 = 512, t = 0;                                                           // my state + 512
     bool started = false, done = !mine || !ok;
     #define FSEQ_NEED(nbits) do { if (b.avail < (nbits)) bc_refill(b, win, base); } while (0)
     for (;;) {
         const int32_t base = bc_windowBase(b, ZS_FAST_SEQWIN);
         wave_sync();
-        if (!done) stageOwnWindow<ZS_FAST_SEQWIN>(S.win[lane & (G - 1)], src, size, base);
+        if (!done) {
+            // the item's window, its 16-byte pieces dealt to the four lanes (a first or last window, which sticks out of the stream: lane 0 alone)
+            constexpr uint32_t N = (ZS_FAST_SEQWIN + 8) / 4 + 2;
+            if (base >= 8 && (uint32_t)base - 8u + 4u * N <= size) {
+                const uint8_t *p = src + base - 8;
+                uint4 v[(N / 4 + 3) / 4];
+                #pragma unroll
+                for (uint32_t u = 0; u < (N / 4 + 3) / 4; u++) if (4 * u + r < N / 4) __builtin_memcpy(&v[u], p + 16 * (4 * u + r), 16);
+                #pragma unroll
+                for (uint32_t u = 0; u < (N / 4 + 3) / 4; u++) if (4 * u + r < N / 4) *reinterpret_cast<uint4 *>(winW + 4 * (4 * u + r)) = v[u];
+            } else if (r == 0) stageOwnWindow<ZS_FAST_SEQWIN>(winW, src, size, base);
+        }
         wave_sync();
         if (!done) {
-            if (!started) { FSEQ_NEED(llLog + ofLog + mlLog); sLL = 512 + bc_take(b, llLog); sOF = 512 + bc_take(b, ofLog); sML = 512 + bc_take(b, mlLog); started = true; }
+            if (!started) {
+                FSEQ_NEED(llLog + ofLog + mlLog);
+                const uint32_t iLL = bc_take(b, llLog), iOF = bc_take(b, ofLog), iML = bc_take(b, mlLog);
+                st1 = 512 + (r == 1 ? iML : (r == 2 ? iOF : iLL)); started = true;
+            }
             const int32_t lim = (base > 0) ? 8 * (base + 24) : -1;
             int32_t bp = b.bitPos;
             while (t < nbSeq && bp > lim) {
-                // One LDS round trip a sequence: the three cells and the 8 stream bytes below the position are read together (no bit
-                // container carried from sequence to sequence).  Bytes below the stream start read as zeros, as in bc_refill.
                 const int32_t bh = (bp - 1) >> 3;                        // bp == 0: -1, the 8 zero bytes in front of the stream
-                const uint32_t cLL = cellsB[sLL], cOF = cellsB[OFB + sOF], cML = cellsB[MLB + sML];
+                const uint32_t cell = cellsB[st1];
                 uint64_t raw = win64(win, (uint32_t)(bh - base + 1));
-                asm volatile("" : "+v"(raw));                            // (read here, beside the cells: left to itself hipcc moves the read behind the cells' arithmetic, a second LDS round trip a step)
-                const uint32_t yLL = cLL & 63u, yML = cML & 63u, yOF = cOF & 63u;
-                const uint32_t pL = cLL >> 6, pM = cML >> 6, pO = cOF >> 6;
-                const uint32_t nL = (uint32_t)__builtin_clz(pL) - 22u, nM = (uint32_t)__builtin_clz(pM) - 22u, nO = (uint32_t)__builtin_clz(pO) - 22u;
-                outp[t++] = zs_fastseq((uint32_t)bp, yLL, yML, yOF);
-                const int32_t iL = (int32_t)yLL, iM = (int32_t)yML;
-                const int32_t xL = max(max((iL - 16) >> 1, (int32_t)(iL >= 16)), (iL >= 25) ? iL - 19 : 0);
-                const int32_t xM = max(max((iM - 32) >> 1, (int32_t)(iM >= 32)), (iM >= 43) ? iM - 36 : 0);
-                const uint32_t xbits = (uint32_t)xL + (uint32_t)xM + yOF;                                   // skipped here, read by the execute kernel
-                const uint32_t sbits = nL + nM + nO;
+                asm volatile("" : "+v"(raw));                            // (read here, beside the cell)
+                const uint32_t y = cell & 63u, p = cell >> 6;
+                const uint32_t nb = ((uint32_t)__builtin_clz(p) - 22u) & nbMask;
+                const int32_t iy = (int32_t)y;
+                const uint32_t xLen = (uint32_t)max(max((iy - c0) >> 1, (int32_t)(iy >= c0)), (iy >= c1) ? iy - c2 : 0);
+                const uint32_t xOwn = (xLen & lenMask) | (y & ofMask);
+                // the quad's sums (every lane gets both) and the other states' counts and symbols
+                const uint32_t x2 = xOwn + ZS_QUAD(xOwn, 0xB1), xbits = x2 + ZS_QUAD(x2, 0x4E);
+                const uint32_t n2 = nb + ZS_QUAD(nb, 0xB1), sbits = n2 + ZS_QUAD(n2, 0x4E);
+                const uint32_t nM = ZS_QUAD(nb, 0x55), nO = ZS_QUAD(nb, 0xAA), yML = ZS_QUAD(y, 0x55), yOF = ZS_QUAD(y, 0xAA);
+                if (r == 0) outp[t] = zs_fastseq((uint32_t)bp, y, yML, yOF);
+                t++;
                 uint64_t c = (raw << (7u - (uint32_t)((bp - 1) & 7))) << xbits;     // >= 57 valid bits from the top, the extra bits skipped
                 const int32_t p2 = bp - (int32_t)xbits;
                 if (xbits + sbits > 57u)                                 // rare (a very long offset + long lengths): read again at the state bits
                     c = (p2 <= 0) ? 0ull : win64(win, (uint32_t)(((p2 - 1) >> 3) - base + 1)) << (7u - (uint32_t)((p2 - 1) & 7));
-                const uint32_t x = __builtin_amdgcn_ubfe((uint32_t)(c >> 32), 32u - sbits, sbits);   // LL bits on top, then ML, then OF (:1547-1550)
+                const uint32_t x = __builtin_amdgcn_ubfe((uint32_t)(c >> 32), 32u - sbits, sbits);
                 bp = p2 - (int32_t)sbits;
-                sLL = (pL << nL) + __builtin_amdgcn_ubfe(x, nM + nO, nL);
-                sML = (pM << nM) + __builtin_amdgcn_ubfe(x, nO, nM);
-                sOF = (pO << nO) + __builtin_amdgcn_ubfe(x, 0u, nO);
+                st1 = (p << nb) + __builtin_amdgcn_ubfe(x, (nM & aboveM) + (nO & aboveO), nb);
             }
             b.bitPos = bp;
             if (t < nbSeq && lim < 0) ok = false;                        // stream exhausted before all sequences
@@ -479,9 +510,8 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
         if (!__ballot(!done)) break;
     }
     #undef FSEQ_NEED
-    if (mine && !ok) descs[item].fast = 0;
+    if (mine && !ok && r == 0) descs[item].fast = 0;
 }
-
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The matches of one tile of <= 64 sequences, lane t = sequence t: destination mdst, length ml, offset off (ml == 0: no sequence).
