@@ -91,6 +91,7 @@ def throughput_by_class(bc, args, torch):
     bound = int(bc.L.zsmi_compressBound(cs)); stride = (bound + 255) // 256 * 256
     doffs = np.arange(n, dtype=np.uint64) * stride
     d_dst = torch.empty(n * stride, dtype=torch.uint8, device="cuda"); d_sizes = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_out = torch.empty(nbytes, dtype=torch.uint8, device="cuda"); d_osz = torch.zeros(n, dtype=torch.int32, device="cuda")
     out = {}
     for name, data in classes.items():
         if name == "period1000":
@@ -110,8 +111,18 @@ def throughput_by_class(bc, args, torch):
         csz = d_sizes.cpu().numpy().astype(np.uint32)
         assert (csz < 0xFFFFFF88).all(), name
         out[name] = {"GiB/s": round(nbytes * k / dt / (1 << 30), 1), "ratio": round(nbytes / float(csz.astype(np.uint64).sum()), 3)}
+        # the same frames decoded back (one call of n frames of cs bytes: a smaller call than the decode leg's, so the classes compare with each other, not with it)
+        dstep = lambda: bc.decompress_device(d_dst.data_ptr(), doffs, csz, d_out.data_ptr(), offs, sizes, d_osz.data_ptr())
+        dstep(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(k):
+            dstep()
+        torch.cuda.synchronize()
+        ddt = time.perf_counter() - t0
+        assert (d_osz.cpu().numpy() == cs).all() and torch.equal(d_out, d_src), "decode of class %s" % name
+        out[name]["decode GiB/s"] = round(nbytes * k / ddt / (1 << 30), 1)
         del d_src
-    return {"per_class": out, "note": "%d x %d B chunks per class (1 MiB of the class tiled to %d MiB; period1000: one random 1000-byte string repeated), level %d, %d steps after one warm-up"
+    return {"per_class": out, "note": "%d x %d B chunks per class (1 MiB of the class tiled to %d MiB; period1000: one random 1000-byte string repeated), level %d, %d steps after one warm-up; decode: the frames just built, decoded back in one call and compared with the input"
             % (n, cs, nbytes >> 20, args.level, 5)}
 
 

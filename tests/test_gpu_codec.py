@@ -536,3 +536,25 @@ def test_units_of_one_repeated_byte_skip_the_parse(codec, level):
         assert f == O.compress(c, level), i
         assert O.decompress(f, len(c)) == c, i
     assert len(frames[0]) < 16 and len(frames[2]) < 24
+
+
+def test_decode_wide_alphabets_flat_huffman_table(codec):
+    """literals over all 256 byte values with a long tail of rare ones: more 9-bit prefixes hold 10 / 11-bit codes than the fast path's two-level
+    Huffman table has sub-tables, so k_dec_prep emits the flat 2^11 table and k_dec_huffman's flat class decodes them (before round 3's end such
+    frames - ELF sections, binary tables - fell to the general kernel).  Frames of this codec and, where present, of upstream libzstd; one- and
+    two-block frames; a table of fewer than 11 bits; against the input and oracle D."""
+    rng = np.random.default_rng(17)
+    def skewed(n, decay, seed):
+        r = np.random.default_rng(seed)
+        p = decay ** np.arange(256); p /= p.sum()
+        perm = r.permutation(256).astype(np.uint8)
+        return perm[r.choice(256, size=n, p=p)].tobytes()
+    chunks = [skewed(65536, 0.975, 1), skewed(131072, 0.98, 2), skewed(40000, 0.96, 3), skewed(3000, 0.985, 4), skewed(65536, 0.99, 5), skewed(20000, 0.97, 6)]
+    frames = _compress_many(codec, chunks, 3)
+    if O.libzstd():
+        frames += [O.zstd_compress(c, 3) for c in chunks]
+        chunks = chunks + chunks
+    got = _decompress_many(codec, frames, [len(c) for c in chunks])
+    for i, (g, c, f) in enumerate(zip(got, chunks, frames)):
+        assert g == (len(c), c), i
+        assert O.decompress(f, len(c)) == c, i

@@ -45,6 +45,8 @@ struct ZsFastDesc {                               // per item, global memory, wr
     uint32_t llLog, ofLog, mlLog;
     uint32_t contentSize, hasContentSize;
     uint32_t hasChecksum, checksum;               // content checksum (low 32 bits of XXH64, ZStdDecompress.cs:2078-2082): checked by k_dec_checksum
+    uint32_t hufFlat;                             // 1: the item's Huffman table is the flat one of 2^11 entries (more long-code prefixes than the two-level table has sub-tables)
+    uint32_t why;                                 // which fast kernel handed the item to the general one (1 Huffman stream, 2 sequence stream, 3.. execute: tools/dec_why.py)
 };
 #define ZS_FAST_HUFTAB_BYTES (2u << ZS_FAST_HUFLOG)                       // uint16 entries
 #define ZS_FAST_SEQTAB_BYTES ((512u + 256u + 512u) * 2u)                  // LL, OF, ML cells, 2 bytes each
@@ -123,7 +125,7 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
             fail = true;
             const size_t slot = (size_t)blk * cap + item;
             ZsFastDesc *dp = descs + slot;
-            if (blk == 0) { DSET(hasContentSize, hasContentSize); DSET(contentSize, contentSize); DSET(hasChecksum, checksumFlag); DSET(checksum, checksumFlag ? rd32(src + srcSize - 4) : 0u); }
+            if (blk == 0) { DSET(why, 0u); DSET(hasContentSize, hasContentSize); DSET(contentSize, contentSize); DSET(hasChecksum, checksumFlag); DSET(checksum, checksumFlag ? rd32(src + srcSize - 4) : 0u); }
             // ---- a block (:646-659): compressed; the last one fills the rest of the item ----
             if ((uint64_t)b0 + 3 + tail > srcSize) break;
             const uint32_t bh = rd24(src + b0);
@@ -152,8 +154,10 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                     break;                                          // timing aid: + block and literals headers, no tables
 #endif
                     uint16_t *ht = reinterpret_cast<uint16_t *>(hufTabs + slot * ZS_FAST_HUFTAB_BYTES);
-                    const uint32_t h = readHufTableT<true>(L, bs + lhSize, litCSize, ht, ZS_FAST_HUFLOG);
-                    if (isErr(h) || h >= litCSize || L.hufLog > ZS_FAST_HUFLOG) break;
+                    uint32_t h = readHufTableT<true>(L, bs + lhSize, litCSize, ht, ZS_FAST_HUFLOG);
+                    if (isErr(h)) break;
+                    DSET(hufFlat, h >> 30); h &= 0x3FFFFFFFu;                  // (readHufTableT<true> marks a flat table in bit 30)
+                    if (h >= litCSize || L.hufLog > ZS_FAST_HUFLOG) break;
                     const uint32_t cs0 = b0 + lhSize + h, csz = litCSize - h;
                     DSET(litType, 2u); DSET(litSize, litSize); DSET(hufLog, L.hufLog);
                     if (single) { DSET(nStreams, 1u); DSET(sOff[0], cs0); DSET(sLen[0], csz); DSET(sCnt[0], litSize); DSET(sOut[0], 0u); }
@@ -206,7 +210,7 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
         ok = !fail;
     } while (0);
 #ifdef ZS_PREP_PROFILE
-    if (lane == 0) {          // phases 0-11, then the wavefront's whole time: behind the item's Huffman table (the two-level table ends at 1280 bytes)
+    if (lane == 0 && !descs[item].hufFlat) {          // phases 0-11, then the wavefront's whole time: behind the item's Huffman table (the two-level table ends at 1280 bytes; a flat one fills the slot)
         unsigned long long *o = reinterpret_cast<unsigned long long *>(hufTabs + (size_t)item * ZS_FAST_HUFTAB_BYTES + 2048);
         for (int k = 0; k < 12; k++) o[k] = L.pp[k];
         o[12] = __builtin_amdgcn_s_memtime() - ppStart;
@@ -280,22 +284,27 @@ __device__ __forceinline__ void stageOwnWindow(uint32_t *win, const uint8_t *src
 // k_dec_huffman : lane 4g + k = stream k of item g.  Tables in LDS (16 x 4 KiB), stream windows in LDS, refilled in rounds
 // by all lanes; symbol loop of the general decoder (four symbols per refill, then the careful tail).
 // ---------------------------------------------------------------------------------------------------------------------
-struct HufLds { uint16_t huf[ZS_FAST_GROUP][ZS_HUF2_ENTRIES]; uint32_t win[64][(ZS_FAST_HUFWIN + 8) / 4 + 2]; };     // two-level tables: 1.25 KiB an item
+// Two table classes (as the sequences kernel's): FLAT = false, the two-level table (1.25 KiB an item, 16 items a wavefront); FLAT = true, items
+// whose codes need more sub-tables than it has - wide alphabets, binaries - with the flat table of 2^11 entries (4 KiB an item, 8 items a
+// wavefront = 32 lanes).  Both are launched over all groups; a lane takes its stream only in the kernel of its item's class.
+template <bool FLAT, uint32_t G>
+struct HufLds { uint16_t huf[G][FLAT ? (1u << ZS_FAST_HUFLOG) : ZS_HUF2_ENTRIES]; uint32_t win[4 * G][(ZS_FAST_HUFWIN + 8) / 4 + 2]; };
 
+template <bool FLAT, uint32_t G>
 __global__ void __launch_bounds__(64)
 k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
               const uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ litScratchAll, uint32_t blk, uint32_t cap)
 {
-    __shared__ __attribute__((aligned(16))) HufLds H;
+    __shared__ __attribute__((aligned(16))) HufLds<FLAT, G> H;
     const uint32_t lane = (uint32_t)zs_lane();
     const uint32_t g = lane >> 2, k = lane & 3u;
-    const uint32_t item = blockIdx.x * ZS_FAST_GROUP + g;
+    const uint32_t item = blockIdx.x * G + g;
     bool mine = false; uint32_t dtLog = 1, n = 0, size = 0;
     const uint8_t *src = srcAll; uint8_t *out = litScratchAll;
     const size_t slot0 = (size_t)blk * cap;                          // this block index's descriptors, tables, literal scratch
-    if (item < nItems) {
+    if (g < G && item < nItems) {
         const ZsFastDesc *d = descs + slot0 + item;
-        if (descs[item].fast && d->fast && d->litType == 2 && k < d->nStreams) {
+        if (descs[item].fast && d->fast && d->litType == 2 && k < d->nStreams && (d->hufFlat != 0) == FLAT) {
             mine = true; dtLog = d->hufLog; n = d->sCnt[k]; size = d->sLen[k];
             src = srcAll + items[item].srcOff + d->sOff[k];
             out = litScratchAll + (slot0 + item) * ((1u << 17) + 64) + d->sOut[k];
@@ -303,14 +312,14 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     }
     if (!__ballot(mine)) return;
     // tables of the items that need them
-    for (uint32_t gg = 0; gg < ZS_FAST_GROUP; gg++) {
-        const uint32_t it2 = blockIdx.x * ZS_FAST_GROUP + gg;
+    for (uint32_t gg = 0; gg < G; gg++) {
+        const uint32_t it2 = blockIdx.x * G + gg;
         const uint32_t log2 = wave_get(mine ? dtLog : 0u, (int)(gg * 4));        // stream 0 of the item exists whenever any does
         if (!log2) continue;
         const uint32_t *ht = reinterpret_cast<const uint32_t *>(hufTabs + (slot0 + it2) * ZS_FAST_HUFTAB_BYTES);
         uint32_t *dstw = reinterpret_cast<uint32_t *>(H.huf[gg]);
-        {   // 5 dwords per lane, the loads issued together
-            constexpr uint32_t words = ZS_HUF2_ENTRIES / 2, per = (words + 63) / 64;
+        {   // 5 (flat: 16) dwords per lane, the loads issued together
+            constexpr uint32_t words = (FLAT ? (1u << ZS_FAST_HUFLOG) : ZS_HUF2_ENTRIES) / 2, per = (words + 63) / 64;
             uint32_t v[per];
             #pragma unroll
             for (uint32_t u = 0; u < per; u++) v[u] = (lane + 64 * u < words) ? ht[lane + 64 * u] : 0u;
@@ -322,12 +331,12 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     bool ok = !mine || bc_init(b, src, size);
     uint32_t i = 0;
     bool done = !mine || !ok || n == 0;
-    const uint16_t *huf = H.huf[g];
-    const uint32_t *win = H.win[lane];
+    const uint16_t *huf = H.huf[min(g, G - 1u)];
+    const uint32_t *win = H.win[min(lane, 4u * G - 1u)];
     for (;;) {
         const int32_t base = bc_windowBase(b, ZS_FAST_HUFWIN);
         wave_sync();
-        if (!done) stageOwnWindow<ZS_FAST_HUFWIN>(H.win[lane], src, size, base);
+        if (!done) stageOwnWindow<ZS_FAST_HUFWIN>(H.win[min(lane, 4u * G - 1u)], src, size, base);
         wave_sync();
         if (!done) {
             while (i + 4 <= n) {
@@ -338,8 +347,8 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
                 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     const uint32_t top = (uint32_t)(c >> 32);
-                    uint32_t e = huf[top >> 23];                                   // 9 bits; codes of 10 / 11 bits: 2 more in a sub-table
-                    if (e & 0x8000u) e = huf[512u + ((e & 0x7FFFu) << 2) + ((top >> 21) & 3u)];
+                    uint32_t e = FLAT ? huf[top >> 21] : huf[top >> 23];             // 9 bits; codes of 10 / 11 bits: 2 more in a sub-table (flat: 11 bits at once)
+                    if (!FLAT && (e & 0x8000u)) e = huf[512u + ((e & 0x7FFFu) << 2) + ((top >> 21) & 3u)];
                     const uint32_t nb = e >> 8;
                     c <<= nb; used += nb; pack |= (e & 0xFFu) << (8 * q);
                 }
@@ -354,8 +363,8 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
                     bc_refill(b, win, base);
                 }
                 const uint32_t top = (uint32_t)(b.c >> 32);
-                uint32_t e = huf[top >> 23];
-                if (e & 0x8000u) e = huf[512u + ((e & 0x7FFFu) << 2) + ((top >> 21) & 3u)];
+                uint32_t e = FLAT ? huf[top >> 21] : huf[top >> 23];
+                if (!FLAT && (e & 0x8000u)) e = huf[512u + ((e & 0x7FFFu) << 2) + ((top >> 21) & 3u)];
                 const uint32_t nb = e >> 8;
                 b.c <<= nb; b.avail -= nb; b.bitPos -= (int32_t)nb;
                 out[i++] = (uint8_t)e;
@@ -365,7 +374,7 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
         if (!__ballot(!done)) break;
     }
     // a stream must end exactly (BitStream.cs:494); otherwise the general decoder takes the item
-    if (mine && (!ok || b.bitPos != 0)) descs[item].fast = 0;
+    if (mine && (!ok || b.bitPos != 0)) { descs[item].fast = 0; descs[item].why = 1; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -510,7 +519,7 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
         if (!__ballot(!done)) break;
     }
     #undef FSEQ_NEED
-    if (mine && !ok && r == 0) descs[item].fast = 0;
+    if (mine && !ok && r == 0) { descs[item].fast = 0; descs[item].why = 2; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -723,7 +732,7 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     const ZsDecItem it = items[itemU];
     uint8_t *dstBase = dstAll + it.dstOff;
     const uint64_t oend = it.dstCap;
-    uint64_t op = 0; bool bad = false;
+    uint64_t op = 0; bool bad = false; uint32_t why = 0;
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                                      // the list carried from tile to tile and block to block (lane 0 holds it)
 #ifdef ZS_EXEC_PROFILE
     uint64_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const uint64_t pfStart = __builtin_amdgcn_s_memtime(); uint64_t pfMark = pfStart;
@@ -784,7 +793,7 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
             tiles[w][1][lane] = mlBase + mlBits;
             // class in the top bits: 0..3 = recent-offset code (with the "literal length 0" shift applied), 4 = a new offset
             tiles[w][2][lane] = (ofAdd <= 1) ? ((ofVal + (llBase == 0)) << 29) : ((4u << 29) | ofVal);
-            if (ofAdd > 28) bad = true;                                         // an offset that does not fit beside the class: general decoder
+            if (ofAdd > 28) { bad = true; why = 3; }                                         // an offset that does not fit beside the class: general decoder
         }
         if (__ballot(bad)) { bad = true; break; }
         wave_sync();
@@ -859,7 +868,7 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
                     }
                 }
             }
-            if (__ballot(e)) { bad = true; break; }
+            if (__ballot(e)) { bad = true; why = 4; break; }
             op += wave_last(incl); litPos += wave_last(inclL);
         }
         wave_sync();
@@ -881,7 +890,7 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
 #if ZS_EXEC_PREEXPAND
     if (!bad) {
         const uint32_t lastLL = d.litSize - litPos;
-        if (lastLL > oend - op) bad = true;
+        if (lastLL > oend - op) { bad = true; why = 5; }
         else {
             const uint32_t blockStart = blockStart32, blockEnd = (uint32_t)op + lastLL;
             uint32_t *bm = litBits[w];
@@ -975,8 +984,9 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     }
 #endif
     }   // blocks of the item
-    if (!bad && hasContentSize && op != contentSize) bad = true;
-    if (lane == 0) { if (bad) descs[item].fast = 0; else dstSizes[item] = (uint32_t)op; }
+    if (!bad && hasContentSize && op != contentSize) { bad = true; why = 6; }
+    if (__ballot(bad)) { const uint32_t wmax = wave_max(why); if (lane == 0) { descs[item].fast = 0; descs[item].why = wmax ? wmax : 7u; } }
+    else if (lane == 0) dstSizes[item] = (uint32_t)op;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------

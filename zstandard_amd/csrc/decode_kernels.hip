@@ -498,7 +498,28 @@ __device__ __forceinline__ uint32_t readHufTableT(DLds &L, const uint8_t *src, u
         #pragma unroll
         for (uint32_t q = 0; q < 8; q++) { ent[q] = sEntry[r[q]]; cnt += (ent[q] >> 8) > 9u; }
         const uint32_t incl = wave_incl_scan(cnt);
-        if (wave_last(incl) > ZS_HUF2_SUBS) return ZE(E_tableLog_tooLarge);
+        if (wave_last(incl) > ZS_HUF2_SUBS) {
+            // more long-code prefixes than sub-tables (wide alphabets: binaries): the FLAT table of 2^11 entries instead (4 KiB, the slot's whole
+            // room; k_dec_huffman's flat class).  Lane l owns entries 32 l .. 32 l + 31: a search for the first, then along the cell-ordered symbols.
+            const uint32_t sh = 11u - tableLog;                                  // a table of fewer bits is spread out
+            const uint32_t j0 = (32u * lane) >> sh;
+            uint32_t rr = 0;
+            #pragma unroll
+            for (uint32_t step = 128; step >= 1; step >>= 1) if (sStart[rr + step] <= j0) rr += step;
+            uint32_t pk[16];
+            #pragma unroll
+            for (uint32_t q = 0; q < 32; q++) {
+                const uint32_t j = (32u * lane + q) >> sh;
+                while (sStart[rr + 1] <= j) rr++;
+                const uint32_t e = sEntry[rr];
+                if (q & 1u) pk[q >> 1] |= e << 16; else pk[q >> 1] = e;
+            }
+            #pragma unroll
+            for (uint32_t q = 0; q < 4; q++) *reinterpret_cast<uint4 *>(hufGlobal + 32 * lane + 8 * q) = make_uint4(pk[4 * q], pk[4 * q + 1], pk[4 * q + 2], pk[4 * q + 3]);
+            wave_sync();
+            PPROF(L, 6);
+            return (iSize + 1) | 0x40000000u;                                    // (bit 30: the flat table; header sizes are < 2^17)
+        }
         uint32_t id = incl - cnt;
         #pragma unroll
         for (uint32_t q = 0; q < 8; q++) {

@@ -431,7 +431,8 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
             LAUNCH(c, "k_dec_prep", (k_dec_prep<ZS_DEC_GROUP>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc, dI, cnt, dD,
                    (uint8_t *)c->dHufTabs.p, (uint8_t *)c->dSeqTabs.p, cap, maxBlocks);
             for (uint32_t blk = 0; blk < maxBlocks; blk++) {          // block index 1: the second block of two-block frames (a wavefront without one leaves at once)
-                LAUNCH(c, "k_dec_huffman", k_dec_huffman, dim3(groups), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, blk, cap);
+                LAUNCH(c, "k_dec_huffman", (k_dec_huffman<false, ZS_FAST_GROUP>), dim3(groups), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, blk, cap);
+                LAUNCH(c, "k_dec_huffman", (k_dec_huffman<true, 8u>), dim3((cnt + 7) / 8), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, blk, cap);
                 LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, blk, cap);
                 // the 2.5 KiB table class: fuller wavefronts (16 items) win when a launch is several rounds of workgroups, emptier ones (4) when it
                 // is less than one (8192 frames of 128 KiB: 83 vs 77 GiB/s; 16384: 117 vs 128)
@@ -726,7 +727,7 @@ extern "C" int zsmi_dbg_copyScratch(zsmi_ctx *c, int which, void *hostDst, size_
     if (!c) return -1;
     (void)hipStreamSynchronize(c->stream);
     zsmi_ctx::Scratch &L0 = c->lanes[0];
-    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : which == 4 ? &L0.dDistHi : which == 7 ? &L0.dRecs : which == 8 ? &L0.dRes : which == 5 ? &c->dLitScratch : which == 9 ? &c->dHufTabs : &L0.dMetas;
+    DevBuf *b = which == 0 ? &L0.dDist : which == 1 ? &L0.dSeqs : which == 2 ? &L0.dHdrs : which == 4 ? &L0.dDistHi : which == 7 ? &L0.dRecs : which == 8 ? &L0.dRes : which == 5 ? &c->dLitScratch : which == 9 ? &c->dHufTabs : which == 10 ? &c->dFastDesc : &L0.dMetas;
     if (bytes > b->cap) return -2;
     return hipMemcpy(hostDst, b->p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -3;
 }
