@@ -21,7 +21,9 @@
 
 #define ZS_FAST_HUFLOG   11u                      // Huffman tables the fast kernel holds: 2^11 entries per item
 #define ZS_FAST_MAXSEQ   16384u                   // sequences per block the fast path buffers (8 bytes each)
+#ifndef ZS_FAST_HUFWIN
 #define ZS_FAST_HUFWIN   128u                     // bytes of each Huffman stream staged in LDS at a time
+#endif
 #ifndef ZS_FAST_SEQWIN
 #define ZS_FAST_SEQWIN   256u
 #endif                     // bytes of each sequence bitstream staged in LDS at a time
