@@ -119,9 +119,6 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
         const uint32_t hasContentSize = fcs != ~0ull, contentSize = (uint32_t)fcs;
         uint32_t b0 = fhs;                                          // offset of the next block header in the item
         bool fail = false;
-#if defined(ZS_PREP_STOP) && ZS_PREP_STOP == 1
-        break;                                                      // timing aid: the frame header only
-#endif
         #pragma unroll 1
         for (uint32_t blk = 0; blk < maxBlocks && !fail; blk++) {
             fail = true;
@@ -152,9 +149,6 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                     else { lhSize = 5; litSize = (lhc >> 4) & 0x3FFFF; litCSize = (lhc >> 22) + ((uint32_t)bs[4] << 10); }
                     if (litSize > (1u << 17) || litCSize + lhSize > cSize) break;
                     if (!single && (litSize == 0 || litCSize == 0)) break;
-#if defined(ZS_PREP_STOP) && ZS_PREP_STOP == 3
-                    break;                                          // timing aid: + block and literals headers, no tables
-#endif
                     uint16_t *ht = reinterpret_cast<uint16_t *>(hufTabs + slot * ZS_FAST_HUFTAB_BYTES);
                     uint32_t h = readHufTableT<true>(L, bs + lhSize, litCSize, ht, ZS_FAST_HUFLOG);
                     if (isErr(h)) break;
@@ -189,9 +183,6 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                 }
             }
             if (litCSizeTot > cSize) break;
-#if defined(ZS_PREP_STOP) && ZS_PREP_STOP == 2
-            break;                                                  // timing aid: + block and literals headers, the Huffman table
-#endif
             // ---- sequence headers + tables (:1110-1180), then the tables leave for the sequences kernel.  st.fseEntropy stays 0: a
             //      table repeated from the block before (mode 3) is an error here and sends the item to the general kernel ----
             const uint8_t *ip = bs + litCSizeTot; uint32_t remaining = cSize - litCSizeTot, nbSeq = 0;
@@ -383,15 +374,12 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
 // LDS of k_dec_sequences: per item its three tables (16-bit cells) and a window of its bitstream.
 // The per-sequence code is decodeBlock's (:1473-1553); results go to global memory, 8 bytes a sequence (ZsFastSeq).
 // ---------------------------------------------------------------------------------------------------------------------
-#ifndef ZS_FAST_CELLPAD
-#define ZS_FAST_CELLPAD 0
-#endif
 // The kernel comes in two table sizes: LOG9 = false holds items whose LL and ML tables have <= 2^8 cells (blocks of <= 2048
 // sequences get such tables: FSE_optimalTableLog) in 1.5 KiB, LOG9 = true the rest in 2.5 KiB.  How many items a CU decodes
 // at once is set by that LDS share, and the kernel's time by how many it decodes at once.  Both are launched over all
 // groups; a lane takes its item only in the kernel of the item's class.
 template <bool LOG9, uint32_t G>
-struct SeqDecLds { uint16_t cells[G][(LOG9 ? 1280 : 768) + ZS_FAST_CELLPAD]; uint32_t win[G][(ZS_FAST_SEQWIN + 8) / 4 + 2]; };
+struct SeqDecLds { uint16_t cells[G][(LOG9 ? 1280 : 768)]; uint32_t win[G][(ZS_FAST_SEQWIN + 8) / 4 + 2]; };
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_dec_sequences : four lanes an item (lane 4 g + r: item g of the group; r = 0 the literal-length state, 1 the match-length state, 2 the
@@ -526,30 +514,22 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
 
 // ---------------------------------------------------------------------------------------------------------------------
 // The matches of one tile of <= 64 sequences, lane t = sequence t: destination mdst, length ml, offset off (ml == 0: no sequence).
-// The literals of the whole block are in place already (k_dec_execute expands them before any match).  Same order rules as
-// execTileT in decode_kernels.hip: matches whose source ends before the tile's first output byte side by side, then the matches
-// that read this tile's own output in groups none of whose members reads what the group writes.
+// The literals of the whole block are in place already (k_dec_execute expands them before any match).  Order: matches whose source ends
+// before the tile's first output byte side by side, then the matches that read this tile's own output - their sources first redirected
+// through the matches they read, what is left level by level of its dependence (below).  Between a round's stores and the next round's loads
+// of the same bytes the wavefront waits for its stores (wave_mem_sync: a workgroup-scope fence, s_waitcnt vmcnt(0)); dropping the wait changed
+// nothing (the wait for a round's loads covers the stores before them: loads and stores share the counter).
 // ---------------------------------------------------------------------------------------------------------------------
-// Between a store and a later load of the same bytes by the SAME wavefront: with ZS_EXEC_FENCE the wavefront waits until its stores are
-// acknowledged (a workgroup-scope fence: s_waitcnt vmcnt(0)); without, only the compiler is kept from reordering, and the order is the
-// memory pipeline's (a wavefront's vector-memory instructions reach the L1 / L2 in issue order).
 #ifndef ZS_EXEC_ROUNDS
 #define ZS_EXEC_ROUNDS 3                // rounds of pointer jumping a tile's matches get (what is left after them stays a dependent match)
 #endif
-#ifndef ZS_EXEC_NOFENCE
-#define ZS_EXEC_ORDER() wave_mem_sync()
-#else
-#define ZS_EXEC_ORDER() wave_sync()
-#endif
 __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, uint32_t off, uint8_t *dstBase, uint32_t tileStart, uint32_t safeEnd, uint32_t *lds3)
 {
-    // The kernel is bound by the NUMBER of vector-memory instructions its wavefronts issue (tools/probe/vmem_rate.hip: ~7 ns of CU time per
-    // instruction with a few lanes active, ~19 ns with all 64; profiles/r3_c_decode_pmc_summary.csv: the texture addresser busy all the
-    // kernel's time), so every piece below is an instruction only if some lane needs it, and short matches share the first load.
+    // Every piece below is an instruction only if some lane needs it, and short matches share the first load (a vector-memory instruction
+    // costs a CU ~7 ns with a few lanes active, ~19 ns with all 64: tools/probe/vmem_rate.hip; the rounds themselves are latency).
     const uint32_t lane = (uint32_t)zs_lane();
     uint32_t msrc = mdst - off;
     lds3[lane] = ml ? mdst : 0xFFFFFFFFu;                                // the tile's match destinations, ascending over the lanes; lanes without a sequence behind every position
-#ifndef ZS_EXEC_NOREDIRECT
     // A match that reads this tile's own output waits for the matches that write it: a memory round trip per level of that dependence
     // (measured on the bench frames: 24 such matches a tile, 8.7 rounds).  Most of those sources lie INSIDE the destination of one earlier
     // match of the tile, whose bytes are a copy themselves: the reader takes them from that match's source instead (and so on: every lane
@@ -575,7 +555,6 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
             wave_sync();
         }
     }
-#endif
     wave_sync();
     const uint32_t effOff = mdst - msrc;                                 // (>= off: the same bytes from further back)
     const bool indep = ml && (msrc + ml <= tileStart);
@@ -627,11 +606,10 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
         const int t = __builtin_ctzll(lm);
         copyLong(wave_get(ml, t), 0xFFFFFFFFu, wave_get(msrc, t), wave_get(mdst, t));
     }
-    ZS_EXEC_ORDER();
+    wave_mem_sync();
 #if defined(ZS_EXEC_STOP) && ZS_EXEC_STOP == 3
     return;                                                              // timing aid: no matches that read their own tile
 #endif
-#ifndef ZS_EXEC_NOLEVELS
     // The matches left read this tile's output across a sequence border.  Each waits for exactly the earlier matches of the tile whose
     // destination its source touches - a run of lanes [a, b], found in the sorted destinations - and only while those are pending: a round
     // copies every pending match none of whose run is pending (the first pending one always is such), so the rounds are the levels of the
@@ -661,43 +639,23 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
                 const uint64_t grp = __ballot(in);
                 const bool self = in && (off < ml);
                 if (__ballot(in && !self && ml <= 32)) copyShort(in && !self && ml <= 32);
+#if defined(ZS_EXEC_STOP) && ZS_EXEC_STOP == 4
+                if (0)                                                   // timing aid: rounds without their long / overlapping matches
+#endif
                 for (uint64_t lm = __ballot(in && (self || ml > 32)); lm; lm &= lm - 1) {
                     const int t = __builtin_ctzll(lm);
                     copyLong(wave_get(ml, t), wave_get(effOff, t), wave_get(msrc, t), wave_get(mdst, t));
                 }
-                ZS_EXEC_ORDER();
+                wave_mem_sync();
                 pend &= ~grp;
             }
         }
     }
-    return;
-#endif
-    for (uint64_t rem = __ballot(ml && !indep); rem; ) {
-        const int g0 = __builtin_ctzll(rem);
-        const uint32_t lo = wave_get(mdst, g0);
-        const uint64_t viol = __ballot(((rem >> lane) & 1ull) && (int)lane > g0 && (msrc + ml > lo));
-        const uint64_t grp = viol ? (rem & ((1ull << __builtin_ctzll(viol)) - 1ull)) : rem;
-        const bool in = (grp >> lane) & 1ull;
-        const bool self = in && (off < ml);                              // only lane g0 can be
-        if (__ballot(in && !self && ml <= 32)) copyShort(in && !self && ml <= 32);
-#if defined(ZS_EXEC_STOP) && ZS_EXEC_STOP == 4
-        if (0)                                                           // timing aid: groups without their long / overlapping matches
-#endif
-        for (uint64_t lm = __ballot(in && (self || ml > 32)); lm; lm &= lm - 1) {
-            const int t = __builtin_ctzll(lm);
-            copyLong(wave_get(ml, t), wave_get(effOff, t), wave_get(msrc, t), wave_get(mdst, t));
-        }
-        ZS_EXEC_ORDER();
-        rem &= ~grp;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_dec_execute : one wavefront per item: the decoded sequences, 64 at a time, through execTile; last literals; size check.
+// k_dec_execute : one wavefront per item: pass A over the decoded sequences (64 at a time), the block's literals, its matches; size check.
 // ---------------------------------------------------------------------------------------------------------------------
-#ifndef ZS_EXEC_PREEXPAND
-#define ZS_EXEC_PREEXPAND 1             // 1: a block's literals are spread into the output before its matches (0: literals tile by tile, execTile)
-#endif
 #define ZS_EXEC_WINDOW 32768u           // output bytes whose literal bits a wavefront holds in LDS at a time
 #ifndef ZS_EXEC_MINWG
 #define ZS_EXEC_MINWG 6                 // 6 workgroups = 6 wavefronts per SIMD at <= 80 VGPRs (24 bytes of spill); measured 1: 5.86 ms, 6: 5.42, 7: 5.43, 8: 6.46
@@ -709,21 +667,17 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
 {
     __shared__ uint32_t tiles[F][3][64];
     __shared__ uint32_t codeTabs[36 + 53];                                      // base | extra bits << 24 of the LL / ML codes
-#if ZS_EXEC_PREEXPAND
     __shared__ uint32_t litBits[F][ZS_EXEC_WINDOW / 32 + 4];                   // a bit per output byte of the window: toggles at match ends -> inside a match -> literal
     __shared__ uint32_t expSel[16];                                             // v_perm selectors that spread the next literals over a 4-bit mask's set bytes
-#endif
     const uint32_t w = threadIdx.x >> 6, lane = (uint32_t)zs_lane();
     const uint32_t item = blockIdx.x * F + w;
     if (threadIdx.x < 36) codeTabs[threadIdx.x] = d_LL_base[threadIdx.x] | ((uint32_t)d_LL_bits[threadIdx.x] << 24);
     else if (threadIdx.x >= 64 && threadIdx.x < 64 + 53) codeTabs[36 + threadIdx.x - 64] = d_ML_base[threadIdx.x - 64] | ((uint32_t)d_ML_bits[threadIdx.x - 64] << 24);
-#if ZS_EXEC_PREEXPAND
     if (threadIdx.x >= 128 && threadIdx.x < 144) {
         const uint32_t m = threadIdx.x - 128; uint32_t sel = 0, k = 0;
         for (uint32_t j = 0; j < 4; j++) { if (m & (1u << j)) { sel |= k << (8 * j); k++; } else sel |= 0x0Cu << (8 * j); }
         expSel[m] = sel;
     }
-#endif
     __syncthreads();                                                            // the only workgroup barrier: before any wavefront leaves
     if (item >= nItems) return;
     // the item index is the same in every lane: said so, its descriptor and item record are scalar loads (27 + 6 registers that
@@ -736,9 +690,6 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     const uint64_t oend = it.dstCap;
     uint64_t op = 0; bool bad = false; uint32_t why = 0;
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                                      // the list carried from tile to tile and block to block (lane 0 holds it)
-#ifdef ZS_EXEC_PROFILE
-    uint64_t pf[8] = {0, 0, 0, 0, 0, 0, 0, 0}; const uint64_t pfStart = __builtin_amdgcn_s_memtime(); uint64_t pfMark = pfStart;
-#endif
     #pragma unroll 1
     for (uint32_t blk = 0; blk < 2 && !bad; blk++) {
     const size_t slot = (size_t)blk * cap + itemU;
@@ -763,10 +714,8 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     };
     uint32_t litPos = 0;
     const uint32_t blockStart32 = (uint32_t)op; (void)blockStart32;       // where this block's output starts (a 32-bit position: the item's capacity is a 32-bit count)
-#if ZS_EXEC_PREEXPAND
     for (uint32_t i = lane; i < ZS_EXEC_WINDOW / 32 + 4; i += 64) litBits[w][i] = 0;      // pass A toggles the first window's bits as it goes
     wave_sync();
-#endif
     for (uint32_t t0 = 0; t0 < d.nbSeq; t0 += 64) {
         const uint32_t T = min(64u, d.nbSeq - t0);
         // lane t: the extra bits of sequence t0 + t (:1487-1545) -> lengths, offset value and its recent-offset class
@@ -849,7 +798,6 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
             }
         }
         wave_sync();
-#if ZS_EXEC_PREEXPAND
         {   // pass A: positions and the reference's checks (ExecSequence :1265-1352; any failure hands the item to the general decoder);
             // the sequence goes back to its 8-byte slot as (ll + ml) | ml << 18 | offset << 35 for the two passes below
             const uint32_t ll = (lane < T) ? tiles[w][0][lane] : 0u, ml = (lane < T) ? tiles[w][1][lane] : 0u, off = (lane < T) ? tiles[w][2][lane] : 0u;
@@ -875,21 +823,6 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
         }
         wave_sync();
     }
-#else
-#ifdef ZS_EXEC_PROFILE
-        { const uint64_t now = __builtin_amdgcn_s_memtime(); pf[3] += now - pfMark; }          // records, bits, recent offsets
-        if (execTile(tiles[w][0], tiles[w][1], tiles[w][2], T, dstBase, 0, oend, litPtr, d.litSize, op, litPos, pf)) { bad = true; break; }
-        pfMark = __builtin_amdgcn_s_memtime();
-#else
-        if (execTile(tiles[w][0], tiles[w][1], tiles[w][2], T, dstBase, 0, oend, litPtr, d.litSize, op, litPos)) { bad = true; break; }
-#endif
-        wave_sync();
-    }
-#ifdef ZS_EXEC_PROFILE
-    if (lane == 0 && blk == 0) { uint64_t *o = reinterpret_cast<uint64_t *>(litBuf + (1u << 17)); pf[4] = __builtin_amdgcn_s_memtime() - pfStart; pf[5] = d.nbSeq; for (int k = 0; k < 8; k++) o[k] = pf[k]; }
-#endif
-#endif
-#if ZS_EXEC_PREEXPAND
     if (!bad) {
         const uint32_t lastLL = d.litSize - litPos;
         if (lastLL > oend - op) { bad = true; why = 5; }
@@ -977,14 +910,6 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
             wave_mem_sync();                                              // the next block's matches read these bytes
         }
     }
-#else
-    if (!bad) {
-        const uint32_t lastLL = d.litSize - litPos;
-        if (lastLL > oend - op) bad = true;
-        else { for (uint32_t j = lane; j < lastLL; j += 64) dstBase[op + j] = litPtr[litPos + j]; op += lastLL; }
-        wave_mem_sync();                                                        // the next block's matches read these bytes
-    }
-#endif
     }   // blocks of the item
     if (!bad && hasContentSize && op != contentSize) { bad = true; why = 6; }
     if (__ballot(bad)) { const uint32_t wmax = wave_max(why); if (lane == 0) { descs[item].fast = 0; descs[item].why = wmax ? wmax : 7u; } }

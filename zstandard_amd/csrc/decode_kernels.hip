@@ -379,9 +379,6 @@ __device__ __forceinline__ uint32_t readHufTableT(DLds &L, const uint8_t *src, u
         if (isErr(r)) return r;
         oSize = r;
     }
-#if defined(ZS_PREP_STOP) && ZS_PREP_STOP == 4
-    return ZE(E_GENERIC);                                                   // timing aid: the weights only
-#endif
     // ---- from here on all lanes.  weights[0 .. oSize) are known; the last symbol's weight is implied ----
     uint32_t wgt[4]; uint32_t weightTotal = 0; bool bad = false;
     #pragma unroll
@@ -461,9 +458,6 @@ __device__ __forceinline__ uint32_t readHufTableT(DLds &L, const uint8_t *src, u
         mism = wave_get(mism, 0);
         if (mism) return 0xFF000000u | mism;
     }
-#endif
-#if defined(ZS_PREP_STOP) && ZS_PREP_STOP == 5
-    return ZE(E_GENERIC);                                                   // timing aid: + ranks and start cells
 #endif
     PPROF(L, 5);
     if (!TO_GLOBAL)
@@ -760,25 +754,13 @@ __device__ static uint64_t xxh64(const uint8_t *p, uint64_t len)
 struct DState { uint32_t rep[3]; uint32_t litEntropy, fseEntropy; uint32_t llRepeatOk; uint32_t hufX4; };   // hufX4: the reference built the current Huffman table for its double-symbol decoder
 
 // ---- one tile of <= 64 decoded sequences (L.u.sq.tile*) -> output bytes.  Returns 0 or an error; advances op / litPos. ----
-#ifdef ZS_EXEC_PROFILE          // development aid (tools/exec_profile.py): s_memtime per phase of execTile, summed per item
-#define ZS_PF_PARAM , uint64_t *pf
-#define ZS_PF_STAMP(k) { const uint64_t now_ = __builtin_amdgcn_s_memtime(); pf[k] += now_ - pfT; pfT = now_; }
-#define ZS_PF_DUMMY , pfDummy
-#else
-#define ZS_PF_PARAM
-#define ZS_PF_STAMP(k)
-#define ZS_PF_DUMMY
-#endif
 // DICT: a dictionary's content is the segment in front of the frame (RefDictContent :2366, CheckContinuity :1911): offsets may reach
 // dictSize bytes beyond the frame's start (:1290-1315); dictEnd = one past the content's last byte.
 template <bool DICT>
 __device__ __forceinline__ uint32_t execTileT(const uint32_t *tileLL, const uint32_t *tileML, const uint32_t *tileOff, uint32_t T, uint8_t *dstBase,
                                               uint64_t frameStart, uint64_t oend, const uint8_t *litPtr, uint32_t litSize, uint64_t &op, uint32_t &litPos,
-                                              const uint8_t *dictEnd, uint32_t dictSize ZS_PF_PARAM)
+                                              const uint8_t *dictEnd, uint32_t dictSize)
 {
-#ifdef ZS_EXEC_PROFILE
-    uint64_t pfT = __builtin_amdgcn_s_memtime();
-#endif
     const uint32_t lane = (uint32_t)zs_lane();
     // execute the tile (ExecSequence :1265-1352).  Lane t owns sequence t: output positions by prefix sums, the checks
     // of the reference in its order (the first failing sequence decides), then all literal runs at once, then all
@@ -851,7 +833,6 @@ __device__ __forceinline__ uint32_t execTileT(const uint32_t *tileLL, const uint
             stores();
             while (lm) { take(); loads(); stores(); }
         }
-        ZS_PF_STAMP(0)                                                        // scans, checks, literals (no wait: the next matches read older output)
         // matches reading only output that existed before this tile
         const uint32_t msrc = mdst - off;                             // (wraps for a match that starts in the dictionary: not used then)
         const bool inDict = DICT && ml && off > mdst - (uint32_t)frameStart;
@@ -877,7 +858,6 @@ __device__ __forceinline__ uint32_t execTileT(const uint32_t *tileLL, const uint
             for (uint32_t j = lane; j < m2; j += 64) dstBase[d2 + j] = dstBase[s2 + j];
         }
         wave_mem_sync();
-        ZS_PF_STAMP(1)                                                        // matches from before the tile
         // matches reading this tile's own output (earlier sequences are complete by then): in order, a group at a time.  A group
         // is a run of such matches none of which reads what the group writes -- destinations ascend, so that is: every source ends
         // at or before the FIRST member's destination.  Its members copy side by side (a lane each, like the matches above); only
@@ -918,17 +898,11 @@ __device__ __forceinline__ uint32_t execTileT(const uint32_t *tileLL, const uint
             wave_mem_sync();
             rem &= ~grp;
         }
-        ZS_PF_STAMP(2)                                                        // matches inside the tile
         op += wave_last(incl);
         litPos += wave_last(inclL);
     }
     return 0;
 }
-#ifdef ZS_EXEC_PROFILE
-#define execTile(a, b, c, T, d, fs, oe, lp, ls, op, lpos, pf) execTileT<false>(a, b, c, T, d, fs, oe, lp, ls, op, lpos, nullptr, 0u, pf)
-#else
-#define execTile(a, b, c, T, d, fs, oe, lp, ls, op, lpos) execTileT<false>(a, b, c, T, d, fs, oe, lp, ls, op, lpos, nullptr, 0u)
-#endif
 
 // A fast-path table cell in 16 bits (half the LDS of a 4-byte cell = twice the items a CU decodes at once): the symbol in
 // bits 0-5; above it 1 << (9 - nbBits) | (nextState >> nbBits).  nextState is a multiple of 2^nbBits, one of 2^(tableLog -
@@ -1164,10 +1138,7 @@ __device__ __forceinline__ uint32_t decodeBlock(DLds &L, DState &st, uint8_t *ds
             wave_sync();
             PROF_ADD(2);
             if (L.misc[0]) return ZE(E_corruption_detected);
-#ifdef ZS_EXEC_PROFILE
-            uint64_t pfDummy[8];
-#endif
-            { const uint32_t e = execTileT<DICT>(L.u.sq.tileLL, L.u.sq.tileML, L.u.sq.tileOff, T, dstBase, frameStart, oend, litPtr, litSize, op, litPos, dictEnd, dictSize ZS_PF_DUMMY); if (e) return e; }
+            { const uint32_t e = execTileT<DICT>(L.u.sq.tileLL, L.u.sq.tileML, L.u.sq.tileOff, T, dstBase, frameStart, oend, litPtr, litSize, op, litPos, dictEnd, dictSize); if (e) return e; }
             PROF_ADD(3);
             left -= T;
         }
