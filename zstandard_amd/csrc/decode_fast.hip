@@ -5,11 +5,12 @@
 // output position and the recent offsets (ZStdDecompress.cs:1596).  A second block that repeats tables (literals type 3,
 // sequence mode 3: ZStdDecompress.cs:696-697, 1062-1064) leaves the item to the general kernel.  The serial entropy decoders run lane-parallel ACROSS frames:
 //
-//   k_dec_prep      one wavefront per item : headers, Huffman table, sequence tables (all lanes, same code as the general
-//                                            decoder) -> tables + a descriptor in global memory; decides fast / general
-//   k_dec_huffman   one wavefront per 16 items: lane 4g + k decodes Huffman stream k of item g (64 streams at once)
+//   k_dec_prep      one wavefront per item : headers, Huffman table (two-level; flat 2^11 for wide alphabets), sequence tables (all lanes build,
+//                                            one lane parses the counts) -> tables + a descriptor in global memory; decides fast / general
+//   k_dec_huffman   one wavefront per 16 items: lane 4g + k decodes Huffman stream k of item g (64 streams at once); flat-table class: 8 items
 //   k_dec_sequences one wavefront per 16 items: four lanes an item, one per FSE state (the three states of a sequence side by side)
-//   k_dec_execute   one wavefront per item : literal / match copies of the decoded sequences (execTile of the general decoder)
+//   k_dec_execute   one wavefront per item : extra bits, recent offsets, positions, checks per tile of 64 sequences; the block's literals spread into
+//                                            the output; then its matches, in-tile sources redirected, the rest level by level
 //
 // Anything unusual -- another frame shape, a table the fast kernels do not hold (Huffman log 12, > 16384 sequences),
 // a stream that does not end exactly, a failed check while executing -- clears the item's fast flag, and the general
@@ -658,7 +659,7 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
 // ---------------------------------------------------------------------------------------------------------------------
 #define ZS_EXEC_WINDOW 32768u           // output bytes whose literal bits a wavefront holds in LDS at a time
 #ifndef ZS_EXEC_MINWG
-#define ZS_EXEC_MINWG 6                 // 6 workgroups = 6 wavefronts per SIMD at <= 80 VGPRs (24 bytes of spill); measured 1: 5.86 ms, 6: 5.42, 7: 5.43, 8: 6.46
+#define ZS_EXEC_MINWG 6                 // 6 wavefronts per SIMD at <= 80 VGPRs (9 spilled); per 57344 frames (round 3): 5: 3.79 ms, 6: 3.57, 7: 3.50, 8: 3.65
 #endif
 template <int F>
 __global__ void __launch_bounds__(64 * F, ZS_EXEC_MINWG)
