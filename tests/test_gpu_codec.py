@@ -558,3 +558,24 @@ def test_decode_wide_alphabets_flat_huffman_table(codec):
     for i, (g, c, f) in enumerate(zip(got, chunks, frames)):
         assert g == (len(c), c), i
         assert O.decompress(f, len(c)) == c, i
+
+
+def test_decode_large_frames_of_many_blocks(codec):
+    """a call that is mostly large frames (3 - 16 blocks each: chunks of 150 KiB - 1 MiB) reserves that many block slots and decodes them on the
+    fast path; frames of more blocks, frames with raw / RLE blocks among the compressed ones and small frames in the same call must come out
+    right whichever kernel takes them.  Against the input and oracle D."""
+    rng = np.random.default_rng(23)
+    text = D.zipf_log(3 << 20, seed_lo=31).tobytes()
+    noise = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    chunks = [text[:150000], text[100000:100000 + 262144], text[:1 << 20], text[5000:5000 + 1000000], text[:(1 << 20) + 1],
+              text[:200000] + noise + text[200000:400000], text[:65536 * 3] + bytes(65536) + text[:70000], text[:40000], text[:65536 * 5 + 17]]
+    frames = _compress_many(codec, chunks, 3)
+    got = _decompress_many(codec, frames, [len(c) for c in chunks])
+    for i, (g, c, f) in enumerate(zip(got, chunks, frames)):
+        assert g == (len(c), c), i
+    assert O.decompress(frames[2], len(chunks[2])) == chunks[2] and O.decompress(frames[6], len(chunks[6])) == chunks[6]
+    # the same frames one by one and among many small ones (the call then keeps its one or two slots: the general kernel takes the large frames)
+    small = [text[i * 30000:(i + 1) * 30000] for i in range(40)]
+    frames2 = _compress_many(codec, small + chunks[:3], 3)
+    got2 = _decompress_many(codec, frames2, [len(c) for c in small + chunks[:3]])
+    assert all(g == (len(c), c) for g, c in zip(got2, small + chunks[:3]))

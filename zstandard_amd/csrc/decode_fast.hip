@@ -1,5 +1,6 @@
 // Fast decode path for the shapes the batch codec itself produces and BASELINE config 4 names: an item that is exactly
-// one frame with one or two compressed blocks (chunks of <= 64 KiB / <= 128 KiB), with or without a content checksum.
+// one frame with one or two compressed blocks (chunks of <= 64 KiB / <= 128 KiB) - up to ZS_FAST_MAXBLOCKS blocks in a call
+// that is mostly large frames -, with or without a content checksum.
 // Everything per block (descriptor, tables, literals, decoded sequences) lives in slot blk * cap + item: the Huffman and
 // sequences kernels are launched once per block index; the execute kernel walks an item's blocks in order, carrying the
 // output position and the recent offsets (ZStdDecompress.cs:1596).  A second block that repeats tables (literals type 3,
@@ -22,6 +23,7 @@
 
 #define ZS_FAST_HUFLOG   11u                      // Huffman tables the fast kernel holds: 2^11 entries per item
 #define ZS_FAST_MAXSEQ   16384u                   // sequences per block the fast path buffers (8 bytes each)
+#define ZS_FAST_MAXBLOCKS 16u                      // block slots per item a call may reserve (frames of up to 1 MiB; 1 or 2 unless the call is mostly large frames)
 #ifndef ZS_FAST_HUFWIN
 #define ZS_FAST_HUFWIN   128u                     // bytes of each Huffman stream staged in LDS at a time
 #endif
@@ -80,7 +82,7 @@ __global__ void __launch_bounds__(64 * F, ZS_PREP_MINWG)
 k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems,
            ZsFastDesc *__restrict__ descs, uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ seqTabs, uint32_t cap, uint32_t maxBlocks)
 {
-    // (maxBlocks: block slots the call reserved per item, 1 or 2 - frames of more compressed blocks are left to the general kernel;
+    // (maxBlocks: block slots the call reserved per item, 1, 2 or up to ZS_FAST_MAXBLOCKS - frames of more compressed blocks are left to the general kernel;
     //  descriptors always have both)
     // the general decoder's LDS image without its Huffman table and with one sequence table instead of three (4.4 of 15.5 KiB)
     __shared__ __attribute__((aligned(16))) unsigned char LSraw[F][(ZS_DLDS_PREP + 15) & ~15u];
@@ -212,8 +214,8 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
 #endif
     // an item is fast only as a whole; a block index it does not use reads as absent
     if (lane == 0) {
-        if (!ok) { descs[item].fast = 0; descs[(size_t)cap + item].fast = 0; }
-        else if (nBlocks < 2) descs[(size_t)cap + item].fast = 0;
+        const uint32_t slots = max(2u, maxBlocks);                               // (a descriptor slot 1 exists even when the call reserved one block slot)
+        for (uint32_t b = ok ? nBlocks : 0u; b < slots; b++) descs[(size_t)b * cap + item].fast = 0;
     }
     #undef DSET
 }
@@ -287,12 +289,17 @@ struct HufLds { uint16_t huf[G][FLAT ? (1u << ZS_FAST_HUFLOG) : ZS_HUF2_ENTRIES]
 template <bool FLAT, uint32_t G>
 __global__ void __launch_bounds__(64)
 k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-              const uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ litScratchAll, uint32_t blk, uint32_t cap)
+              const uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ litScratchAll, uint32_t nBlk, uint32_t cap)
 {
     __shared__ __attribute__((aligned(16))) HufLds<FLAT, G> H;
     const uint32_t lane = (uint32_t)zs_lane();
     const uint32_t g = lane >> 2, k = lane & 3u;
-    const uint32_t item = blockIdx.x * G + g;
+    // one launch for every block index of the call (nBlk of them): the grid is nBlk runs of the items' groups - blocks decode independently of
+    // each other, and a launch per block index was a launch of few wavefronts each when the items are large frames (r3: 16 launches -> 1)
+    const uint32_t groupsPerBlk = (nItems + G - 1) / G;
+    const uint32_t blk = blockIdx.x / groupsPerBlk, bx = blockIdx.x - blk * groupsPerBlk;
+    (void)nBlk;
+    const uint32_t item = bx * G + g;
     bool mine = false; uint32_t dtLog = 1, n = 0, size = 0;
     const uint8_t *src = srcAll; uint8_t *out = litScratchAll;
     const size_t slot0 = (size_t)blk * cap;                          // this block index's descriptors, tables, literal scratch
@@ -307,7 +314,7 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     if (!__ballot(mine)) return;
     // tables of the items that need them
     for (uint32_t gg = 0; gg < G; gg++) {
-        const uint32_t it2 = blockIdx.x * G + gg;
+        const uint32_t it2 = bx * G + gg;
         const uint32_t log2 = wave_get(mine ? dtLog : 0u, (int)(gg * 4));        // stream 0 of the item exists whenever any does
         if (!log2) continue;
         const uint32_t *ht = reinterpret_cast<const uint32_t *>(hufTabs + (slot0 + it2) * ZS_FAST_HUFTAB_BYTES);
@@ -403,14 +410,17 @@ struct SeqDecLds { uint16_t cells[G][(LOG9 ? 1280 : 768)]; uint32_t win[G][(ZS_F
 template <bool LOG9, uint32_t G>
 __global__ void __launch_bounds__(64)
 k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-                  const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t blk, uint32_t cap)
+                  const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t nBlk, uint32_t cap)
 {
+    const uint32_t groupsPerBlk = (nItems + G - 1) / G;                          // (one launch for every block index: see k_dec_huffman)
+    const uint32_t blk = blockIdx.x / groupsPerBlk, bx = blockIdx.x - blk * groupsPerBlk;
+    (void)nBlk;
     static_assert(G <= 16, "four lanes an item");
     __shared__ __attribute__((aligned(16))) SeqDecLds<LOG9, G> S;
     constexpr uint32_t LLC = LOG9 ? 512 : 256, OFB = LLC, MLB = LLC + 256;        // cells of the LL table; where OF and ML start
     const uint32_t lane = (uint32_t)zs_lane();
     const uint32_t g = lane >> 2, r = lane & 3u;
-    const uint32_t item = blockIdx.x * G + g;
+    const uint32_t item = bx * G + g;
     bool mine = false; uint32_t nbSeq = 0, size = 0, llLog = 0, ofLog = 0, mlLog = 0;
     const uint8_t *src = srcAll;
     const size_t slot0 = (size_t)blk * cap;
@@ -421,7 +431,7 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
     if (!__ballot(mine)) return;
     for (uint32_t gg = 0; gg < G; gg++) {
         if (!wave_get(mine ? 1u : 0u, (int)(4 * gg))) continue;
-        const uint32_t *st = reinterpret_cast<const uint32_t *>(seqTabs + (slot0 + blockIdx.x * G + gg) * ZS_FAST_SEQTAB_BYTES);
+        const uint32_t *st = reinterpret_cast<const uint32_t *>(seqTabs + (slot0 + bx * G + gg) * ZS_FAST_SEQTAB_BYTES);
         const uint32_t a = 1u << wave_get(llLog, (int)(4 * gg)), o = 1u << wave_get(ofLog, (int)(4 * gg)), m = 1u << wave_get(mlLog, (int)(4 * gg));
         {   // the three tables, two cells a dword: every load issued before the first LDS store (up to 4 + 2 + 4 dwords per lane)
             uint32_t va[4], vo[2], vm[4];
@@ -664,7 +674,7 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
 template <int F>
 __global__ void __launch_bounds__(64 * F, ZS_EXEC_MINWG)
 k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-              ZsFastSeq *seqAll, uint8_t *__restrict__ litScratchAll, uint8_t *dstAll, uint32_t *__restrict__ dstSizes, uint32_t cap)
+              ZsFastSeq *seqAll, uint8_t *__restrict__ litScratchAll, uint8_t *dstAll, uint32_t *__restrict__ dstSizes, uint32_t cap, uint32_t slots)
 {
     __shared__ uint32_t tiles[F][3][64];
     __shared__ uint32_t codeTabs[36 + 53];                                      // base | extra bits << 24 of the LL / ML codes
@@ -692,7 +702,7 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     uint64_t op = 0; bool bad = false; uint32_t why = 0;
     uint32_t rep0 = 1, rep1 = 4, rep2 = 8;                                      // the list carried from tile to tile and block to block (lane 0 holds it)
     #pragma unroll 1
-    for (uint32_t blk = 0; blk < 2 && !bad; blk++) {
+    for (uint32_t blk = 0; blk < slots && !bad; blk++) {
     const size_t slot = (size_t)blk * cap + itemU;
     const ZsFastDesc *dp = descs + slot;
     if (blk && !dp->fast) break;                                                // a one-block frame

@@ -404,9 +404,18 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
     // an item that has two smaller blocks then goes to the general kernel.  Scratch per item in flight: the general kernel's literal
     // buffer 128 KiB; fast path: + Huffman and sequence tables + 16384 sequences of 8 bytes = ~263 KiB per slot.  The items in flight are
     // cut down where that would take more than half of the device memory that is free (a shared or smaller device).
-    uint32_t maxBlocks = 1;
-    for (uint32_t i = 0; i < n && maxBlocks == 1; i++) if (dstCaps[i] > ZS_BLOCK_MAX) maxBlocks = 2;
-    const size_t perItem = ((size_t)(1u << 17) + 64) * (fast ? maxBlocks : 1) + (fast ? 2 * sizeof(ZsFastDesc) + (size_t)maxBlocks * (ZS_FAST_HUFTAB_BYTES + ZS_FAST_SEQTAB_BYTES + (size_t)ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)) : 0);
+    // (round 3) More slots - up to ZS_FAST_MAXBLOCKS, frames of up to 1 MiB - are reserved when at least a quarter of the call's items can hold
+    // more than two blocks (a call of large frames); a few large frames among many small ones go to the general kernel as before, so the small
+    // ones do not pay for slots and launches they do not use.
+    uint32_t maxBlocks = 1, bigItems = 0, needBlocks = 1;
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t nb = (uint32_t)(((uint64_t)dstCaps[i] + ZS_BLOCK_MAX - 1) / ZS_BLOCK_MAX);
+        if (nb > 1) maxBlocks = 2;
+        if (nb > 2) { bigItems++; needBlocks = std::max(needBlocks, std::min<uint32_t>(nb, ZS_FAST_MAXBLOCKS)); }
+    }
+    if (bigItems && (uint64_t)bigItems * 4 >= n) maxBlocks = needBlocks;
+    const uint32_t descSlots = std::max(2u, maxBlocks);
+    const size_t perItem = ((size_t)(1u << 17) + 64) * (fast ? maxBlocks : 1) + (fast ? descSlots * sizeof(ZsFastDesc) + (size_t)maxBlocks * (ZS_FAST_HUFTAB_BYTES + ZS_FAST_SEQTAB_BYTES + (size_t)ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)) : 0);
     uint32_t cap = std::min<uint32_t>(n, c->maxItemsInFlight);
     {
         size_t freeB = 0, totalB = 0;
@@ -417,7 +426,7 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
         }
     }
     if (!c->dLitScratch.reserve((size_t)cap * (fast ? maxBlocks : 1) * ((1u << 17) + 64))) return ZSMI_error_memory_allocation;
-    if (fast && (!c->dFastDesc.reserve((size_t)cap * 2 * sizeof(ZsFastDesc)) || !c->dHufTabs.reserve((size_t)cap * maxBlocks * ZS_FAST_HUFTAB_BYTES) ||
+    if (fast && (!c->dFastDesc.reserve((size_t)cap * descSlots * sizeof(ZsFastDesc)) || !c->dHufTabs.reserve((size_t)cap * maxBlocks * ZS_FAST_HUFTAB_BYTES) ||
                  !c->dSeqTabs.reserve((size_t)cap * maxBlocks * ZS_FAST_SEQTAB_BYTES) || !c->dSeqOut.reserve((size_t)cap * maxBlocks * ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)))) return ZSMI_error_memory_allocation;
     for (uint32_t i0 = 0; i0 < n; i0 += cap) {
         const uint32_t cnt = std::min(cap, n - i0);
@@ -430,22 +439,24 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
             const uint32_t groups = (cnt + ZS_FAST_GROUP - 1) / ZS_FAST_GROUP;
             LAUNCH(c, "k_dec_prep", (k_dec_prep<ZS_DEC_GROUP>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc, dI, cnt, dD,
                    (uint8_t *)c->dHufTabs.p, (uint8_t *)c->dSeqTabs.p, cap, maxBlocks);
-            for (uint32_t blk = 0; blk < maxBlocks; blk++) {          // block index 1: the second block of two-block frames (a wavefront without one leaves at once)
-                LAUNCH(c, "k_dec_huffman", (k_dec_huffman<false, ZS_FAST_GROUP>), dim3(groups), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, blk, cap);
-                LAUNCH(c, "k_dec_huffman", (k_dec_huffman<true, 8u>), dim3((cnt + 7) / 8), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, blk, cap);
-                LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, blk, cap);
+            {   // every block index of the items in one launch per kernel class (the grid: maxBlocks runs of the items' groups; a wavefront whose items
+                // have no such block leaves at once)
+                const uint32_t mb = maxBlocks, vcnt = cnt * mb;                 // (item, block) pairs: what a launch's rounds of workgroups count
+                LAUNCH(c, "k_dec_huffman", (k_dec_huffman<false, ZS_FAST_GROUP>), dim3(groups * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, mb, cap);
+                LAUNCH(c, "k_dec_huffman", (k_dec_huffman<true, 8u>), dim3(((cnt + 7) / 8) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, mb, cap);
+                LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3(((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap);
                 // the 2.5 KiB table class: fuller wavefronts (16 items) win when a launch is several rounds of workgroups, emptier ones (4) when it
                 // is less than one (8192 frames of 128 KiB: 83 vs 77 GiB/s; 16384: 117 vs 128)
                 // (r3: and when 4 items a wavefront save a whole round of workgroups - 14 x 4 = 56 items a CU against 3 x 16 = 48 -: 57344 libzstd
-                //  frames of 32 KiB are 4 rounds instead of 5, 3.8 vs 5.2 ms; 16384 of 128 KiB are 2 rounds either way, 6.8 vs 5.6 ms)
-                const uint32_t rounds16 = (cnt + 48u * 256u - 1) / (48u * 256u), rounds4 = (cnt + 56u * 256u - 1) / (56u * 256u);
-                if (cnt >= ZS_FAST_SEQGROUP_MANY && rounds4 >= rounds16)
-                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, ZS_FAST_SEQGROUP>), dim3((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, blk, cap);
+                //  frames of 32 KiB are 4 rounds instead of 5, 3.8 vs 5.2 ms)
+                const uint32_t rounds16 = (vcnt + 48u * 256u - 1) / (48u * 256u), rounds4 = (vcnt + 56u * 256u - 1) / (56u * 256u);
+                if (vcnt >= ZS_FAST_SEQGROUP_MANY && rounds4 >= rounds16)
+                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, ZS_FAST_SEQGROUP>), dim3(((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap);
                 else
-                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, 4u>), dim3((cnt + 3) / 4), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, blk, cap);
+                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, 4u>), dim3(((cnt + 3) / 4) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap);
             }
             LAUNCH(c, "k_dec_execute", (k_dec_execute<4>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (ZsFastSeq *)c->dSeqOut.p,
-                   (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap);
+                   (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap, descSlots);
             LAUNCH(c, "k_dec_checksum", k_dec_checksum, dim3((cnt + 63) / 64), dim3(64), 0, dI, cnt, (const ZsFastDesc *)dD, (const uint8_t *)dDst, dDstSizes + i0);
             doneFlags = &dD->fast;
         }
