@@ -668,11 +668,10 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
 // k_dec_execute : one wavefront per item: pass A over the decoded sequences (64 at a time), the block's literals, its matches; size check.
 // ---------------------------------------------------------------------------------------------------------------------
 #define ZS_EXEC_WINDOW 32768u           // output bytes whose literal bits a wavefront holds in LDS at a time
-#ifndef ZS_EXEC_MINWG
-#define ZS_EXEC_MINWG 6                 // 6 wavefronts per SIMD at <= 80 VGPRs (9 spilled); per 57344 frames (round 3): 5: 3.79 ms, 6: 3.57, 7: 3.50, 8: 3.65
-#endif
-template <int F>
-__global__ void __launch_bounds__(64 * F, ZS_EXEC_MINWG)
+// wavefronts per SIMD the kernel is compiled for: 6 = 80 VGPRs (9 spilled), 7 = 72 (more spills).  Per 57344 frames of 32 KiB: 5: 3.79 ms, 6: 3.57,
+// 7: 3.41, 8: 3.65; per 16384 frames of 128 KiB: 6: 5.42, 7: 5.57 - so a call of one-block items takes the 7 form, any other the 6 form (MW)
+template <int F, int MW>
+__global__ void __launch_bounds__(64 * F, MW)
 k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
               ZsFastSeq *seqAll, uint8_t *__restrict__ litScratchAll, uint8_t *dstAll, uint32_t *__restrict__ dstSizes, uint32_t cap, uint32_t slots)
 {

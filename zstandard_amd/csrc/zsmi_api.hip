@@ -455,8 +455,12 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
                 else
                     LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, 4u>), dim3(((cnt + 3) / 4) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap);
             }
-            LAUNCH(c, "k_dec_execute", (k_dec_execute<4>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (ZsFastSeq *)c->dSeqOut.p,
-                   (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap, descSlots);
+            if (maxBlocks == 1)
+                LAUNCH(c, "k_dec_execute", (k_dec_execute<4, 7>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (ZsFastSeq *)c->dSeqOut.p,
+                       (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap, descSlots);
+            else
+                LAUNCH(c, "k_dec_execute", (k_dec_execute<4, 6>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (ZsFastSeq *)c->dSeqOut.p,
+                       (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap, descSlots);
             LAUNCH(c, "k_dec_checksum", k_dec_checksum, dim3((cnt + 63) / 64), dim3(64), 0, dI, cnt, (const ZsFastDesc *)dD, (const uint8_t *)dDst, dDstSizes + i0);
             doneFlags = &dD->fast;
         }
