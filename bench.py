@@ -161,6 +161,32 @@ def libzstd_frames_decode(bc, args, torch, host, nf, fs):
 
 
 
+def large_frames_decode(bc, args, torch, host, nf=2048, fs=1 << 20):
+    """Frames of 16 blocks (1 MiB chunks of the same stream, this codec's encoder at level 3): a call of large frames reserves up to 16 block slots an
+    item and stays on the decoder's fast path.  Whole output verified; not part of `value`."""
+    n = min(nf, len(host) // fs)
+    d_src = torch.from_numpy(host[:n * fs]).cuda()
+    bound = int(bc.L.zsmi_compressBound(fs)); stride = (bound + 255) // 256 * 256
+    d_frames = torch.empty(n * stride, dtype=torch.uint8, device="cuda"); d_fsz = torch.zeros(n, dtype=torch.int32, device="cuda")
+    offs = np.arange(n, dtype=np.uint64) * fs; sizes = np.full(n, fs, dtype=np.uint32); foffs = np.arange(n, dtype=np.uint64) * stride
+    bc.compress_device(d_src.data_ptr(), offs, sizes, d_frames.data_ptr(), foffs, d_fsz.data_ptr(), 3); torch.cuda.synchronize()
+    fsz = d_fsz.cpu().numpy().astype(np.uint32)
+    d_out = torch.empty(n * fs, dtype=torch.uint8, device="cuda"); d_osz = torch.zeros(n, dtype=torch.int32, device="cuda")
+    step = lambda: bc.decompress_device(d_frames.data_ptr(), foffs, fsz, d_out.data_ptr(), offs, sizes, d_osz.data_ptr())
+    step(); torch.cuda.synchronize()
+    k = 3
+    t0 = time.perf_counter()
+    for _ in range(k):
+        step()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    bc.enable_timing(True); step(); torch.cuda.synchronize(); kt = bc.kernel_times(); bc.enable_timing(False)
+    assert (d_osz.cpu().numpy() == fs).all() and torch.equal(d_out, d_src), "a large frame failed to decode"
+    return {"value": round(n * fs * k / dt / (1 << 30), 3), "unit": "GiB/s", "frames": n, "frame_bytes": fs, "blocks_per_frame": fs // 65536,
+            "kernels_ms_per_step": {kk: round(v[0] * 1e3, 4) for kk, v in kt.items()},
+            "label": "frames of 16 compressed blocks built by this codec from the same stream, one call; the general kernel's share shows frames that left the fast path"}
+
+
 def io_inclusive_leg(torch, dist, rank, world, all_sizes, root_src, compress_shard, device, barrier, reps=3):
     """SURVEY 8e end to end, the job that starts and ends on rank 0: scatter the shards (one grouped batch of sends), every rank compresses
     and packs its shard, all-gather of the frame sizes, gather of the frames to rank 0 (one grouped batch of receives).
@@ -249,6 +275,10 @@ def decode_leg(bc, args, rank, world, distributed, barrier, torch, dist):
         zl = libzstd_frames_decode(bc, args, torch, host, nf, fs)
         if zl:
             out["libzstd_frames"] = zl
+        try:
+            out["large_frames"] = large_frames_decode(bc, args, torch, host)
+        except Exception as e:                                  # an extra: say what happened and go on
+            out["large_frames"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     if not args.no_cpu_baseline:
         cores = usable_cores(); m = min(nf, 4096)
         fr = d_frames[:m * stride].cpu().numpy(); L = O.lib(); vp = ctypes.c_void_p
