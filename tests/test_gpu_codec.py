@@ -579,3 +579,25 @@ def test_decode_large_frames_of_many_blocks(codec):
     frames2 = _compress_many(codec, small + chunks[:3], 3)
     got2 = _decompress_many(codec, frames2, [len(c) for c in small + chunks[:3]])
     assert all(g == (len(c), c) for g, c in zip(got2, small + chunks[:3]))
+
+
+def test_decode_libzstd_frames_of_many_blocks_with_repeated_tables(codec):
+    """upstream libzstd's multi-block frames (blocks of 128 KiB; later blocks repeat the Huffman table - "treeless" literals - and sequence tables,
+    ZStdDecompress.cs:696-697, 1062-1064) in a call of mostly large frames: k_dec_prep copies a repeated table into the block's own slot, so the
+    frames stay on the fast path; levels 1 - 19, text and binary-ish data, against the input and oracle D."""
+    if not O.libzstd():
+        pytest.skip("no libzstd here")
+    rng = np.random.default_rng(29)
+    text = D.zipf_log(2 << 20, seed_lo=41).tobytes()
+    skew = np.random.default_rng(3)
+    p = 0.97 ** np.arange(256); p /= p.sum()
+    binary = skew.permutation(256).astype(np.uint8)[skew.choice(256, size=600000, p=p)].tobytes()
+    chunks, frames = [], []
+    for i, (data, n, lvl) in enumerate([(text, 300000, 1), (text, 400000, 3), (text, 1 << 20, 3), (text, 700000, 5), (text, 262144, 9), (text, 393216, 19),
+                                        (binary, 400000, 3), (binary, 600000, 1), (text[:200000] + binary[:200000] + text[:150000], 550000, 3), (text, 131073, 3)]):
+        a = int(rng.integers(0, len(data) - n + 1)); c = data[a:a + n]
+        chunks.append(c); frames.append(O.zstd_compress(c, lvl))
+    got = _decompress_many(codec, frames, [len(c) for c in chunks])
+    for i, (g, c, f) in enumerate(zip(got, chunks, frames)):
+        assert g == (len(c), c), i
+    assert O.decompress(frames[1], len(chunks[1])) == chunks[1] and O.decompress(frames[6], len(chunks[6])) == chunks[6]

@@ -3,8 +3,8 @@
 // that is mostly large frames -, with or without a content checksum.
 // Everything per block (descriptor, tables, literals, decoded sequences) lives in slot blk * cap + item: the Huffman and
 // sequences kernels are launched once per block index; the execute kernel walks an item's blocks in order, carrying the
-// output position and the recent offsets (ZStdDecompress.cs:1596).  A second block that repeats tables (literals type 3,
-// sequence mode 3: ZStdDecompress.cs:696-697, 1062-1064) leaves the item to the general kernel.  The serial entropy decoders run lane-parallel ACROSS frames:
+// output position and the recent offsets (ZStdDecompress.cs:1596).  A block that repeats tables (literals type 3, sequence mode 3:
+// ZStdDecompress.cs:696-697, 1062-1064) gets a copy of them in its own slot from k_dec_prep.  The serial entropy decoders run lane-parallel ACROSS frames:
 //
 //   k_dec_prep      one wavefront per item : headers, Huffman table (two-level; flat 2^11 for wide alphabets), sequence tables (all lanes build,
 //                                            one lane parses the counts) -> tables + a descriptor in global memory; decides fast / general
@@ -122,6 +122,10 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
         const uint32_t hasContentSize = fcs != ~0ull, contentSize = (uint32_t)fcs;
         uint32_t b0 = fhs;                                          // offset of the next block header in the item
         bool fail = false;
+        // tables a later block may repeat (literals type 3, sequence mode 3: ZStdDecompress.cs:696-697, 1062-1064): the slot that holds the frame's
+        // current Huffman table, the slot of the last block that had sequences (it holds all three sequence tables, built or copied) and their logs.
+        // A repeating block gets a COPY in its own slot, so the kernels behind this one never look at another slot.
+        int32_t hufSlotBlk = -1, seqSlotBlk = -1; uint32_t hufLogCur = 0, hufFlatCur = 0, seqLogs[3] = { 0, 0, 0 };
         #pragma unroll 1
         for (uint32_t blk = 0; blk < maxBlocks && !fail; blk++) {
             fail = true;
@@ -142,8 +146,8 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
             uint32_t litCSizeTot;
             {
                 const uint32_t type = bs[0] & 3, lhl = (bs[0] >> 2) & 3;
-                if (type == 3) break;                               // a repeated Huffman table: general kernel
-                if (type == 2) {
+                if (type == 3 && hufSlotBlk < 0) break;             // a repeated Huffman table without one before it: the general kernel says what is wrong
+                if (type >= 2) {
                     if (cSize < 5) break;
                     const uint32_t lhc = rd32(bs);
                     uint32_t lhSize, litSize, litCSize; bool single = false;
@@ -153,12 +157,28 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                     if (litSize > (1u << 17) || litCSize + lhSize > cSize) break;
                     if (!single && (litSize == 0 || litCSize == 0)) break;
                     uint16_t *ht = reinterpret_cast<uint16_t *>(hufTabs + slot * ZS_FAST_HUFTAB_BYTES);
-                    uint32_t h = readHufTableT<true>(L, bs + lhSize, litCSize, ht, ZS_FAST_HUFLOG);
-                    if (isErr(h)) break;
-                    DSET(hufFlat, h >> 30); h &= 0x3FFFFFFFu;                  // (readHufTableT<true> marks a flat table in bit 30)
-                    if (h >= litCSize || L.hufLog > ZS_FAST_HUFLOG) break;
+                    uint32_t h = 0;
+                    if (type == 2) {
+                        h = readHufTableT<true>(L, bs + lhSize, litCSize, ht, ZS_FAST_HUFLOG);
+                        if (isErr(h)) break;
+                        hufFlatCur = h >> 30; h &= 0x3FFFFFFFu;                // (readHufTableT<true> marks a flat table in bit 30)
+                        if (h >= litCSize || L.hufLog > ZS_FAST_HUFLOG) break;
+                        hufLogCur = L.hufLog;
+                    } else {
+                        // the table of the block that built it, into this block's slot (the whole 4 KiB: 16 bytes a lane, 4 rounds)
+                        const uint4 *from = reinterpret_cast<const uint4 *>(hufTabs + ((size_t)hufSlotBlk * cap + item) * ZS_FAST_HUFTAB_BYTES);
+                        uint4 *to = reinterpret_cast<uint4 *>(ht);
+                        uint4 v[ZS_FAST_HUFTAB_BYTES / 16 / 64];
+                        wave_mem_sync();                               // (stored by this wavefront, some blocks earlier)
+                        #pragma unroll
+                        for (uint32_t u = 0; u < ZS_FAST_HUFTAB_BYTES / 16 / 64; u++) v[u] = from[lane + 64 * u];
+                        #pragma unroll
+                        for (uint32_t u = 0; u < ZS_FAST_HUFTAB_BYTES / 16 / 64; u++) to[lane + 64 * u] = v[u];
+                    }
+                    hufSlotBlk = (int32_t)blk;
+                    DSET(hufFlat, hufFlatCur);
                     const uint32_t cs0 = b0 + lhSize + h, csz = litCSize - h;
-                    DSET(litType, 2u); DSET(litSize, litSize); DSET(hufLog, L.hufLog);
+                    DSET(litType, 2u); DSET(litSize, litSize); DSET(hufLog, hufLogCur);
                     if (single) { DSET(nStreams, 1u); DSET(sOff[0], cs0); DSET(sLen[0], csz); DSET(sCnt[0], litSize); DSET(sOut[0], 0u); }
                     else {
                         if (csz < 10) break;
@@ -189,14 +209,18 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
             // ---- sequence headers + tables (:1110-1180), then the tables leave for the sequences kernel.  st.fseEntropy stays 0: a
             //      table repeated from the block before (mode 3) is an error here and sends the item to the general kernel ----
             const uint8_t *ip = bs + litCSizeTot; uint32_t remaining = cSize - litCSizeTot, nbSeq = 0;
-            DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = 0; st.llRepeatOk = 0; st.hufX4 = 0;
+            DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = seqSlotBlk >= 0; st.llRepeatOk = 0; st.hufX4 = 0;
             uint16_t *stab = reinterpret_cast<uint16_t *>(seqTabs + slot * ZS_FAST_SEQTAB_BYTES);
-            if (lane < 3) L.misc[8 + lane] = 0;
-            if (seqHeadersT<true>(L, st, ip, remaining, nbSeq, stab, &L.misc[8])) break;
+            const uint16_t *stabPrev = seqSlotBlk >= 0 ? reinterpret_cast<const uint16_t *>(seqTabs + ((size_t)seqSlotBlk * cap + item) * ZS_FAST_SEQTAB_BYTES) : nullptr;
+            wave_sync();
+            if (lane < 3) L.misc[8 + lane] = seqLogs[lane];          // (a repeated table keeps the log it had)
+            wave_sync();
+            if (seqHeadersT<true>(L, st, ip, remaining, nbSeq, stab, &L.misc[8], stabPrev)) break;
             if (nbSeq > ZS_FAST_MAXSEQ) break;
             if (nbSeq == 0 && remaining != 0) break;
             DSET(nbSeq, nbSeq); DSET(seqOff, (uint32_t)(ip - src)); DSET(seqSize, remaining);
             DSET(llLog, nbSeq ? L.misc[8] : 0u); DSET(ofLog, nbSeq ? L.misc[9] : 0u); DSET(mlLog, nbSeq ? L.misc[10] : 0u);
+            if (nbSeq) { seqSlotBlk = (int32_t)blk; seqLogs[0] = L.misc[8]; seqLogs[1] = L.misc[9]; seqLogs[2] = L.misc[10]; }
             DSET(fast, 1u);
             nBlocks = blk + 1;
             b0 += cSize;

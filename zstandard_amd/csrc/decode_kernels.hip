@@ -914,7 +914,7 @@ __device__ __forceinline__ uint32_t zs_fastcell(uint32_t next, uint32_t nb, uint
 //      EMIT (k_dec_prep): each table is built in L.LL, turned into 16-bit fast-path cells and stored to stab (LL at cell 0, OF at
 //      512, ML at 768) before the next one takes its place; logsOut[t] = its tableLog.
 template <bool EMIT>
-__device__ __forceinline__ uint32_t seqHeadersT(DLds &L, const DState &st, const uint8_t *&ip, uint32_t &remaining, uint32_t &nbSeq, uint16_t *stab, uint32_t *logsOut)
+__device__ __forceinline__ uint32_t seqHeadersT(DLds &L, const DState &st, const uint8_t *&ip, uint32_t &remaining, uint32_t &nbSeq, uint16_t *stab, uint32_t *logsOut, const uint16_t *stabPrev = nullptr)
 {
     const uint32_t lane = (uint32_t)zs_lane();
     {
@@ -969,7 +969,14 @@ __device__ __forceinline__ uint32_t seqHeadersT(DLds &L, const DState &st, const
                 if (type == 0 || type == 2) buildSeqTableWave(L, cells, tl, bmax, blog);
                 wave_sync();
                 PPROF(L, 10);
-                if (EMIT) {
+                if (EMIT && type == 3) {
+                    // a table repeated from the last block that had sequences: its 16-bit cells copied from that block's slot (logsOut[t] holds its log)
+                    const uint32_t log = logsOut[t], at = t == 0 ? 0u : (t == 1 ? 512u : 768u);
+                    if (!stabPrev) return ZE(E_corruption_detected);
+                    wave_mem_sync();                                   // (the cells were stored by this wavefront, a block earlier)
+                    for (uint32_t i = lane; i < (1u << log); i += 64) stab[at + i] = stabPrev[at + i];
+                    wave_sync();
+                } else if (EMIT) {
                     const uint32_t log = *tl, at = t == 0 ? 0u : (t == 1 ? 512u : 768u);
                     for (uint32_t i = lane; i < (1u << log); i += 64) { const SeqSym c = cells[i]; stab[at + i] = (uint16_t)zs_fastcell(c.nextState, c.nbBits, c.sym); }
                     if (lane == 0) logsOut[t] = log;
