@@ -7,7 +7,8 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import torch
 from zstandard_amd import BatchCodec
 import _data as D
-ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=2048); ap.add_argument("--chunk", type=int, default=1 << 20); ap.add_argument("--steps", type=int, default=3); a = ap.parse_args()
+ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=2048); ap.add_argument("--chunk", type=int, default=1 << 20); ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--libzstd", action="store_true", help="frames built by upstream libzstd (level 3) on the host"); a = ap.parse_args()
 n, cs = a.frames, a.chunk
 host = D.zipf_log(min(n * cs, 1 << 30), threads=32)
 host = np.tile(host, (n * cs + len(host) - 1) // len(host))[:n * cs]
@@ -16,8 +17,16 @@ d_src = torch.from_numpy(host).cuda()
 bound = int(bc.L.zsmi_compressBound(cs)); stride = (bound + 255) // 256 * 256
 d_frames = torch.empty(n * stride, dtype=torch.uint8, device="cuda"); d_fsz = torch.zeros(n, dtype=torch.int32, device="cuda")
 offs = np.arange(n, dtype=np.uint64) * cs; sizes = np.full(n, cs, dtype=np.uint32); foffs = np.arange(n, dtype=np.uint64) * stride
-bc.compress_device(d_src.data_ptr(), offs, sizes, d_frames.data_ptr(), foffs, d_fsz.data_ptr(), 3); torch.cuda.synchronize()
-fsz = d_fsz.cpu().numpy().astype(np.uint32)
+if a.libzstd:
+    import ctypes, _oracle as O
+    assert O.libzstd(), "no libzstd here"
+    zb = np.empty(n * stride, dtype=np.uint8); fsz = np.zeros(n, dtype=np.uint32); vp = ctypes.c_void_p
+    rc = O.lib().zso_libzstdCompressBatch(zb.ctypes.data_as(vp), foffs.ctypes.data_as(vp), fsz.ctypes.data_as(vp), host.ctypes.data_as(vp), offs.ctypes.data_as(vp), sizes.ctypes.data_as(vp), n, 3, 16)
+    assert rc == 0
+    d_frames = torch.from_numpy(zb).cuda()
+else:
+    bc.compress_device(d_src.data_ptr(), offs, sizes, d_frames.data_ptr(), foffs, d_fsz.data_ptr(), 3); torch.cuda.synchronize()
+    fsz = d_fsz.cpu().numpy().astype(np.uint32)
 d_out = torch.empty(n * cs, dtype=torch.uint8, device="cuda"); d_osz = torch.zeros(n, dtype=torch.int32, device="cuda")
 step = lambda: bc.decompress_device(d_frames.data_ptr(), foffs, fsz, d_out.data_ptr(), offs, sizes, d_osz.data_ptr())
 step(); torch.cuda.synchronize()
