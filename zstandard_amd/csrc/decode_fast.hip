@@ -125,7 +125,11 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
         // tables a later block may repeat (literals type 3, sequence mode 3: ZStdDecompress.cs:696-697, 1062-1064): the slot that holds the frame's
         // current Huffman table, the slot of the last block that had sequences (it holds all three sequence tables, built or copied) and their logs.
         // A repeating block gets a COPY in its own slot, so the kernels behind this one never look at another slot.
-        int32_t hufSlotBlk = -1, seqSlotBlk = -1; uint32_t hufLogCur = 0, hufFlatCur = 0, seqLogs[3] = { 0, 0, 0 };
+        // (kept in LDS words, not registers: the loop body is the whole table code inlined, and eight more values alive across it brought the spills back.
+        //  misc[11]: block + 1 of the Huffman table's slot; misc[12]: block + 1 of the last block with sequences; misc[13]: Huffman log | flat << 8;
+        //  misc[14]: raw / RLE blocks so far; misc[8..10]: the sequence tables' logs, left alone by a block without sequences)
+        if (lane < 8) L.misc[8 + lane] = 0;
+        wave_sync();
         #pragma unroll 1
         for (uint32_t blk = 0; blk < maxBlocks && !fail; blk++) {
             fail = true;
@@ -136,7 +140,26 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
             if ((uint64_t)b0 + 3 + tail > srcSize) break;
             const uint32_t bh = rd24(src + b0);
             const uint32_t lastBlock = bh & 1, btype = (bh >> 1) & 3, cSize = bh >> 3;
-            if (btype != 2 || cSize >= (1u << 17) || cSize < 3) break;
+            if (btype == 3) break;
+            if (btype != 2) {
+                // a raw or RLE block among the compressed ones (:2043-2056): to the kernels behind this one a block of nothing but literals - raw
+                // literals at the block's bytes, or RLE literals of its byte - and no sequences; the entropy tables a later block may repeat stay
+                const uint32_t csz = btype == 1 ? 1u : cSize;
+                if (cSize > (1u << 17)) break;
+                if ((uint64_t)b0 + 3 + csz + tail > srcSize) break;
+                if (lastBlock && (uint64_t)b0 + 3 + csz + tail != srcSize) break;
+                if (!lastBlock && blk + 1 == maxBlocks) break;
+                b0 += 3;
+                DSET(litType, btype == 0 ? 0u : 1u); DSET(litSrc, btype == 0 ? b0 : (uint32_t)src[b0]); DSET(litSize, cSize); DSET(nStreams, 0u);
+                DSET(nbSeq, 0u); DSET(seqOff, 0u); DSET(seqSize, 0u); DSET(llLog, 0u); DSET(ofLog, 0u); DSET(mlLog, 0u); DSET(hufFlat, 0u);
+                DSET(fast, 1u);
+                nBlocks = blk + 1; if (lane == 0) L.misc[14] = L.misc[14] + 1;
+                b0 += csz;
+                fail = false;
+                if (lastBlock) break;
+                continue;
+            }
+            if (cSize >= (1u << 17) || cSize < 3) break;
             if ((uint64_t)b0 + 3 + cSize + tail > srcSize) break;
             if (lastBlock && (uint64_t)b0 + 3 + cSize + tail != srcSize) break;
             if (!lastBlock && blk + 1 == maxBlocks) break;           // more blocks than slots: general kernel
@@ -146,7 +169,7 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
             uint32_t litCSizeTot;
             {
                 const uint32_t type = bs[0] & 3, lhl = (bs[0] >> 2) & 3;
-                if (type == 3 && hufSlotBlk < 0) break;             // a repeated Huffman table without one before it: the general kernel says what is wrong
+                if (type == 3 && L.misc[11] == 0) break;            // a repeated Huffman table without one before it: the general kernel says what is wrong
                 if (type >= 2) {
                     if (cSize < 5) break;
                     const uint32_t lhc = rd32(bs);
@@ -161,12 +184,12 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                     if (type == 2) {
                         h = readHufTableT<true>(L, bs + lhSize, litCSize, ht, ZS_FAST_HUFLOG);
                         if (isErr(h)) break;
-                        hufFlatCur = h >> 30; h &= 0x3FFFFFFFu;                // (readHufTableT<true> marks a flat table in bit 30)
+                        const uint32_t flat = h >> 30; h &= 0x3FFFFFFFu;       // (readHufTableT<true> marks a flat table in bit 30)
                         if (h >= litCSize || L.hufLog > ZS_FAST_HUFLOG) break;
-                        hufLogCur = L.hufLog;
+                        if (lane == 0) L.misc[13] = L.hufLog | (flat << 8);
                     } else {
                         // the table of the block that built it, into this block's slot (the whole 4 KiB: 16 bytes a lane, 4 rounds)
-                        const uint4 *from = reinterpret_cast<const uint4 *>(hufTabs + ((size_t)hufSlotBlk * cap + item) * ZS_FAST_HUFTAB_BYTES);
+                        const uint4 *from = reinterpret_cast<const uint4 *>(hufTabs + ((size_t)(L.misc[11] - 1u) * cap + item) * ZS_FAST_HUFTAB_BYTES);
                         uint4 *to = reinterpret_cast<uint4 *>(ht);
                         uint4 v[ZS_FAST_HUFTAB_BYTES / 16 / 64];
                         wave_mem_sync();                               // (stored by this wavefront, some blocks earlier)
@@ -175,10 +198,12 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                         #pragma unroll
                         for (uint32_t u = 0; u < ZS_FAST_HUFTAB_BYTES / 16 / 64; u++) to[lane + 64 * u] = v[u];
                     }
-                    hufSlotBlk = (int32_t)blk;
-                    DSET(hufFlat, hufFlatCur);
+                    wave_sync();
+                    if (lane == 0) L.misc[11] = blk + 1;
+                    wave_sync();
+                    DSET(hufFlat, L.misc[13] >> 8);
                     const uint32_t cs0 = b0 + lhSize + h, csz = litCSize - h;
-                    DSET(litType, 2u); DSET(litSize, litSize); DSET(hufLog, hufLogCur);
+                    DSET(litType, 2u); DSET(litSize, litSize); DSET(hufLog, L.misc[13] & 0xFFu);
                     if (single) { DSET(nStreams, 1u); DSET(sOff[0], cs0); DSET(sLen[0], csz); DSET(sCnt[0], litSize); DSET(sOut[0], 0u); }
                     else {
                         if (csz < 10) break;
@@ -209,25 +234,25 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
             // ---- sequence headers + tables (:1110-1180), then the tables leave for the sequences kernel.  st.fseEntropy stays 0: a
             //      table repeated from the block before (mode 3) is an error here and sends the item to the general kernel ----
             const uint8_t *ip = bs + litCSizeTot; uint32_t remaining = cSize - litCSizeTot, nbSeq = 0;
-            DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = seqSlotBlk >= 0; st.llRepeatOk = 0; st.hufX4 = 0;
+            const uint32_t seqPrev = L.misc[12];                    // block + 1 of the last block that had sequences (its slot holds all three tables)
+            DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = seqPrev != 0; st.llRepeatOk = 0; st.hufX4 = 0;
             uint16_t *stab = reinterpret_cast<uint16_t *>(seqTabs + slot * ZS_FAST_SEQTAB_BYTES);
-            const uint16_t *stabPrev = seqSlotBlk >= 0 ? reinterpret_cast<const uint16_t *>(seqTabs + ((size_t)seqSlotBlk * cap + item) * ZS_FAST_SEQTAB_BYTES) : nullptr;
-            wave_sync();
-            if (lane < 3) L.misc[8 + lane] = seqLogs[lane];          // (a repeated table keeps the log it had)
-            wave_sync();
-            if (seqHeadersT<true>(L, st, ip, remaining, nbSeq, stab, &L.misc[8], stabPrev)) break;
+            const uint16_t *stabPrev = seqPrev ? reinterpret_cast<const uint16_t *>(seqTabs + ((size_t)(seqPrev - 1u) * cap + item) * ZS_FAST_SEQTAB_BYTES) : nullptr;
+            if (seqHeadersT<true>(L, st, ip, remaining, nbSeq, stab, &L.misc[8], stabPrev)) break;      // (misc[8..10]: a repeated table keeps the log it had)
             if (nbSeq > ZS_FAST_MAXSEQ) break;
             if (nbSeq == 0 && remaining != 0) break;
             DSET(nbSeq, nbSeq); DSET(seqOff, (uint32_t)(ip - src)); DSET(seqSize, remaining);
             DSET(llLog, nbSeq ? L.misc[8] : 0u); DSET(ofLog, nbSeq ? L.misc[9] : 0u); DSET(mlLog, nbSeq ? L.misc[10] : 0u);
-            if (nbSeq) { seqSlotBlk = (int32_t)blk; seqLogs[0] = L.misc[8]; seqLogs[1] = L.misc[9]; seqLogs[2] = L.misc[10]; }
+            if (nbSeq && lane == 0) L.misc[12] = blk + 1;
+            wave_sync();
             DSET(fast, 1u);
             nBlocks = blk + 1;
             b0 += cSize;
             fail = false;
             if (lastBlock) break;
         }
-        ok = !fail;
+        wave_sync();
+        ok = !fail && L.misc[14] < nBlocks;                             // (a frame of raw / RLE blocks only is a plain copy: the general kernel's)
     } while (0);
 #ifdef ZS_PREP_PROFILE
     if (lane == 0 && !descs[item].hufFlat) {          // phases 0-11, then the wavefront's whole time: behind the item's Huffman table (the two-level table ends at 1280 bytes; a flat one fills the slot)
