@@ -80,7 +80,7 @@ __device__ __forceinline__ uint32_t zs_mlExtraBits(uint32_t s) { return s < 32 ?
 template <int F>
 __global__ void __launch_bounds__(64 * F, ZS_PREP_MINWG)
 k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems,
-           ZsFastDesc *__restrict__ descs, uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ seqTabs, uint32_t cap, uint32_t maxBlocks)
+           ZsFastDesc *__restrict__ descs, uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ seqTabs, uint32_t cap, uint32_t maxBlocks, uint32_t *__restrict__ seqLists)
 {
     // (maxBlocks: block slots the call reserved per item, 1, 2 or up to ZS_FAST_MAXBLOCKS - frames of more compressed blocks are left to the general kernel;
     //  descriptors always have both)
@@ -243,7 +243,14 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
             if (nbSeq == 0 && remaining != 0) break;
             DSET(nbSeq, nbSeq); DSET(seqOff, (uint32_t)(ip - src)); DSET(seqSize, remaining);
             DSET(llLog, nbSeq ? L.misc[8] : 0u); DSET(ofLog, nbSeq ? L.misc[9] : 0u); DSET(mlLog, nbSeq ? L.misc[10] : 0u);
-            if (nbSeq && lane == 0) L.misc[12] = blk + 1;
+            if (nbSeq && lane == 0) {
+                L.misc[12] = blk + 1;
+                // the block joins the list of its table class (k_dec_sequences takes its items from the lists: a launch over every slot with most lanes
+                // idle cost a whole chain's time for a class that holds a tenth of the blocks - libzstd's 32 KiB frames: 9 % have 2^9-cell tables)
+                const uint32_t cls = (L.misc[8] > 8u || L.misc[10] > 8u) ? 1u : 0u;
+                const uint32_t at = atomicAdd(&seqLists[cls], 1u);
+                seqLists[2 + (size_t)cls * cap * maxBlocks + at] = (uint32_t)slot;
+            }
             wave_sync();
             DSET(fast, 1u);
             nBlocks = blk + 1;
@@ -459,28 +466,30 @@ struct SeqDecLds { uint16_t cells[G][(LOG9 ? 1280 : 768)]; uint32_t win[G][(ZS_F
 template <bool LOG9, uint32_t G>
 __global__ void __launch_bounds__(64)
 k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-                  const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t nBlk, uint32_t cap)
+                  const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t nBlk, uint32_t cap, const uint32_t *__restrict__ seqLists)
 {
-    const uint32_t groupsPerBlk = (nItems + G - 1) / G;                          // (one launch for every block index: see k_dec_huffman)
-    const uint32_t blk = blockIdx.x / groupsPerBlk, bx = blockIdx.x - blk * groupsPerBlk;
-    (void)nBlk;
+    // the blocks of this table class, listed by k_dec_prep (every block index of the call in one launch: blocks decode independently)
+    const uint32_t listed = seqLists[LOG9 ? 1 : 0];
+    if (blockIdx.x * G >= listed) return;
+    const uint32_t *list = seqLists + 2 + (LOG9 ? (size_t)cap * nBlk : 0);
     static_assert(G <= 16, "four lanes an item");
     __shared__ __attribute__((aligned(16))) SeqDecLds<LOG9, G> S;
     constexpr uint32_t LLC = LOG9 ? 512 : 256, OFB = LLC, MLB = LLC + 256;        // cells of the LL table; where OF and ML start
     const uint32_t lane = (uint32_t)zs_lane();
     const uint32_t g = lane >> 2, r = lane & 3u;
-    const uint32_t item = bx * G + g;
+    const uint32_t v = blockIdx.x * G + g;
+    const uint32_t slot = (g < G && v < listed) ? list[v] : 0u;                 // block index * cap + item
+    const uint32_t item = slot % cap;
     bool mine = false; uint32_t nbSeq = 0, size = 0, llLog = 0, ofLog = 0, mlLog = 0;
     const uint8_t *src = srcAll;
-    const size_t slot0 = (size_t)blk * cap;
-    if (g < G && item < nItems) {
-        const ZsFastDesc *d = descs + slot0 + item;
+    if (g < G && v < listed && item < nItems) {
+        const ZsFastDesc *d = descs + slot;
         if (descs[item].fast && d->fast && d->nbSeq && ((d->llLog > 8 || d->mlLog > 8) == LOG9)) { mine = true; nbSeq = d->nbSeq; size = d->seqSize; llLog = d->llLog; ofLog = d->ofLog; mlLog = d->mlLog; src = srcAll + items[item].srcOff + d->seqOff; }
     }
     if (!__ballot(mine)) return;
     for (uint32_t gg = 0; gg < G; gg++) {
         if (!wave_get(mine ? 1u : 0u, (int)(4 * gg))) continue;
-        const uint32_t *st = reinterpret_cast<const uint32_t *>(seqTabs + (slot0 + bx * G + gg) * ZS_FAST_SEQTAB_BYTES);
+        const uint32_t *st = reinterpret_cast<const uint32_t *>(seqTabs + (size_t)wave_get(slot, (int)(4 * gg)) * ZS_FAST_SEQTAB_BYTES);
         const uint32_t a = 1u << wave_get(llLog, (int)(4 * gg)), o = 1u << wave_get(ofLog, (int)(4 * gg)), m = 1u << wave_get(mlLog, (int)(4 * gg));
         {   // the three tables, two cells a dword: every load issued before the first LDS store (up to 4 + 2 + 4 dwords per lane)
             uint32_t va[4], vo[2], vm[4];
@@ -504,7 +513,7 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
     const uint32_t gi = min(g, G - 1u);
     uint32_t *winW = S.win[gi];
     const uint32_t *win = winW;
-    ZsFastSeq *outp = seqOutAll + (slot0 + item) * ZS_FAST_MAXSEQ;
+    ZsFastSeq *outp = seqOutAll + (size_t)slot * ZS_FAST_MAXSEQ;
     // what a lane's role fixes: its table, the constants of its code's extra-bit count (see k_dec_sequences; an offset code IS its count),
     // where its state bits sit below the other states' (LL on top, then ML, then OF, :1547-1550)
     const uint16_t *cellsB = S.cells[gi] + (r == 1 ? MLB : (r == 2 ? OFB : 0u)) - 512;

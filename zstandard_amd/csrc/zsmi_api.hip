@@ -138,7 +138,7 @@ struct zsmi_ctx {
     std::vector<uint64_t> planKey;       // copy of (srcOffsets, srcSizes, dstOffsets) the device-side plan was built from
     uint64_t planBlocks = 0; uint32_t planMaxChunkBlocks = 1;
     // decompress workspace
-    DevBuf dItems, dLitScratch, dFastDesc, dHufTabs, dSeqTabs, dSeqOut;     // decode: items, literal scratch, fast-path tables and sequences
+    DevBuf dItems, dLitScratch, dFastDesc, dHufTabs, dSeqTabs, dSeqOut, dSeqLists;     // decode: items, literal scratch, fast-path tables and sequences, the blocks of each table class
     bool decodeFast = true;              // ZSMI_DEC_FAST=0: general kernel only
     uint32_t maxItemsInFlight = 65536;   // ZSMI_ITEMS_IN_FLIGHT: items per decode launch (scratch: ~263 KiB per item and block slot, one slot unless an item can hold two 64 KiB blocks; cut down to half the free device memory).
                                          // Every decode kernel is a long dependent chain per item: a launch is one to three rounds of workgroups and its
@@ -215,7 +215,7 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
 {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dUnits, &c->dItems, &c->dLitScratch, &c->dFastDesc, &c->dHufTabs, &c->dSeqTabs, &c->dSeqOut, &c->sSrc, &c->sDst, &c->sSizes, &c->sDict, &c->sPack, &c->sPackOff }) b->release();
+    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dUnits, &c->dItems, &c->dLitScratch, &c->dFastDesc, &c->dHufTabs, &c->dSeqTabs, &c->dSeqOut, &c->dSeqLists, &c->sSrc, &c->sDst, &c->sSizes, &c->sDict, &c->sPack, &c->sPackOff }) b->release();
     for (int i = 0; i < zsmi_ctx::kMaxLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
         if (L.stream) (void)hipStreamSynchronize(L.stream);
@@ -427,7 +427,8 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
     }
     if (!c->dLitScratch.reserve((size_t)cap * (fast ? maxBlocks : 1) * ((1u << 17) + 64))) return ZSMI_error_memory_allocation;
     if (fast && (!c->dFastDesc.reserve((size_t)cap * descSlots * sizeof(ZsFastDesc)) || !c->dHufTabs.reserve((size_t)cap * maxBlocks * ZS_FAST_HUFTAB_BYTES) ||
-                 !c->dSeqTabs.reserve((size_t)cap * maxBlocks * ZS_FAST_SEQTAB_BYTES) || !c->dSeqOut.reserve((size_t)cap * maxBlocks * ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)))) return ZSMI_error_memory_allocation;
+                 !c->dSeqTabs.reserve((size_t)cap * maxBlocks * ZS_FAST_SEQTAB_BYTES) || !c->dSeqOut.reserve((size_t)cap * maxBlocks * ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)) ||
+                 !c->dSeqLists.reserve((2 + 2 * (size_t)cap * maxBlocks) * sizeof(uint32_t)))) return ZSMI_error_memory_allocation;
     for (uint32_t i0 = 0; i0 < n; i0 += cap) {
         const uint32_t cnt = std::min(cap, n - i0);
         const ZsDecItem *dI = (const ZsDecItem *)c->dItems.p + i0;
@@ -437,23 +438,25 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
             // (decode_fast.hip); whatever those kernels do not take or reject is left to the general kernel below
             ZsFastDesc *dD = (ZsFastDesc *)c->dFastDesc.p;
             const uint32_t groups = (cnt + ZS_FAST_GROUP - 1) / ZS_FAST_GROUP;
+            uint32_t *dLists = (uint32_t *)c->dSeqLists.p;                // [0], [1]: blocks listed per sequence-table class; then the two lists
+            if (hipMemsetAsync(dLists, 0, 2 * sizeof(uint32_t), c->stream) != hipSuccess) return ZSMI_error_GENERIC;
             LAUNCH(c, "k_dec_prep", (k_dec_prep<ZS_DEC_GROUP>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc, dI, cnt, dD,
-                   (uint8_t *)c->dHufTabs.p, (uint8_t *)c->dSeqTabs.p, cap, maxBlocks);
+                   (uint8_t *)c->dHufTabs.p, (uint8_t *)c->dSeqTabs.p, cap, maxBlocks, dLists);
             {   // every block index of the items in one launch per kernel class (the grid: maxBlocks runs of the items' groups; a wavefront whose items
                 // have no such block leaves at once)
                 const uint32_t mb = maxBlocks, vcnt = cnt * mb;                 // (item, block) pairs: what a launch's rounds of workgroups count
                 LAUNCH(c, "k_dec_huffman", (k_dec_huffman<false, ZS_FAST_GROUP>), dim3(groups * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, mb, cap);
                 LAUNCH(c, "k_dec_huffman", (k_dec_huffman<true, 8u>), dim3(((cnt + 7) / 8) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, mb, cap);
-                LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3(((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap);
+                LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3(((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists);
                 // the 2.5 KiB table class: fuller wavefronts (16 items) win when a launch is several rounds of workgroups, emptier ones (4) when it
                 // is less than one (8192 frames of 128 KiB: 83 vs 77 GiB/s; 16384: 117 vs 128)
                 // (r3: and when 4 items a wavefront save a whole round of workgroups - 14 x 4 = 56 items a CU against 3 x 16 = 48 -: 57344 libzstd
                 //  frames of 32 KiB are 4 rounds instead of 5, 3.8 vs 5.2 ms)
                 const uint32_t rounds16 = (vcnt + 48u * 256u - 1) / (48u * 256u), rounds4 = (vcnt + 56u * 256u - 1) / (56u * 256u);
                 if (vcnt >= ZS_FAST_SEQGROUP_MANY && rounds4 >= rounds16)
-                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, ZS_FAST_SEQGROUP>), dim3(((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap);
+                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, ZS_FAST_SEQGROUP>), dim3(((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists);
                 else
-                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, 4u>), dim3(((cnt + 3) / 4) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap);
+                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, 4u>), dim3(((cnt + 3) / 4) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists);
             }
             if (maxBlocks == 1)
                 LAUNCH(c, "k_dec_execute", (k_dec_execute<4, 7>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (ZsFastSeq *)c->dSeqOut.p,
