@@ -53,7 +53,16 @@ def test_two_ranks_gloo():
     assert res == (True, True, True)
 
 
-def _worker_io(rank, world, port, q):
+def _io_sizes(kind):
+    rng = np.random.default_rng(9)
+    if kind == "skewed8":
+        # what 8 ranks make of it: a chunk that is a whole shard and more (the ranks behind it get EMPTY shards), a rank whose shard is ONE chunk,
+        # runs of empty and tiny chunks, and ordinary shards - all seven peers of the root transfer at once, or not at all
+        return np.concatenate([[131072 * 3], [0, 0, 7], rng.integers(20000, 50000, 6), [131072], [1, 2, 3], rng.integers(0, 30000, 10)]).astype(np.uint32)
+    return np.concatenate([rng.integers(0, 70000, 21), [0, 131072, 5]]).astype(np.uint32)
+
+
+def _worker_io(rank, world, port, q, kind="plain"):
     """scatter from rank 0 -> per-shard codec call (oracle, CPU) -> gather to rank 0: the §8e data path end to end"""
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     import torch, torch.distributed as dist
@@ -61,8 +70,7 @@ def _worker_io(rank, world, port, q):
     from zstandard_amd.sharding import scatter_chunks, gather_frames
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    rng = np.random.default_rng(9)
-    sizes = np.concatenate([rng.integers(0, 70000, 21), [0, 131072, 5]]).astype(np.uint32)      # known to every rank
+    sizes = _io_sizes(kind)                                                                      # known to every rank
     total = int(sizes.astype(np.uint64).sum())
     data = torch.from_numpy(D.zipf_log(total + 16)[:total].copy()) if rank == 0 else None        # only the root has the input
     shard, (b, e) = scatter_chunks(data, sizes, root=0)
@@ -88,6 +96,26 @@ def _worker_io(rank, world, port, q):
     else:
         assert out is None and len(gsizes) == len(sizes)
     dist.destroy_process_group()
+
+
+def test_scatter_compress_gather_gloo_world8():
+    """the configuration the driver's scaling run uses: 8 ranks, the root sending to / receiving from 7 peers in one grouped batch;
+    shards that are empty, a shard of one chunk"""
+    import torch.multiprocessing as mp
+    from zstandard_amd.sharding import partition_chunks
+    parts = partition_chunks(_io_sizes("skewed8"), 8)
+    counts = [e - b for b, e in parts]
+    assert 0 in counts and 1 in counts and max(counts) > 3, counts          # the shapes this test is for
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    ps = [ctx.Process(target=_worker_io, args=(r, 8, port, q, "skewed8")) for r in range(8)]
+    for p in ps:
+        p.start()
+    res = q.get(timeout=300)
+    for p in ps:
+        p.join(timeout=120)
+    assert res is True and all(p.exitcode == 0 for p in ps)
 
 
 @pytest.mark.parametrize("world", [2, 3])

@@ -252,18 +252,36 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
 // Last, the records that count are packed, 1 KiB of source (an OUTPUT RANGE = 1024 / R walk ranges) at a time, into the layout the
 // entropy kernels read: seqAll[block][64 output ranges][256 records] + hdrAll (nseq, trailing, litSum, first = 0).
 // ---------------------------------------------------------------------------------------------
+#ifndef ZS_WALK_MASK
+#define ZS_WALK_MASK 1             // 1: lanes without a candidate / walkers at rest take no part in the step's LDS reads
+#endif
 #ifndef ZS_WALK_MINW
 #define ZS_WALK_MINW 1             // waves per SIMD the small-unit kernel is compiled for (register budget)
 #endif
-// lanes per walker = aligned groups of 8 positions a step looks at (oracle: windowGroups): 2 for walk ranges of 256 bytes, 4 for ranges of 512
-// bytes (levels <= 2) - either way a walker per walk range and 512 threads per 64 KiB
-#define ZS_WALK_LPW(WLOG) ((WLOG) >= 9 ? 4 : 2)
+// aligned groups of 8 positions a step looks at (oracle: windowGroups): 2 for walk ranges of 256 bytes, 4 for ranges of 512 bytes (levels <= 2);
+// a walker = LPW lanes that share them (LPW divides the groups); either way a walker per walk range
+#define ZS_WALK_WGRP(WLOG) ((WLOG) >= 9 ? 4 : 2)
+#ifndef ZS_WALK_LPW_256
+#define ZS_WALK_LPW_256 2
+#endif
+#ifndef ZS_WALK_LPW_512
+#define ZS_WALK_LPW_512 4
+#endif
+#define ZS_WALK_LPW(WLOG) ((WLOG) >= 9 ? ZS_WALK_LPW_512 : ZS_WALK_LPW_256)
 #define ZS_WALK_THREADS(BIG, WLOG) ((((BIG) ? ZS_UNIT_MAX : ZS_BLOCK_MAX) >> (WLOG)) * ZS_WALK_LPW(WLOG))
-#define ZS_WALK_KERNEL(LOOK, REPW, BIG, WLOG) k_lz_walk<ZS_WALK_LPW(WLOG), LOOK, REPW, BIG, ZS_WALK_THREADS(BIG, WLOG)>
-#define ZS_WALK_FRONT 16u          // LDS bytes in front of the unit (backward reads near position 0)
+#define ZS_WALK_KERNEL(LOOK, REPW, BIG, WLOG) k_lz_walk<ZS_WALK_LPW(WLOG), ZS_WALK_WGRP(WLOG), LOOK, REPW, BIG, ZS_WALK_THREADS(BIG, WLOG)>
+// The unit's source in LDS is SKEWED: rows of 256 source bytes lie 256 + ZS_WALK_SKEW bytes apart, and the ZS_WALK_SKEW bytes behind a row
+// repeat the head of the next row, so a read of up to 24 bytes that STARTS in a row is contiguous in that row's storage:
+// LDS address of position p = SRC + p + ZS_WALK_SKEW * (p >> 8) (p signed: row -1 is the front pad).  Why: the walkers of a wavefront sit at
+// nearly the same offset inside ranges that are 256 bytes apart - bank (a / 4) mod 32 made every "own side" read of a step a 4 - 16-way
+// conflict (tools/lab/lds_sim.c prices the kernel's reads with the bank rules: 309 LDS cycles a wave step, measured 293; with the skew
+// and idle lanes masked 171).  24 bytes = 6 banks a row: 16 walkers (32 lanes = a dword-read group) land on 16 different bank pairs.
+#define ZS_WALK_SKEW  24u
+#define ZS_WALK_FRONT 48u          // row -1 of the staged source: 24 zero bytes (positions -24 .. -1: backward reads near position 0) + the copy of row 0's head
 #define ZS_WALK_TAIL  144u         // zero bytes behind the unit (forward reads near the end)
-// exchange buffer (16 bytes a lane) + source + queue head + a byte a lane (BIG: bit 16 of the distances)
-#define ZS_WALK_LDS(CAPB) (ZS_WALK_FRONT + (CAPB) + ZS_WALK_TAIL + (CAPB) / 8 + 16 + 16 + 1024)
+#define ZS_WALK_SRCBYTES(CAPB) ((((CAPB) + ZS_WALK_TAIL + ZS_WALK_SKEW * (((CAPB) + ZS_WALK_TAIL) / 256u + 1u)) + 15u) & ~15u)
+// exchange buffer (16 bytes a lane) + front + skewed source + queue head + a byte a lane (BIG: bit 16 of the distances)
+#define ZS_WALK_LDS(CAPB) ((CAPB) / 8 + 16 + ZS_WALK_FRONT + ZS_WALK_SRCBYTES(CAPB) + 16 + 1024)
 
 // K dwords of the LDS copy starting at any byte offset, fetched as K + 1 aligned dwords and shifted into place
 // (an unaligned ds_read_b64 / b128 costs the LDS several passes: SQ_LDS_UNALIGNED_STALL was 80 % of its busy time)
@@ -299,19 +317,19 @@ __device__ __forceinline__ uint32_t zs_agree16(const uint32_t (&a)[4], const uin
 // or / max / min over the LPW (2 or 4) adjacent lanes of a walker (data-parallel-primitive moves inside a quad: no LDS round trip)
 template <int LPW> __device__ __forceinline__ uint32_t walker_or(uint32_t v)
 {
-    v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+    if constexpr (LPW >= 2) v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
     if constexpr (LPW == 4) v |= (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
     return v;
 }
 template <int LPW> __device__ __forceinline__ int walker_max(int v)
 {
-    v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));
+    if constexpr (LPW >= 2) v = max(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));
     if constexpr (LPW == 4) v = max(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));
     return v;
 }
 template <int LPW> __device__ __forceinline__ uint32_t walker_min(uint32_t v)
 {
-    v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+    if constexpr (LPW >= 2) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
     if constexpr (LPW == 4) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
     return v;
 }
@@ -351,20 +369,29 @@ __device__ __forceinline__ uint32_t zs_nonzero8(const uint4 d)
 #else
 #define WPROF_STAMP(k)
 #endif
-template <int LPW, int LOOK, int REPWIN, bool BIG, int NT>
+template <int LPW, int WGRP, int LOOK, int REPWIN, bool BIG, int NT>
 __global__ void __launch_bounds__(NT, BIG ? 1 : ZS_WALK_MINW)
 k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units, uint32_t block0,
           const uint16_t *__restrict__ distAll, const uint8_t *__restrict__ distHiAll,
           uint2 *__restrict__ recAll, uint32_t junkSlot, uint4 *__restrict__ resAll, int rangeLogArg)
 {
     constexpr uint32_t CAP = BIG ? ZS_UNIT_MAX : ZS_BLOCK_MAX;                  // unit capacity in bytes
-    constexpr uint32_t CPL = LOOK / LPW, RPL = REPWIN / LPW;                     // candidates / recent-offset positions per lane and step
-    static_assert((LPW == 2 || LPW == 4) && LOOK % LPW == 0 && REPWIN % LPW == 0 && CPL >= 1 && RPL >= 1 && LOOK <= 8 && REPWIN <= 8, "a walker's lanes share the candidates evenly");
-    static_assert(NT >= 256 && NT % 64 == 0 && NT * 16 <= CAP / 8, "the stitch takes a block's <= 256 ranges a thread each; the exchange buffer holds 16 bytes a lane");
+    constexpr uint32_t CPL = LOOK / LPW, RPL = REPWIN / LPW, GPL = WGRP / LPW;   // candidates / recent-offset positions / groups of distances per lane and step
+    static_assert((LPW == 1 || LPW == 2 || LPW == 4) && WGRP % LPW == 0 && LOOK % LPW == 0 && REPWIN % LPW == 0 && CPL >= 1 && RPL >= 1 && LOOK <= 8 && REPWIN <= 8, "a walker's lanes share the groups and candidates evenly");
+    static_assert(NT >= 64 && NT % 64 == 0 && NT * GPL * 16 <= CAP / 8, "the exchange buffer holds 16 bytes a lane and group");
     extern __shared__ __attribute__((aligned(16))) uint8_t walkLds[];
     // LDS: exchange buffer (the low addresses: the LDS-DMA's base register is not known to reach beyond 64 KiB), front pad, source, tail pad, results, queue, xhi
     constexpr uint32_t SRC = CAP / 8 + 16 + ZS_WALK_FRONT;                       // LDS address of source byte 0
-    uint8_t *ls = walkLds + SRC;                                                 // ls[p] = source byte p
+    // LDS address of source position p (p may be a little negative: row -1 = the front pad)
+    auto lpos = [](uint32_t p) { return SRC + p + (uint32_t)__mul24((int)p >> 8, (int)ZS_WALK_SKEW); };
+    // 16 source bytes at position i (a multiple of 16) into the skewed copy, and into the row before's tail where they are a row's head
+    auto stage16 = [&](uint32_t i, const uint4 v) {
+        uint8_t *d = walkLds + lpos(i);
+        *reinterpret_cast<uint2 *>(d) = make_uint2(v.x, v.y); *reinterpret_cast<uint2 *>(d + 8) = make_uint2(v.z, v.w);
+        const uint32_t o = i & 255u;
+        if (o == 0) { *reinterpret_cast<uint2 *>(d - ZS_WALK_SKEW) = make_uint2(v.x, v.y); *reinterpret_cast<uint2 *>(d - ZS_WALK_SKEW + 8) = make_uint2(v.z, v.w); }
+        else if (o == 16) *reinterpret_cast<uint2 *>(d - ZS_WALK_SKEW) = make_uint2(v.x, v.y);
+    };
     const uint32_t tid = threadIdx.x, lane = tid & 63u;
     const uint32_t rangeLog = (uint32_t)rangeLogArg, R = 1u << rangeLog;
     const ZsUnitDesc ud = units[blockIdx.x];
@@ -373,8 +400,9 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
     const uint32_t n = ud.size;
     const uint16_t *dist = distAll + (size_t)slot * ZS_BLOCK_MAX;
     const uint8_t *distHi = distHiAll + (size_t)slot * (ZS_BLOCK_MAX / 8);
-    uint4 *xbuf = reinterpret_cast<uint4 *>(walkLds);                              // exchange buffer: lane t's 8 distances at xbuf[t]
-    uint32_t *queue = reinterpret_cast<uint32_t *>(walkLds + SRC + CAP + ZS_WALK_TAIL);
+    uint4 *xbuf = reinterpret_cast<uint4 *>(walkLds);                              // exchange buffer: wavefront w's region holds GPL x 64 slots of 8 distances: lane t's k-th group at [(64 w) GPL + 64 k + t]
+    const uint32_t xw = (tid & ~63u) * GPL;                                      // my wavefront's first slot
+    uint32_t *queue = reinterpret_cast<uint32_t *>(walkLds + SRC + ZS_WALK_SRCBYTES(CAP));
     uint4 *res = resAll + (size_t)slot * ZS_RES_PER_BLOCK;                       // per walk range (R >= 256: at most 256 a block): records, last match end in its block, last offset
     uint8_t *xhi = reinterpret_cast<uint8_t *>(queue + 4);                        // BIG: lane t's byte of bit 16 of its 8 distances
     uint2 *recs = recAll + (size_t)slot * (ZS_BLOCK_MAX / 4);                     // range at unit position p: slots from p / 4 (its matches start inside it, >= 4 bytes each)
@@ -386,7 +414,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
 
     // ---- stage the unit ----
     uint32_t mixed = 0;                                                          // some byte of the unit differs from its first byte
-    if (tid < ZS_WALK_FRONT / 4) reinterpret_cast<uint32_t *>(walkLds + SRC - ZS_WALK_FRONT)[tid] = 0;
+    if (tid < (ZS_WALK_FRONT - ZS_WALK_SKEW) / 4) reinterpret_cast<uint32_t *>(walkLds + SRC - ZS_WALK_FRONT)[tid] = 0;
     if (tid == 0) { queue[0] = 0; queue[1] = 0; }
     __syncthreads();
     {
@@ -406,7 +434,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
         #pragma unroll
         for (uint32_t k = 0; k < PER; k++) {
             const uint32_t i = (tid + k * NT) * 16;
-            if (i + 16 <= nFull) *reinterpret_cast<uint4 *>(ls + i) = v[k];
+            if (i + 16 <= nFull) stage16(i, v[k]);
             // (clamped pieces hold piece 0: comparing them too is harmless)
             mixed |= (v[k].x ^ splat) | (v[k].y ^ splat) | (v[k].z ^ splat) | (v[k].w ^ splat);
         }
@@ -418,7 +446,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
                 for (uint32_t k = 0; k < 16 && i + k < n; k++) { const uint64_t c = s[i + k]; if (k < 8) lo |= c << (8 * k); else hi |= c << (8 * (k - 8)); }
                 w = make_uint4((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32));
             }
-            if (i + 16 <= CAP + ZS_WALK_TAIL) *reinterpret_cast<uint4 *>(ls + i) = w;
+            if (i + 16 <= CAP + ZS_WALK_TAIL) stage16(i, w);
         }
     }
 #if defined(ZS_WALK_STOP) && ZS_WALK_STOP == 1
@@ -451,14 +479,17 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
         // cannot tell apart from the destination; this one is waited for by hand: "s_waitcnt vmcnt(0)" at the top of the step and where a
         // walker takes a new range.  M0 = LDS destination of lane 0, set inside the statement that uses it.)
         typedef __attribute__((address_space(3))) uint4 *ZsLdsU4;
-        const uint32_t xwaveLds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(ZsLdsU4)(xbuf + (tid & ~63u)));
-        uint32_t gh = 0;
+        const uint32_t xwaveLds = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(uintptr_t)(ZsLdsU4)(xbuf + xw));
+        uint32_t gh[GPL] = {};
         auto loadGroup = [&](uint32_t p) {
-            const uint32_t g = (p >> 3) + sub;
-            const uint16_t *gsrc = dist + (size_t)g * 8u;
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(xwaveLds) : "memory");
-            if (BIG) gh = (uint32_t)distHi[g];
+            #pragma unroll
+            for (uint32_t k = 0; k < GPL; k++) {                                 // the lane's groups: sub, sub + LPW, ..
+                const uint32_t g = (p >> 3) + sub + LPW * k;
+                const uint16_t *gsrc = dist + (size_t)g * 8u;
+                uint32_t keep;
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0" : "=&s"(keep) : "v"(gsrc), "s"(xwaveLds + k * 1024u) : "memory");
+                if (BIG) gh[k] = (uint32_t)distHi[g];
+            }
         };
         for (;;) {
             if (__any(!active && more)) {
@@ -490,17 +521,21 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
 #ifdef ZS_WALK_PROFILE
             wprof[8] += 1; wprof[9] += (unsigned long long)__popcll(__ballot(active));
 #endif
-            const uint32_t wend = min((ip & ~7u) + 8u * LPW, scanEnd);            // the walker's LPW groups
+            const uint32_t wend = min((ip & ~7u) + 8u * WGRP, scanEnd);           // the walker's groups
             // ---- recent offsets: the walker's lanes try RPL positions each ----
             uint32_t rm0 = 0, rm1 = 0;                                           // bit i: rep0 / rep1 repeats 4 bytes at ip + i
             {
                 const bool t0 = active && rep0 != 0 && ip >= rep0, t1 = active && rep1 != 0 && ip >= rep1;
                 const uint32_t p0 = ip + sub * RPL;
                 constexpr int SP = (RPL + 3 + 3) / 4;                            // dwords that hold RPL + 3 bytes
-                uint32_t a[SP], b[SP], c[SP];
-                lds_span<SP>(SRC + p0, a);
-                lds_span<SP>(SRC + (t0 ? p0 - rep0 : p0), b);
-                lds_span<SP>(SRC + (t1 ? p0 - rep1 : p0), c);
+                uint32_t a[SP] = {}, b[SP] = {}, c[SP] = {};
+                // (lanes with nothing to try stay out of the reads: an LDS instruction costs what its busiest bank takes, and walkers at rest
+                // all sit at a range end - the same bank)
+                if (!ZS_WALK_MASK || t0 || t1) {
+                    lds_span<SP>(lpos(p0), a);
+                    lds_span<SP>(lpos(t0 ? p0 - rep0 : p0), b);
+                    lds_span<SP>(lpos(t1 ? p0 - rep1 : p0), c);
+                }
                 auto tryAt = [&](auto iTag) {
                     constexpr int I = decltype(iTag)::value;
                     const uint32_t q = p0 + I;
@@ -512,15 +547,21 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
                 tryAt(std::integral_constant<int, 0>{});
                 if constexpr (RPL >= 2) tryAt(std::integral_constant<int, 1>{});
                 if constexpr (RPL >= 4) { tryAt(std::integral_constant<int, 2>{}); tryAt(std::integral_constant<int, 3>{}); }
+                if constexpr (RPL >= 8) { tryAt(std::integral_constant<int, 4>{}); tryAt(std::integral_constant<int, 5>{}); tryAt(std::integral_constant<int, 6>{}); tryAt(std::integral_constant<int, 7>{}); }
                 rm0 = walker_or<LPW>(rm0); rm1 = walker_or<LPW>(rm1);
                 rm1 &= ~rm0;                                                     // rep0 is tried first
             }
             WPROF_STAMP(2)
             // ---- the window: the walker's four groups of distances are in the exchange buffer (requested a step ago); my group's candidate bits, the four groups' side by side ----
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const uint4 gd = xbuf[tid];
-            if (BIG) xhi[tid] = (uint8_t)gh;
-            uint32_t m = walker_or<LPW>((zs_nonzero8(gd) | gh) << (8u * sub)) >> (ip & 7u);            // bit i: position ip + i has a candidate
+            uint32_t m = 0;
+            #pragma unroll
+            for (uint32_t k = 0; k < GPL; k++) {
+                const uint4 gd = xbuf[xw + 64u * k + lane];
+                if (BIG) xhi[xw + 64u * k + lane] = (uint8_t)gh[k];
+                m |= (zs_nonzero8(gd) | gh[k]) << (8u * (sub + LPW * k));
+            }
+            m = walker_or<LPW>(m) >> (ip & 7u);                                  // bit i: position ip + i has a candidate
             if (active) m = (m & (0xFFFFFFFFu >> (32u - (wend - ip)))) | rm0 | rm1; else m = 0;   // 1 <= wend - ip <= 8 LPW while active
             {                                                                    // lane sub takes the candidates sub * CPL ..: clear the lower ones
                 const uint32_t skip = sub * CPL;
@@ -538,7 +579,8 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
                 const bool r0 = ((rm0 >> idx[c]) & 1u) != 0, r1 = ((rm1 >> idx[c]) & 1u) != 0;
                 isRep[c] = have[c] && (r0 || r1);
                 // the distance: group (q >> 3) - (ip >> 3) of the walker, that lane's slot of the exchange buffer (same wavefront: in order behind the stores above)
-                const uint32_t owner = (tid & ~(LPW - 1u)) + ((q >> 3) - (ip >> 3));
+                const uint32_t j = (q >> 3) - (ip >> 3);                         // its group: lane j % LPW of the walker, that lane's group j / LPW
+                const uint32_t owner = xw + 64u * (j / LPW) + (lane & ~(LPW - 1u)) + (j % LPW);
                 uint32_t d = reinterpret_cast<const uint16_t *>(xbuf + owner)[q & 7u];
                 if (BIG) d |= (((uint32_t)xhi[owner] >> (q & 7u)) & 1u) << 16;
                 off[c] = r0 ? rep0 : (r1 ? rep1 : d);
@@ -550,9 +592,11 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
             #pragma unroll
             for (uint32_t c = 0; c < CPL; c++) {
                 const uint32_t q = ip + idx[c];
-                uint32_t a[3], b[3];                                             // bytes [q - 4, q + 8) of both sides
-                lds_span<3>(SRC + q - 4, a);
-                lds_span<3>(SRC + q - off[c] - 4, b);
+                uint32_t a[3] = {}, b[3] = {};                                   // bytes [q - 4, q + 8) of both sides
+                if (!ZS_WALK_MASK || have[c]) {
+                    lds_span<3>(lpos(q - 4), a);
+                    lds_span<3>(lpos(q - off[c] - 4), b);
+                }
                 const uint32_t xb = a[0] ^ b[0], x0 = a[1] ^ b[1], x1 = a[2] ^ b[2];
                 const uint32_t f0 = x0 ? (uint32_t)__builtin_ctz(x0) : 32u, f1 = x1 ? (uint32_t)__builtin_ctz(x1) : 32u;
                 const uint32_t fwd = min(((x0 ? f0 : 32u + f1)) >> 3, limit - q);
@@ -581,8 +625,8 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
                     uint32_t nb = 0;
                     if (fo < cap) {
                         uint32_t a[4], b[4];
-                        lds_span<4>(SRC + pos + fo, a);
-                        lds_span<4>(SRC + pos - boff + fo, b);
+                        lds_span<4>(lpos(pos + fo), a);
+                        lds_span<4>(lpos(pos - boff + fo), b);
                         nb = zs_agree16(a, b);
                     }
                     if (nb < 16u || fo + 16u >= cap) e = min(fo + nb, cap);
