@@ -1,0 +1,22 @@
+import os, sys, ctypes
+os.environ["ZSMI_DEBUG_LIB"] = "1"
+import numpy as np, torch
+ROOT = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import _data as D
+from zstandard_amd import BatchCodec, _lib
+n, cs = 1024, 65536
+data = D.zipf_log(n * cs)
+dsrc = torch.from_numpy(data).cuda()
+bc = BatchCodec(0); Z = _lib.lib()
+off = np.arange(n, dtype=np.uint64) * cs; sz = np.full(n, cs, dtype=np.uint32)
+bound = int(Z.zsmi_compressBound(cs)); doff = np.arange(n, dtype=np.uint64) * bound
+ddst = torch.empty(n * bound, dtype=torch.uint8, device="cuda"); dsz = torch.empty(n, dtype=torch.int32, device="cuda")
+bc.compress_device(dsrc.data_ptr(), off, sz, ddst.data_ptr(), doff, dsz.data_ptr(), 3); bc.sync()
+buf = np.zeros(n * 32, dtype=np.uint8)
+rc = Z.zsmi_dbg_copyScratch(bc.ctx, 3, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(buf))); assert rc == 0, rc
+m = buf.view(np.uint32).reshape(n, 8)
+fails = m[:, 6] & 0xFFFF; rounds = m[:, 6] >> 16
+K = m[:, 7] & 0xFF; Sb = (m[:, 7] >> 8) & 0xFF; ns = m[:, 7] >> 16
+print("blocks", n, "K", np.bincount(K), "Sb mean", Sb.mean(), "nseq mean", ns.mean())
+print("failed seams per block: mean %.2f max %d; repair rounds mean %.2f max %d; blocks with none: %d" % (fails.mean(), fails.max(), rounds.mean(), rounds.max(), (fails == 0).sum()))

@@ -138,9 +138,7 @@ struct SeqLds {                      // sequences kernel.  Kept under 10 KiB: 16
     int16_t norm[64];
     union {
         struct { uint8_t tableSymbol[512]; uint32_t cumul[66]; uint32_t symCount[64]; uint32_t symMask[128]; } build;      // while a table is built
-        struct { uint2    op[3][66];         // per tile and table: {deltaNbBits, deltaFindState} of each sequence's code (+ padding)
-                 uint32_t tileState[3][64];  // per tile: state bits out (value | nbBits << 16)
-               } tile;                                                                                 // while the bitstream is written
+        struct { uint32_t op[3][64]; } chain;    // while the state chains run: per table and code, deltaNbBits | (deltaFindState + 1024) << 20 (one read a step)
     } u;
     uint32_t tile[208];              // bit-packing tile
     uint32_t misc[16];
@@ -1180,13 +1178,27 @@ __device__ static void buildCTableWave(SeqLds &L, FseCT &ct, const int16_t *norm
 #ifndef ZS_SEQ_GROUP
 #define ZS_SEQ_GROUP 4             // blocks (= wavefronts) per workgroup of the sequences kernel
 #endif
+#ifndef ZS_SEQ_TB
+#define ZS_SEQ_TB 4                // tiles of 64 sequences whose records are requested together (pass 1, packing)
+#endif
+#define ZS_CHAIN_CODES 16384u      // most sequences a block can hold (64 output ranges of 256 record slots): elements per table in the chain scratch
+#ifndef ZS_CHAIN_WARM
+#define ZS_CHAIN_WARM 512u         // steps a chain segment starts ahead of its first output (a multiple of 16)
+#endif
+#ifndef ZS_CHAIN_MAXSEG
+#define ZS_CHAIN_MAXSEG 21u        // most segments a chain is cut in (3 chains a wavefront: <= 21)
+#endif
+#ifndef ZS_CHAIN_MINSEG
+#define ZS_CHAIN_MINSEG 4u         // shortest segment, in blocks of 16 steps
+#endif
+static_assert(3u * ZS_CHAIN_CODES <= ZS_BLOCK_MAX + 64u && 3u * 2u * ZS_CHAIN_CODES <= 4u * ZS_STREAM_STRIDE && ZS_CHAIN_CODES == ZS_WALK_RANGES * ZS_SEQ_PER_RANGE, "the chain scratch fits the buffers it borrows");
 template <int G>
 __global__ void __launch_bounds__(64 * G)
-k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsSeqRec *__restrict__ seqAll, const ZsRangeHdr *__restrict__ hdrAll,
-                   uint8_t *__restrict__ seqSecAll, ZsBlockMeta *__restrict__ metas, int stopAt)
+k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, const ZsSeqRec *__restrict__ seqAll, const ZsRangeHdr *__restrict__ hdrAll,
+                   uint8_t *__restrict__ seqSecAll, ZsBlockMeta *__restrict__ metas, int stopAt, uint8_t *__restrict__ litsAll, uint8_t *__restrict__ streamAll,
+                   uint2 *__restrict__ packRecAll)
 {
     __shared__ SeqLds LS[G];
-    __shared__ uint32_t tilesOf[G];                    // bitstream tiles (64 sequences each) of the workgroup's blocks
     const uint32_t wave = threadIdx.x >> 6;
     SeqLds &L = LS[wave];
     const uint32_t blk = blockIdx.x * G + wave;
@@ -1194,10 +1206,15 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
     const bool exists = blk < nBlocks;
     const ZsBlockDesc bd = blocks[exists ? blk : 0];
     const uint32_t n = bd.size;
-    ZsSeqRec *seqBase = seqAll + (size_t)blk * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE;
+    const ZsSeqRec *seqBase = seqAll + (size_t)blk * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE;
     const ZsRangeHdr *hdr = hdrAll + (size_t)blk * ZS_WALK_RANGES;
     uint8_t *out = seqSecAll + (size_t)blk * ZS_SEQSEC_STRIDE;         // 4-byte aligned
     const uint32_t cap = n + 512;
+    // scratch of part 2's state chains, borrowed from the literals kernel (which runs after this one and writes both before it reads them):
+    // a code byte a sequence and table in the block's literal buffer, 16 bits of chain output a sequence and table in its Huffman stream buffers
+    uint8_t *chainCodes = litsAll + (size_t)blk * (ZS_BLOCK_MAX + 64);
+    uint16_t *chainOuts = reinterpret_cast<uint16_t *>(streamAll + (size_t)blk * 4 * ZS_STREAM_STRIDE);
+    uint2 *packRec = packRecAll + (size_t)blk * ZS_CHAIN_CODES;       // 8 bytes a sequence: its extra bits; the block's slot of the stage-1 distances (128 KiB), dead since the walk
 
     // ======== part 1, each wavefront on its own block (no workgroup barrier inside): header, recent-offset codes,
     //          histograms, tables.  result: section size so far / 0xFFFFFFFF = no compressed sequences section ========
@@ -1231,7 +1248,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
             if (bd.firstInChunk) { cPrev = 1; cA = 4; cB = 8; } else { cPrev = 0xFFFFFFF1u; cA = 0xFFFFFFF2u; cB = 0xFFFFFFF3u; }
             // sequences are taken 64 at a time in block order, whatever walk range they belong to; the records of the next 64 are
             // loaded while these are worked on (their addresses depend on nothing that is carried)
-            auto locate = [&](uint32_t g, uint32_t &kOut, uint32_t &rrOut) -> ZsSeqRec * {
+            auto locate = [&](uint32_t g, uint32_t &kOut, uint32_t &rrOut) -> const ZsSeqRec * {
                 uint32_t rr = 0;
                 #pragma unroll
                 for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
@@ -1239,15 +1256,33 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                 return seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + L.rngFirst[rr] + kOut;
             };
             // (a record travels as its two raw words and is taken apart only where it is used: unpacked next to the load, the
-            // compiler waits for the load on the spot)
-            uint2 rawN = make_uint2(0, 0); ZsSeqRec *rpN = seqBase; uint32_t kN = 1, rrN = 0;
-            if (lane < nseq) { rpN = locate(lane, kN, rrN); rawN = *reinterpret_cast<const uint2 *>(rpN); }
-            asm volatile("" : "+v"(rawN.x), "+v"(rawN.y));                  // the first records are waited for here, not inside the loop
-            for (uint32_t base = 0; base < nseq; base += 64) {
+            // compiler waits for the load on the spot).  ZS_SEQ_TB tiles of 64 are requested together and worked through one after the other:
+            // a request a tile was a memory round trip a tile (the kernel's wavefronts spent half their time in s_waitcnt).
+            constexpr uint32_t TB = ZS_SEQ_TB;
+            uint2 rawN[TB]; uint32_t kN[TB], rrN[TB];
+            auto request = [&](uint32_t base) {
+                #pragma unroll
+                for (uint32_t t = 0; t < TB; t++) {
+                    const uint32_t g = base + 64u * t + lane;
+                    rawN[t] = make_uint2(0, 0); kN[t] = 1; rrN[t] = 0;
+                    if (g < nseq) { const ZsSeqRec *rp = locate(g, kN[t], rrN[t]); rawN[t] = *reinterpret_cast<const uint2 *>(rp); }
+                }
+            };
+            request(0);
+            #pragma unroll
+            for (uint32_t t = 0; t < TB; t++) asm volatile("" : "+v"(rawN[t].x), "+v"(rawN[t].y));     // the first records are waited for here, not inside the loop
+            for (uint32_t base0 = 0; base0 < nseq; base0 += 64u * TB) {
+                uint2 rawC[TB]; uint32_t kC[TB], rrC[TB];
+                #pragma unroll
+                for (uint32_t t = 0; t < TB; t++) { rawC[t] = rawN[t]; kC[t] = kN[t]; rrC[t] = rrN[t]; }
+                if (base0 + 64u * TB < nseq) request(base0 + 64u * TB);
+                #pragma unroll
+                for (uint32_t t = 0; t < TB; t++) {
+                const uint32_t base = base0 + 64u * t;
+                if (base >= nseq) break;
                 const uint32_t g = base + lane;
                 const bool in = g < nseq;
-                const uint2 raw = rawN; ZsSeqRec *rp = rpN; const uint32_t k = kN, rr = rrN;
-                if (g + 64 < nseq) { rpN = locate(g + 64, kN, rrN); rawN = *reinterpret_cast<const uint2 *>(rpN); }
+                const uint2 raw = rawC[t]; const uint32_t k = kC[t], rr = rrC[t];
                 uint32_t off = 0, ll = 0, ml = 0;
                 if (in) { off = zs_rec_off(raw.x, raw.y); ll = zs_rec_ll(raw.x); ml = zs_rec_ml(raw.x); if (k == 0) ll += rngCarry[rr]; }
                 uint32_t prev = ZS_DPP(0, off, 0x138, 0xF, true); if (lane == 0) prev = cPrev;      // wave_shr:1        // rep0 before me
@@ -1263,11 +1298,19 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                     uint32_t val;
                     if (ll) { val = (off == prev) ? 1u : (off == a) ? 2u : (off == b) ? 3u : 0u; }
                     else    { val = (off == a) ? 1u : (off == b) ? 2u : 0u; }
-                    rp->x = zs_rec_with_rep(raw.x, val);
                     const uint32_t v = val ? val : off + 3;
-                    atomicAdd(&L.count[llCodeOf(ll)], 1u);
-                    atomicAdd(&L.count[64 + zs_highbit(v)], 1u);
-                    atomicAdd(&L.count[128 + mlCodeOf(ml - 3)], 1u);
+                    const uint32_t llc = llCodeOf(ll), ofc = zs_highbit(v), mlc = mlCodeOf(ml - 3);
+                    atomicAdd(&L.count[llc], 1u);
+                    atomicAdd(&L.count[64 + ofc], 1u);
+                    atomicAdd(&L.count[128 + mlc], 1u);
+                    // for part 2, in encoding order (last sequence first): the codes the state chains walk along, and the sequence's extra bits
+                    // as they follow its three state outputs in the stream (literal length, match length, offset: <= 16 + 16 + 17 bits) with their count
+                    const uint32_t je = nseq - 1u - g;
+                    chainCodes[je] = (uint8_t)llc; chainCodes[ZS_CHAIN_CODES + je] = (uint8_t)ofc; chainCodes[2u * ZS_CHAIN_CODES + je] = (uint8_t)mlc;
+                    uint32_t xbL, xbM;
+                    const uint32_t xvL = llExtraOf(ll, xbL), xvM = mlExtraOf(ml - 3, xbM);
+                    const uint64_t E = (uint64_t)xvL | ((uint64_t)xvM << xbL) | ((uint64_t)(v - (1u << ofc)) << (xbL + xbM));
+                    packRec[je] = make_uint2((uint32_t)E, (uint32_t)(E >> 32) | ((xbL + xbM + ofc) << 24));
                 }
                 // carries for the next 64: state after the last sequence of this batch
                 const uint32_t cnt = min(64u, nseq - base);
@@ -1276,6 +1319,7 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
                 if (chm) { const int jl = 63 - __builtin_clzll(chm); cA = wave_get(prev, jl); }
                 if (rsm) { const int kl = 63 - __builtin_clzll(rsm); cB = wave_get(a, kl); }
                 cPrev = lastOff;
+                }
             }
         }
         wave_sync();
@@ -1335,156 +1379,196 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, ZsS
         live = true;
     } while (0);
 
-    // ======== part 2: sequences bitstream (inverse of ZStdDecompress.cs:1473-1608), last sequence first.  Per tile of 64
-    //   sequences: every wavefront turns its block's sequences into codes + table operands (all lanes); then wavefront 0
-    //   runs the FSE state chains of ALL G blocks at once (lane 3g + c: table c = LL, OF, ML of block g) -- a chain step is a
-    //   dependent LDS lookup per sequence, so sharing its instructions between blocks is what keeps the vector ALU free --;
-    //   then every wavefront packs its block's bits (all lanes).  The stream is built 4-byte aligned and moved down. ========
-    const uint32_t nT = live ? (nseq + 63u) >> 6 : 0u;
-    if (lane == 0) tilesOf[wave] = nT;
-    __syncthreads();
-    uint32_t maxT = 0;
-    #pragma unroll
-    for (int g = 0; g < G; g++) maxT = max(maxT, tilesOf[g]);
-
+    // ======== part 2: sequences bitstream (inverse of ZStdDecompress.cs:1473-1608), last sequence first; each wavefront on its own block,
+    //   no workgroup barrier.  An FSE state chain is a dependent table look-up per sequence (~3600 a block and table), and the format fixes
+    //   ONE chain per table.  But chains over the same symbols COUPLE: started from any state they agree with the true chain after some
+    //   steps for good (a step keeps state >> nbBits: tools/lab/coupling.c measures half of them coupled after 60 steps, 99.5 % after 512 on
+    //   the Zipf log, 96.5 % on the mixed corpus).  So a table's chain is cut in K <= 21 SEGMENTS of whole blocks of 16 steps; lane c K + k runs
+    //   segment k of table c, started ZS_CHAIN_WARM steps early from the state its first symbol alone gives (the rule of the block's true
+    //   first step), silent until its own segment begins; then the seams are checked in order - entry state of segment k == exit
+    //   state of segment k - 1 - and a segment that fails is run again from the right state (its outputs overwritten) before the
+    //   next seam is looked at, so the result is exactly the serial chain's.  63 lanes run ~(nseq / K + 512) steps instead of 3 lanes nseq.
+    //   Codes come from pass 1 (a byte a step and table, in encoding order), outputs go to scratch as 16 bits a step
+    //   (state bits | count << 12); both live in the literals kernel's scratch (streams, literals), which that kernel writes after this one.
+    //   Then the tiles of 64 sequences are packed, all lanes. ========
     uint8_t *bsTmp = out + ((bitstreamOff + 3u) & ~3u);                // aligned start inside the section buffer
     BitSink sink; sink_init(sink, bsTmp, L.tile);
     const uint32_t bsCap = ZS_SEQSEC_STRIDE - ((bitstreamOff + 3u) & ~3u) - 1024u;
-    uint32_t chainState = 0;                          // wavefront 0, lane 3g + c
     bool overflow = false;
-    uint32_t remaining = live ? nseq : 0u;
-    // sequence records are fetched one tile ahead: the loads of tile i+1 fly while the state chains of tile i run
-    // (as raw words, taken apart where they are used: see pass 1)
-    uint2 recN = make_uint2(0, 0); uint32_t carryN = 0; bool validN = false;
-    auto fetch = [&](uint32_t rem) {
-        validN = false; carryN = 0; recN = make_uint2(0, 0);
-        const uint32_t T2 = min(64u, rem);
-        if (lane < T2) {
-            const uint32_t g = rem - 1 - lane;
-            uint32_t rr = 0;                                                  // last walk range whose first sequence index is <= g
+    if (live && !ZS_STOP_AT(3)) {                                      // stopAt 3: timing aid, no chains
+        const uint32_t nFull = nseq >> 4, tail = nseq & 15u;           // whole blocks of 16 steps; the steps behind them belong to the last segment
+        uint32_t Sb = max((nFull + ZS_CHAIN_MAXSEG - 1u) / ZS_CHAIN_MAXSEG, (uint32_t)ZS_CHAIN_MINSEG);   // blocks a segment
+        const uint32_t K = max((nFull + Sb - 1u) / Sb, 1u);            // segments a chain (<= 21)
+        const uint32_t c = (lane >= K ? 1u : 0u) + (lane >= 2u * K ? 1u : 0u), k = lane - c * K;
+        const bool chainLane = lane < 3u * K && !L.ct[min(c, 2u)].rle;
+        const FseCT &ct = L.ct[min(c, 2u)];
+        const uint8_t *codes = chainCodes + (size_t)min(c, 2u) * ZS_CHAIN_CODES;
+        uint16_t *outs = chainOuts + (size_t)min(c, 2u) * ZS_CHAIN_CODES;
+        typedef const __attribute__((address_space(3))) uint16_t *LdsU16;
+        typedef const __attribute__((address_space(3))) uint32_t *LdsU32;
+        // a code's two operands in one word: deltaNbBits < 2^20 (a state added to it stays below), deltaFindState + 1024 in the bits above
+        #pragma unroll
+        for (uint32_t t = 0; t < 3; t++) L.u.chain.op[t][lane] = L.ct[t].deltaNbBits[lane] | ((uint32_t)(L.ct[t].deltaFindState[lane] + 1024) << 20);
+        wave_sync();
+        const uint32_t tabAddr = (uint32_t)(uintptr_t)(LdsU16)ct.stateTable - 2048u, opAddr = (uint32_t)(uintptr_t)(LdsU32)L.u.chain.op[min(c, 2u)];
+        const uint32_t firstOut = k * Sb, bEnd = min(firstOut + Sb, nFull);
+        const bool lastSeg = k + 1u == K;
+        const uint32_t bWarm = firstOut > ZS_CHAIN_WARM / 16u ? firstOut - ZS_CHAIN_WARM / 16u : 0u;
+        // one step: the state's low bits leave (their count from the sum's high half), the rest picks the next state from the symbol's stretch of the table
+        #define CHAIN_STEP(sym, o) { \
+            const uint32_t op_ = *(LdsU32)(uintptr_t)(opAddr + ((sym) << 2)); \
+            const uint32_t nbo_ = __builtin_amdgcn_ubfe(state + op_, 16, 4); \
+            (o) = __builtin_amdgcn_ubfe(state, 0, nbo_) | (nbo_ << 12); \
+            state = *(LdsU16)(uintptr_t)(tabAddr + (((state >> nbo_) + (op_ >> 20)) << 1)); }
+        // the blocks [from, to) with the state carried; outputs stored for blocks >= outFrom; entry: the state in front of block `mark`.
+        // Loads and stores share the wavefront's vmcnt, and the compiler waits vmcnt(0) for a load it sees - behind a round's stores that is their
+        // whole trip to L2, every round.  So the codes of round r + 1 are requested BEFORE round r's two stores, by a load the compiler does not
+        // see, and waited for by count: vmcnt(2) leaves exactly those stores in flight (in-order return: DESIGN section 6).  For the count to
+        // hold every lane stores every round - where it has nothing to store, into a junk slot of the section buffer (written by the packing later).
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        uint8_t *junk = out + 32768u + 32u * lane;
+        auto runBlocks = [&](uint32_t from, uint32_t to, uint32_t outFrom, uint32_t mark, uint32_t &state, uint32_t &entry, uint32_t rounds) {
+            u32x4 cw;
+            {
+                const uint8_t *a0 = codes + 16u * min(from, nFull ? nFull - 1u : 0u);
+                asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(cw) : "v"(a0) : "memory");
+            }
+            for (uint32_t it = 0; it < rounds; it++) {
+                const uint32_t blkI = from + it;
+                const bool act = blkI < to;
+                const u32x4 cur = cw;
+                {
+                    const uint8_t *a1 = codes + 16u * min(blkI + 1u, nFull ? nFull - 1u : 0u);
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(cw) : "v"(a1) : "memory");
+                }
+                if (act && blkI == mark) entry = state;
+                uint32_t o[16] = {};
+                if (act) {
+                    const uint32_t w4[4] = { cur.x, cur.y, cur.z, cur.w };
+                    #pragma unroll
+                    for (uint32_t t = 0; t < 16; t++) { const uint32_t sym = (w4[t >> 2] >> (8u * (t & 3u))) & 0xFFu; CHAIN_STEP(sym, o[t]) }
+                }
+                uint4 *op_ = reinterpret_cast<uint4 *>((act && blkI >= outFrom) ? reinterpret_cast<uint8_t *>(outs + 16u * blkI) : junk);
+                op_[0] = make_uint4(o[0] | (o[1] << 16), o[2] | (o[3] << 16), o[4] | (o[5] << 16), o[6] | (o[7] << 16));
+                op_[1] = make_uint4(o[8] | (o[9] << 16), o[10] | (o[11] << 16), o[12] | (o[13] << 16), o[14] | (o[15] << 16));
+                asm volatile("s_waitcnt vmcnt(2)" : "+v"(cw) :: "memory");
+            }
+        };
+        // the same without outputs (a segment's warm-up: most of a lane's steps): lanes run the LAST `n` of `rounds` rounds, blocks [to - n, to)
+        auto warmBlocks = [&](uint32_t to, uint32_t n, uint32_t &state, uint32_t rounds) {
+            u32x4 cw;
+            {
+                const uint8_t *a0 = codes + 16u * min(to - n, nFull ? nFull - 1u : 0u);
+                asm volatile("global_load_dwordx4 %0, %1, off\n\ts_waitcnt vmcnt(0)" : "=&v"(cw) : "v"(a0) : "memory");
+            }
+            for (uint32_t it = 0; it < rounds; it++) {
+                const bool act = it + n >= rounds;                      // my first round is rounds - n
+                const uint32_t blkI = to - rounds + it;                 // (meaningful where act)
+                const u32x4 cur = cw;
+                {
+                    const uint8_t *a1 = codes + 16u * (act ? min(blkI + 1u, nFull ? nFull - 1u : 0u) : min(to - n, nFull ? nFull - 1u : 0u));
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=&v"(cw) : "v"(a1) : "memory");
+                }
+                if (act) {
+                    const uint32_t w4[4] = { cur.x, cur.y, cur.z, cur.w };
+                    #pragma unroll
+                    for (uint32_t t = 0; t < 16; t++) {
+                        const uint32_t sym = (w4[t >> 2] >> (8u * (t & 3u))) & 0xFFu;
+                        const uint32_t op_ = *(LdsU32)(uintptr_t)(opAddr + (sym << 2));
+                        const uint32_t nbo_ = __builtin_amdgcn_ubfe(state + op_, 16, 4);
+                        state = *(LdsU16)(uintptr_t)(tabAddr + (((state >> nbo_) + (op_ >> 20)) << 1));
+                    }
+                }
+                asm volatile("s_waitcnt vmcnt(0)" : "+v"(cw) :: "memory");
+            }
+        };
+        auto runTail = [&](uint32_t &state) {                           // the steps behind the whole blocks, one by one
+            for (uint32_t t = 0; t < tail; t++) { const uint32_t sym = codes[16u * nFull + t]; uint32_t o; CHAIN_STEP(sym, o) outs[16u * nFull + t] = (uint16_t)o; }
+        };
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");          // pass 1's code bytes (other lanes' stores) are read below
+#ifdef ZS_CHAIN_COUNT
+        if (lane == 0) { metas[blk].pad[0] = 0; metas[blk].pad[1] = K | (Sb << 8) | (nseq << 16); }
+#endif
+        uint32_t state = 0, entry = 0;
+        const bool runs = chainLane && (firstOut < nFull || k == 0);
+        if (runs) {
+            // the first step of a chain takes its state from the symbol alone (ZStdCompress' first-symbol rule; the decoder's final state); as a
+            // step from a made-up state: nbBits = (deltaNbBits + 2^15) >> 16, state = (nbBits << 16) - deltaNbBits
+            const uint32_t sym0 = codes[16u * bWarm];
+            const uint32_t dnb0 = ct.deltaNbBits[sym0], nb0 = (dnb0 + (1u << 15)) >> 16;
+            state = (nb0 << 16) - dnb0;
+        }
+        const uint32_t warmN = runs ? firstOut - bWarm : 0u;            // silent blocks in front of my segment
+        const uint32_t warmRounds = wave_max(warmN), rounds = wave_max(runs ? bEnd - firstOut : 0u);
+        if (warmRounds) warmBlocks(firstOut, warmN, state, warmRounds);
+        entry = state;
+        if (runs) {
+            uint32_t dummy = 0;
+            runBlocks(firstOut, bEnd, firstOut, 0xFFFFFFFFu, state, dummy, rounds);
+            if (lastSeg && tail) runTail(state);
+        }
+        // the seams, in order
+        for (uint32_t kk = 1; kk < K; kk++) {
+            const uint32_t prevExit = ZS_DPP(0, state, 0x138, 0xF, true);           // wave_shr:1: lane c K + kk - 1
+            const bool bad = runs && k == kk && entry != prevExit;
+            if (__any(bad)) {
+#ifdef ZS_CHAIN_COUNT
+                if (lane == 0) metas[blk].pad[0] += (uint32_t)__popcll(__ballot(bad)) | (1u << 16);      // development aid: seams that failed / rounds of repair
+#endif
+                if (bad) {
+                    uint32_t dummy = 0;
+                    state = prevExit;
+                    runBlocks(firstOut, bEnd, firstOut, 0xFFFFFFFFu, state, dummy, bEnd - firstOut);
+                    if (lastSeg && tail) runTail(state);
+                }
+            }
+        }
+        #undef CHAIN_STEP
+        if (chainLane && k == 0) outs[0] = 0;                           // the first step of all writes no bits
+        // final states of the three tables -> misc[4..6] (an RLE table has none)
+        if (lane < 3u * K && k + 1u == K) L.misc[4 + c] = state;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");          // the outputs (other lanes' stores) are read below
+        wave_sync();
+    }
+    if (live && !ZS_STOP_AT(3) && !ZS_STOP_AT(4)) {                     // stopAt 4: timing aid, no packing
+        // per sequence: the three chains' outputs of its step and its extra bits (pass 1), all in encoding order: consecutive lanes, consecutive
+        // addresses.  ZS_SEQ_TB tiles are requested together (clamped, branch-free) and packed one after the other.
+        constexpr uint32_t TB = ZS_SEQ_TB;
+        const bool rle0 = L.ct[0].rle != 0, rle1 = L.ct[1].rle != 0, rle2 = L.ct[2].rle != 0;
+        uint2 prN[TB]; uint32_t sN[TB][3];
+        auto request = [&](uint32_t j0) {
             #pragma unroll
-            for (uint32_t stepb = ZS_WALK_RANGES / 2; stepb >= 1; stepb >>= 1) if (g >= L.rngStart[rr + stepb]) rr += stepb;
-            const uint32_t k = g - L.rngStart[rr];
-            recN = *reinterpret_cast<const uint2 *>(seqBase + (size_t)rr * ZS_SEQ_PER_RANGE + L.rngFirst[rr] + k);
-            carryN = (k == 0) ? L.rngCarry[rr] : 0u;
-            validN = true;
-        }
-    };
-    if (remaining) fetch(remaining);
-    asm volatile("" : "+v"(recN.x), "+v"(recN.y));                     // the first tile's records are waited for here, not inside the loop
-    for (uint32_t i = 0; i < maxT; i++) {
-        const bool mine = (i < nT) && !overflow;
-        uint32_t T = 0, ll = 0, ml = 0, val = 0, llc = 0, mlc = 0, ofc = 0;
-        if (mine) {
-            T = min(64u, remaining);
-            const uint2 raw = recN; const uint32_t carry = carryN; const bool valid = validN;
-            if (remaining > T) fetch(remaining - T);
-            uint2 o0 = make_uint2(0, 0), o1 = o0, o2 = o0;
-            if (valid) {
-                ll = zs_rec_ll(raw.x) + carry;
-                ml = zs_rec_ml(raw.x); const uint32_t rep = zs_rec_rep(raw.x);
-                val = rep ? rep : zs_rec_off(raw.x, raw.y) + 3;
-                llc = llCodeOf(ll); mlc = mlCodeOf(ml - 3); ofc = zs_highbit(val);
-                o0 = make_uint2(L.ct[0].deltaNbBits[llc], (uint32_t)L.ct[0].deltaFindState[llc]);
-                o1 = make_uint2(L.ct[1].deltaNbBits[ofc], (uint32_t)L.ct[1].deltaFindState[ofc]);
-                o2 = make_uint2(L.ct[2].deltaNbBits[mlc], (uint32_t)L.ct[2].deltaFindState[mlc]);
+            for (uint32_t t = 0; t < TB; t++) {
+                const uint32_t j = min(j0 + 64u * t + lane, nseq - 1u);
+                prN[t] = packRec[j];
+                sN[t][0] = chainOuts[j]; sN[t][1] = chainOuts[ZS_CHAIN_CODES + j]; sN[t][2] = chainOuts[2u * ZS_CHAIN_CODES + j];
             }
-            L.u.tile.op[0][lane] = o0; L.u.tile.op[1][lane] = o1; L.u.tile.op[2][lane] = o2;
-            if (lane < 2) { L.u.tile.op[0][64 + lane] = make_uint2(0, 0); L.u.tile.op[1][64 + lane] = make_uint2(0, 0); L.u.tile.op[2][64 + lane] = make_uint2(0, 0); }
-        }
-        if (lane == 0) L.misc[3] = T;                  // 0: no tile of this block in this round
-        __syncthreads();
-        if (wave == 0) {
-            const uint32_t g = min(lane / 3u, (uint32_t)(G - 1)), c = lane - 3u * (lane / 3u);
-            const bool chainLane = lane < 3u * G;
-            SeqLds &B = LS[g];
-            const uint32_t Tg = chainLane ? B.misc[3] : 0u;
-            const uint32_t Tmax = wave_max(Tg);
-            const bool allFull = __ballot(chainLane && Tg != 0u && !B.ct[c].rle && Tg != 64u) == 0ull;   // no moving lane has a part-filled tile
-            if (chainLane && !ZS_STOP_AT(3)) {                    // stopAt 3: timing aid, no chains
-                const FseCT &ct = B.ct[c];
-                const uint2 *op = B.u.tile.op[c];
-                uint32_t *outp = B.u.tile.tileState[c];
-                // One loop without branches for all chain lanes: a lane whose block has no tile this round, whose tile is shorter, or
-                // whose table is RLE (one state, no bits) runs along on zero operands and keeps its state.  The chain is the
-                // critical path of the workgroup -- per step an add, two shifts, an add and the dependent table read -- so
-                // nothing else (branches, exec-mask updates) may sit between two steps.
-                const bool moves = Tg && !ct.rle;
-                const uint32_t Tact = moves ? Tg : 0u;
-                uint32_t t0 = 0;
-                if (i == 0) {                          // first step of the block: the state is chosen from the symbol alone
-                    if (moves) {
-                        const uint32_t dnb = op[0].x;
-                        const uint32_t nbo = (dnb + (1u << 15)) >> 16;
-                        const uint32_t v = (nbo << 16) - dnb;
-                        chainState = ct.stateTable[(v >> nbo) + (int)op[0].y];
-                    }
-                    if (Tg) outp[0] = 0;
-                    t0 = 1;
+        };
+        request(0);
+        for (uint32_t j0 = 0; j0 < nseq && !overflow; j0 += 64u * TB) {
+            uint2 pr[TB]; uint32_t sC[TB][3];
+            #pragma unroll
+            for (uint32_t t = 0; t < TB; t++) { pr[t] = prN[t]; sC[t][0] = sN[t][0]; sC[t][1] = sN[t][1]; sC[t][2] = sN[t][2]; }
+            if (j0 + 64u * TB < nseq) request(j0 + 64u * TB);
+            #pragma unroll
+            for (uint32_t t = 0; t < TB; t++) {
+                const uint32_t jt = j0 + 64u * t;
+                if (jt >= nseq || overflow) break;
+                uint64_t lo = 0; uint32_t hi = 0, nb = 0;
+                if (jt + lane < nseq) {
+                    const uint32_t sLL = rle0 ? 0u : sC[t][0], sOF = rle1 ? 0u : sC[t][1], sML = rle2 ? 0u : sC[t][2];
+                    #define PUTB(v, b) { const uint32_t b_ = (b); if (b_) { const uint64_t v_ = (uint64_t)(v); if (nb < 64) { lo |= v_ << nb; if (nb + b_ > 64) hi |= (uint32_t)(v_ >> (64 - nb)); } else hi |= (uint32_t)(v_ << (nb - 64)); nb += b_; } }
+                    PUTB(sOF & 0xFFFu, sOF >> 12);
+                    PUTB(sML & 0xFFFu, sML >> 12);
+                    PUTB(sLL & 0xFFFu, sLL >> 12);
+                    PUTB((uint64_t)pr[t].x | ((uint64_t)(pr[t].y & 0xFFFFFFu) << 32), pr[t].y >> 24);
+                    #undef PUTB
                 }
-                // its wavefront issues ahead of the others on its SIMD
-                __builtin_amdgcn_s_setprio(3);
-                if (allFull) {
-                    // Every chain lane that moves has a whole tile of 64 (all tiles but a block's last): the lanes that do not move sit out the
-                    // loop as a whole (one exec mask for the tile), so a step needs no select, no per-step mask and no zeroed operands:
-                    // add, shift (the count taken straight from the sum's high half), shift-add onto the step's table address, the read.
-                    if (moves) {
-                        typedef const __attribute__((address_space(3))) uint16_t *LdsU16;
-                        const uint32_t tabAddr = (uint32_t)(uintptr_t)(LdsU16)ct.stateTable;   // LDS byte address of this lane's table
-                        uint2 cur = op[t0];
-                        #define CHAIN_STEP(t) { \
-                            const uint2 nxt = op[(t) + 1];                                 /* operands of step t+1: read before the dependent lookup of step t */ \
-                            uint32_t pre = tabAddr + (cur.y << 1);                         /* off the chain: known a step ahead */ \
-                            asm("" : "+v"(pre));                                           /* (kept apart, so the chain's last op is one shift-add) */ \
-                            const uint32_t nbo = (chainState + cur.x) >> 16; \
-                            const uint32_t ns = *(LdsU16)(uintptr_t)(pre + ((chainState >> nbo) << 1)); \
-                            outp[t] = (chainState & ((1u << nbo) - 1)) | (nbo << 16); \
-                            chainState = ns; cur = nxt; }
-                        uint32_t t = t0;
-                        while (t & 3u) { CHAIN_STEP(t) t++; }
-                        for (; t < 64u; t += 4) { CHAIN_STEP(t) CHAIN_STEP(t + 1) CHAIN_STEP(t + 2) CHAIN_STEP(t + 3) }
-                        #undef CHAIN_STEP
-                    }
-                } else {
-                uint2 cur = moves ? op[t0] : make_uint2(0, 0);
-                #pragma unroll 4
-                for (uint32_t t = t0; t < Tmax; t++) {
-                    uint2 nxt = op[t + 1];                                         // operands of step t+1: read before the dependent lookup of step t
-                    if (!moves) nxt = make_uint2(0, 0);
-                    const uint32_t nbo = (chainState + cur.x) >> 16;
-                    const uint32_t ns = ct.stateTable[(chainState >> nbo) + (int)cur.y];
-                    const uint32_t o = (chainState & ((1u << nbo) - 1)) | (nbo << 16);
-                    if (t < Tg) outp[t] = moves ? o : 0u;
-                    chainState = (t < Tact) ? ns : chainState;
-                    cur = nxt;
-                }
-                }
-                __builtin_amdgcn_s_setprio(0);
+                if (sink.bitpos / 8 + 1024 > bsCap) overflow = true;
+                else sink_put(sink, lo, hi, nb);
             }
-        }
-        __syncthreads();
-        if (mine && !ZS_STOP_AT(4)) {                             // stopAt 4: timing aid, no packing
-            uint64_t lo = 0; uint32_t hi = 0, nb = 0;
-            if (lane < T) {
-                #define PUTB(v, b) { const uint32_t b_ = (b); if (b_) { const uint64_t v_ = (uint64_t)(v); if (nb < 64) { lo |= v_ << nb; if (nb + b_ > 64) hi |= (uint32_t)(v_ >> (64 - nb)); } else hi |= (uint32_t)(v_ << (nb - 64)); nb += b_; } }
-                // (a table in RLE mode has one state and writes no bits: its chain lane may have sat the tile out)
-                const uint32_t sOF = L.ct[1].rle ? 0u : L.u.tile.tileState[1][lane], sML = L.ct[2].rle ? 0u : L.u.tile.tileState[2][lane], sLL = L.ct[0].rle ? 0u : L.u.tile.tileState[0][lane];
-                PUTB(sOF & 0xFFFFu, sOF >> 16);
-                PUTB(sML & 0xFFFFu, sML >> 16);
-                PUTB(sLL & 0xFFFFu, sLL >> 16);
-                { uint32_t xb; const uint32_t xv = llExtraOf(ll, xb); PUTB(xv, xb); }
-                { uint32_t xb; const uint32_t xv = mlExtraOf(ml - 3, xb); PUTB(xv, xb); }
-                PUTB(val - (1u << ofc), ofc);
-                #undef PUTB
-            }
-            if (sink.bitpos / 8 + 1024 > bsCap) overflow = true;
-            else sink_put(sink, lo, hi, nb);
-            remaining -= T;
         }
     }
-    // final states back to their blocks
-    if (wave == 0 && lane < 3u * G) LS[lane / 3u].misc[4 + lane % 3u] = chainState;
-    __syncthreads();
     if (live && !overflow) {
         {
             // final states: ML, OF, LL (ZStdDecompress.cs:1578-1580 reads LL, OF, ML)

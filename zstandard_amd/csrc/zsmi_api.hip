@@ -365,8 +365,8 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         if (c->stopAfterWalk) { chunk0 = chunk1; continue; }
         // sequences first: the literals kernel assembles the frames of one-block chunks as its workgroups finish, and reads the sequence
         // sections then.  (The two side by side on two streams was measured slower: both want the whole LDS.)
-        LAUNCH_ON(c, st, "k_encode_sequences", (k_encode_sequences<ZS_SEQ_GROUP>), dim3((nb + ZS_SEQ_GROUP - 1) / ZS_SEQ_GROUP), dim3(64 * ZS_SEQ_GROUP), 0, dB, nb, (ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
-                  (uint8_t *)L.dSeqSec.p, (ZsBlockMeta *)L.dMetas.p, c->stopSeq);
+        LAUNCH_ON(c, st, "k_encode_sequences", (k_encode_sequences<ZS_SEQ_GROUP>), dim3((nb + ZS_SEQ_GROUP - 1) / ZS_SEQ_GROUP), dim3(64 * ZS_SEQ_GROUP), 0, dB, nb, (const ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
+                  (uint8_t *)L.dSeqSec.p, (ZsBlockMeta *)L.dMetas.p, c->stopSeq, (uint8_t *)L.dLits.p, (uint8_t *)L.dStreams.p, (uint2 *)L.dDist.p);
         LAUNCH_ON(c, st, "k_encode_literals", k_encode_literals, dim3(nb), dim3(256), 0, (const uint8_t *)dSrc, dB, (const ZsSeqRec *)L.dSeqs.p, (const ZsRangeHdr *)L.dHdrs.p,
                   (uint8_t *)L.dLits.p, (uint8_t *)L.dStreams.p, (uint8_t *)L.dLitSec.p, (ZsBlockMeta *)L.dMetas.p, c->stopLit,
                   (const ZsChunkDesc *)c->dChunks.p, (const uint8_t *)L.dSeqSec.p, (uint8_t *)dDst, dDstSizes);
