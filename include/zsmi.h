@@ -128,6 +128,14 @@ typedef struct { char name[48]; double seconds; uint32_t launches; } zsmi_kernel
 int zsmi_enableKernelTiming(zsmi_ctx *ctx, int on);
 int zsmi_getKernelTimes(zsmi_ctx *ctx, zsmi_kernel_time *out, int maxEntries);
 
+/* device scratch the context holds for decoding after the last zsmi_decompressBatch* call (bytes): sized by that call's items in flight and
+ * its largest capacity; a later, smaller call gives most of it back */
+size_t zsmi_decodeScratchBytes(zsmi_ctx *ctx);
+
+/* Releases the per-device contexts the one-shot calls (zsmi_compress / zsmi_decompress*) keep.  For embedders that unload the library: nothing
+ * is released from an exit-time destructor (the HIP runtime may be gone by then); call this before dlclose.  No one-shot call may be running. */
+void zsmi_shutdown(void);
+
 /* library / device description, for logs */
 const char *zsmi_versionString(void);
 

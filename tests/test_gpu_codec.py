@@ -607,15 +607,11 @@ def test_intended_shapes_stay_on_the_decode_fast_path():
     """tools/fastpath_check.py (its own process: the library with the debug hooks): every shape the fast path is meant to take is decoded
     THERE - a silent fall-back to the general kernel decodes correctly, 4 x slower, and no other test would notice."""
     import json, subprocess
-    if not os.path.exists(os.path.join(ROOT, "zstandard_amd", "lib", "libzsmi_debug.so")):
-        pytest.skip("the debug-hook build of the library is not here (__graft_entry__.build() makes it)")
+    # (the tool builds the debug-hook library itself when it is missing or stale: on a GPU run this test never skips)
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fastpath_check.py")], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert len(res) >= 5, res
     for label, (fast, n) in res.items():
         assert fast >= 0, (label, "wrong output")
-        if "general kernel" in label:
-            assert fast == 0, (label, fast, n)
-        else:
-            assert fast == n, (label, fast, n)
+        assert fast == n, (label, fast, n)

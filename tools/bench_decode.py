@@ -63,6 +63,6 @@ cdt = time.perf_counter() - t1
 assert (dst == host[:m * cs]).all()
 secs = sum(v[0] for v in kt.values()); launches = kt["k_decode_frames"][1]
 print({k: round(v[0] / a.steps * 1e3, 3) for k, v in kt.items()}, file=sys.stderr)
-print(json.dumps({"metric": "GiB/s decompress (output bytes), frames of %d B" % cs, "value": round(n * cs * a.steps / dt / 2**30, 3), "frames": n, "ms_per_step": round(dt / a.steps * 1e3, 3),
+print(json.dumps({"metric": "GiB/s decompress (output bytes), frames of %d B" % cs, "value": round(n * cs * a.steps / dt / 2**30, 3), "frames": n, "ms_per_step": round(dt / a.steps * 1e3, 3), "decode_scratch_bytes": int(bc.L.zsmi_decodeScratchBytes(bc.ctx)),
                   "roofline": {"bound": "hbm", "kernel": "decode kernels together", "achieved": round((n * cs + comp) * a.steps / secs / 1e9, 2), "peak": 8000.0, "unit": "GB/s"},
                   "cpu_baseline": {"value": round(m * cs / cdt / 2**30, 3), "unit": "GiB/s", "cores": cores, "kind": "port", "sample": "%d frames, oracle D (restated reference decoder)" % m}}))

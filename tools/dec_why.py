@@ -11,7 +11,8 @@ from zstandard_amd import BatchCodec, _lib
 cs, n = 65536, 4096
 bc = BatchCodec(0, torch.cuda.current_stream().cuda_stream); Z = _lib.lib()
 classes = dict(C.corpus(1 << 20))
-DESC_WORDS = 34                                          # sizeof(ZsFastDesc) / 4 (decode_fast.hip)
+_lay = (ctypes.c_uint32 * 6)(); Z.zsmi_dbg_descLayout(_lay)
+DESC_WORDS, FAST_AT, WHY_AT, NBSEQ_AT, LITTYPE_AT, HUFLOG_AT = (int(x) for x in _lay)     # the library's own layout of a ZsFastDesc
 WHY = {0: "-", 1: "Huffman stream did not end exactly", 2: "sequence stream exhausted", 3: "offset code > 28", 4: "a sequence failed pass A's checks", 5: "last literals do not fit", 6: "content size differs", 7: "execute (other)"}
 for name in (sys.argv[1:] or list(classes)):
     one = np.frombuffer(classes[name], dtype=np.uint8)
@@ -28,7 +29,7 @@ for name in (sys.argv[1:] or list(classes)):
     buf = np.zeros(n * DESC_WORDS, dtype=np.uint32)
     rc = Z.zsmi_dbg_copyScratch(bc.ctx, 10, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes)); assert rc == 0, rc
     d = buf.reshape(n, DESC_WORDS)
-    fast, why = d[:, 0], d[:, DESC_WORDS - 1]
+    fast, why = d[:, FAST_AT], d[:, WHY_AT]
     left = np.nonzero(fast == 0)[0]
     hist = {WHY.get(int(k), int(k)): int(v) for k, v in zip(*np.unique(why[left], return_counts=True))} if len(left) else {}
-    print(f"{name:12s} frames {n}  left the fast path: {len(left)}  {hist}  first: {left[:4].tolist()}  nbSeq of those: {d[left[:4], 22].tolist()} litType {d[left[:4], 1].tolist()} hufLog {d[left[:4], 4].tolist()}")
+    print(f"{name:12s} frames {n}  left the fast path: {len(left)}  {hist}  first: {left[:4].tolist()}  nbSeq of those: {d[left[:4], NBSEQ_AT].tolist()} litType {d[left[:4], LITTYPE_AT].tolist()} hufLog {d[left[:4], HUFLOG_AT].tolist()}")

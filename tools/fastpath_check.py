@@ -11,13 +11,22 @@ import numpy as np
 import _data as D, _oracle as O, _corpus as C
 from zstandard_amd import BatchCodec, _lib
 
-DESC_WORDS = 34                                          # sizeof(ZsFastDesc) / 4 (decode_fast.hip)
+
+def desc_layout(Z):
+    """words of a ZsFastDesc and the word index of `fast`: asked of the library itself (zsmi_dbg_descLayout), so a field added to the descriptor
+    cannot make this check read the wrong word"""
+    lay = (ctypes.c_uint32 * 6)()
+    Z.zsmi_dbg_descLayout(lay)
+    return int(lay[0]), int(lay[1])
+
 
 
 def main():
     if _lib.built_fingerprint() != _lib.source_fingerprint():
         _lib.build()                                      # (a stale debug build would check yesterday's kernels)
     bc = BatchCodec(0); Z = _lib.lib()
+    DESC_WORDS, FAST_AT = desc_layout(Z)
+    assert 8 <= DESC_WORDS <= 256 and FAST_AT < DESC_WORDS
     rng = np.random.default_rng(5)
     text = D.zipf_log(6 << 20, seed_lo=41).tobytes()
     noise = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
@@ -39,13 +48,15 @@ def main():
         n = len(chunks)
         buf = np.zeros(n * DESC_WORDS, dtype=np.uint32)
         rc = Z.zsmi_dbg_copyScratch(bc.ctx, 10, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(buf.nbytes)); assert rc == 0, rc
-        res[label] = [int((buf.reshape(-1, DESC_WORDS)[:n, 0] == 1).sum()) if ok else -1, n]
+        res[label] = [int((buf.reshape(-1, DESC_WORDS)[:n, FAST_AT] == 1).sum()) if ok else -1, n]
 
     run("own 32 KiB", [text[i * 32768:(i + 1) * 32768] for i in range(64)])
     run("own 128 KiB", [text[i * 40000:i * 40000 + 131072] for i in range(32)])
     run("own 1 MiB", [text[i * 70000:i * 70000 + (1 << 20)] for i in range(16)])
     run("own, raw and RLE blocks among compressed ones", [text[i * 50000:i * 50000 + 200000] + noise[i * 1000:i * 1000 + 70000] + bytes(70000) + text[:100000] for i in range(16)])
-    run("own, raw blocks only (stays with the general kernel)", [noise[i * 100:i * 100 + 65536] for i in range(16)])
+    run("own, raw blocks only", [noise[i * 100:i * 100 + 65536] for i in range(16)])
+    run("own, RLE blocks only: 1 MiB of zeros (BASELINE config 1)", [bytes(1 << 20)])
+    run("own, raw blocks only, 300 KB", [noise[i * 100:i * 100 + 300000] for i in range(8)])
     if elf is not None:
         run("own, ELF class (wide alphabets: flat Huffman table)", [elf[i * 65536:(i + 1) * 65536] for i in range(16)])
     if O.libzstd():

@@ -10,17 +10,27 @@ LIB_PATH = os.environ.get("ZSMI_LIB_FILE") or os.path.join(_HERE, "lib", "libzsm
 CSRC = os.path.join(_HERE, "csrc")
 
 
+def extra_flags():
+    """compile flags beyond the fixed ones: kernel-shape experiments (ZSMI_HIPCC_FLAGS) and the debug-hook switch - part of the fingerprint, so
+    that a variant build is never taken for the tree's product library"""
+    return os.environ.get("ZSMI_HIPCC_FLAGS", "").split() + (["-DZSMI_DEBUG_HOOKS"] if DEBUG else [])
+
+
 def source_fingerprint():
-    """sha256 over the kernel sources (comments and white space do not count): the library carries the one it was built from
-    (zsmi_versionString), profiles/*_traffic.json the one it was measured at"""
+    """sha256 over the kernel sources (*.hip, *.h; comments and white space do not count) and the extra compile flags: the library carries
+    the one it was built from (zsmi_versionString), profiles/*_traffic.json the one it was measured at"""
     import hashlib, re
     h = hashlib.sha256()
-    for f in sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "zsmi.h")]:
+    names = sorted(f for f in os.listdir(CSRC) if f.endswith((".hip", ".h")) and os.path.isfile(os.path.join(CSRC, f)))
+    for f in names + [os.path.join("..", "..", "include", "zsmi.h")]:
         text = open(os.path.join(CSRC, f), "r", errors="replace").read()
         text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
         text = re.sub(r"//[^\n]*", "", text)
         text = re.sub(r"\s+", "", text)
         h.update(f.encode()); h.update(text.encode())
+    flags = extra_flags()
+    if flags:
+        h.update(" ".join(flags).encode())
     return h.hexdigest()[:16]
 
 
@@ -46,9 +56,7 @@ def build(force=False):
     os.makedirs(os.path.dirname(LIB_PATH), exist_ok=True)
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-shared", "-fPIC", '-DZSMI_SOURCE_FP="%s"' % fp, "-o", LIB_PATH, os.path.join(CSRC, "zsmi_api.hip")]
-    cmd += os.environ.get("ZSMI_HIPCC_FLAGS", "").split()          # kernel-shape experiments (-DZS_CAND_G=4 ...)
-    if DEBUG:
-        cmd.append("-DZSMI_DEBUG_HOOKS")
+    cmd += extra_flags()                                           # kernel-shape experiments (-DZS_CAND_G=4 ...), the debug hooks
     subprocess.check_call(cmd)
     return LIB_PATH
 
@@ -89,6 +97,8 @@ def lib():
     L.zsmi_packFramesDevice.restype = i32; L.zsmi_packFramesDevice.argtypes = [vp, vp, vp, vp, u32, vp, vp]
     L.zsmi_enableKernelTiming.restype = i32; L.zsmi_enableKernelTiming.argtypes = [vp, i32]
     L.zsmi_getKernelTimes.restype = i32; L.zsmi_getKernelTimes.argtypes = [vp, ctypes.POINTER(KernelTime), i32]
+    L.zsmi_decodeScratchBytes.restype = sz; L.zsmi_decodeScratchBytes.argtypes = [vp]
+    L.zsmi_shutdown.restype = None; L.zsmi_shutdown.argtypes = []
     if DEBUG or hasattr(L, "zsmi_dbg_copyScratch"):            # (a variant build named by ZSMI_LIB_FILE may carry the hooks too)
         L.zsmi_dbg_copyScratch.restype = i32; L.zsmi_dbg_copyScratch.argtypes = [vp, i32, vp, sz]
     _lib = L
@@ -99,4 +109,4 @@ EXPORTS = ["zsmi_isError", "zsmi_getErrorName", "zsmi_getErrorCode", "zsmi_decom
            "zsmi_compress", "zsmi_compressBound", "zsmi_createCtx", "zsmi_freeCtx", "zsmi_sync",
            "zsmi_compressBatchDevice", "zsmi_decompressBatchDevice", "zsmi_compressBatchHost", "zsmi_decompressBatchHost",
            "zsmi_decompress_usingDict", "zsmi_decompressBatchDevice_usingDict", "zsmi_decompressBatchHost_usingDict",
-           "zsmi_packFramesDevice", "zsmi_enableKernelTiming", "zsmi_getKernelTimes", "zsmi_versionString"]
+           "zsmi_packFramesDevice", "zsmi_enableKernelTiming", "zsmi_getKernelTimes", "zsmi_versionString", "zsmi_decodeScratchBytes", "zsmi_shutdown"]

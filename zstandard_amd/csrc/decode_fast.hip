@@ -80,8 +80,11 @@ __device__ __forceinline__ uint32_t zs_mlExtraBits(uint32_t s) { return s < 32 ?
 template <int F>
 __global__ void __launch_bounds__(64 * F, ZS_PREP_MINWG)
 k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems,
-           ZsFastDesc *__restrict__ descs, uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ seqTabs, uint32_t cap, uint32_t maxBlocks, uint32_t *__restrict__ seqLists)
+           ZsFastDesc *__restrict__ descs, uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ seqTabs, uint32_t cap, uint32_t maxBlocks, uint32_t *__restrict__ seqLists,
+           uint32_t litCap, uint32_t seqCap)
 {
+    // (litCap, seqCap: literal bytes / sequences a block slot of this call holds - sized by the call's largest capacity, zsmi_api.hip; a block that
+    //  wants more cannot fit its item's capacity and is left to the general kernel, which says why)
     // (maxBlocks: block slots the call reserved per item, 1, 2 or up to ZS_FAST_MAXBLOCKS - frames of more compressed blocks are left to the general kernel;
     //  descriptors always have both)
     // the general decoder's LDS image without its Huffman table and with one sequence table instead of three (4.4 of 15.5 KiB)
@@ -145,7 +148,7 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                 // a raw or RLE block among the compressed ones (:2043-2056): to the kernels behind this one a block of nothing but literals - raw
                 // literals at the block's bytes, or RLE literals of its byte - and no sequences; the entropy tables a later block may repeat stay
                 const uint32_t csz = btype == 1 ? 1u : cSize;
-                if (cSize > (1u << 17)) break;
+                if (cSize > (1u << 17) || (btype == 1 && cSize > litCap)) break;       // (an RLE block is spread through the slot's literal buffer)
                 if ((uint64_t)b0 + 3 + csz + tail > srcSize) break;
                 if (lastBlock && (uint64_t)b0 + 3 + csz + tail != srcSize) break;
                 if (!lastBlock && blk + 1 == maxBlocks) break;
@@ -177,7 +180,7 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                     if (lhl < 2) { single = !lhl; lhSize = 3; litSize = (lhc >> 4) & 0x3FF; litCSize = (lhc >> 14) & 0x3FF; }
                     else if (lhl == 2) { lhSize = 4; litSize = (lhc >> 4) & 0x3FFF; litCSize = lhc >> 18; }
                     else { lhSize = 5; litSize = (lhc >> 4) & 0x3FFFF; litCSize = (lhc >> 22) + ((uint32_t)bs[4] << 10); }
-                    if (litSize > (1u << 17) || litCSize + lhSize > cSize) break;
+                    if (litSize > litCap || litCSize + lhSize > cSize) break;
                     if (!single && (litSize == 0 || litCSize == 0)) break;
                     uint16_t *ht = reinterpret_cast<uint16_t *>(hufTabs + slot * ZS_FAST_HUFTAB_BYTES);
                     uint32_t h = 0;
@@ -226,7 +229,7 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                     else if (lhl == 3) { lhSize = 3; litSize = rd24(bs) >> 4; }
                     else { lhSize = 1; litSize = bs[0] >> 3; }
                     if (type == 0) { if (litSize + lhSize > cSize) break; DSET(litType, 0u); DSET(litSrc, b0 + lhSize); litCSizeTot = lhSize + litSize; }
-                    else { if (lhSize + 1 > cSize || litSize > (1u << 17)) break; DSET(litType, 1u); DSET(litSrc, (uint32_t)bs[lhSize]); litCSizeTot = lhSize + 1; }
+                    else { if (lhSize + 1 > cSize || litSize > litCap) break; DSET(litType, 1u); DSET(litSrc, (uint32_t)bs[lhSize]); litCSizeTot = lhSize + 1; }
                     DSET(litSize, litSize); DSET(nStreams, 0u);
                 }
             }
@@ -239,7 +242,7 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
             uint16_t *stab = reinterpret_cast<uint16_t *>(seqTabs + slot * ZS_FAST_SEQTAB_BYTES);
             const uint16_t *stabPrev = seqPrev ? reinterpret_cast<const uint16_t *>(seqTabs + ((size_t)(seqPrev - 1u) * cap + item) * ZS_FAST_SEQTAB_BYTES) : nullptr;
             if (seqHeadersT<true>(L, st, ip, remaining, nbSeq, stab, &L.misc[8], stabPrev)) break;      // (misc[8..10]: a repeated table keeps the log it had)
-            if (nbSeq > ZS_FAST_MAXSEQ) break;
+            if (nbSeq > seqCap) break;
             if (nbSeq == 0 && remaining != 0) break;
             DSET(nbSeq, nbSeq); DSET(seqOff, (uint32_t)(ip - src)); DSET(seqSize, remaining);
             DSET(llLog, nbSeq ? L.misc[8] : 0u); DSET(ofLog, nbSeq ? L.misc[9] : 0u); DSET(mlLog, nbSeq ? L.misc[10] : 0u);
@@ -259,7 +262,7 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
             if (lastBlock) break;
         }
         wave_sync();
-        ok = !fail && L.misc[14] < nBlocks;                             // (a frame of raw / RLE blocks only is a plain copy: the general kernel's)
+        ok = !fail;                                                     // (round 4: also a frame of raw / RLE blocks only - BASELINE config 1's 1 MiB of zeros is 16 RLE blocks - : a lane-parallel copy / fill in k_dec_execute instead of a wavefront an item in the general kernel)
     } while (0);
 #ifdef ZS_PREP_PROFILE
     if (lane == 0 && !descs[item].hufFlat) {          // phases 0-11, then the wavefront's whole time: behind the item's Huffman table (the two-level table ends at 1280 bytes; a flat one fills the slot)
@@ -345,7 +348,7 @@ struct HufLds { uint16_t huf[G][FLAT ? (1u << ZS_FAST_HUFLOG) : ZS_HUF2_ENTRIES]
 template <bool FLAT, uint32_t G>
 __global__ void __launch_bounds__(64)
 k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-              const uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ litScratchAll, uint32_t nBlk, uint32_t cap)
+              const uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ litScratchAll, uint32_t nBlk, uint32_t cap, uint32_t litStride)
 {
     __shared__ __attribute__((aligned(16))) HufLds<FLAT, G> H;
     const uint32_t lane = (uint32_t)zs_lane();
@@ -364,7 +367,7 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
         if (descs[item].fast && d->fast && d->litType == 2 && k < d->nStreams && (d->hufFlat != 0) == FLAT) {
             mine = true; dtLog = d->hufLog; n = d->sCnt[k]; size = d->sLen[k];
             src = srcAll + items[item].srcOff + d->sOff[k];
-            out = litScratchAll + (slot0 + item) * ((1u << 17) + 64) + d->sOut[k];
+            out = litScratchAll + (slot0 + item) * litStride + d->sOut[k];
         }
     }
     if (!__ballot(mine)) return;
@@ -466,7 +469,7 @@ struct SeqDecLds { uint16_t cells[G][(LOG9 ? 1280 : 768)]; uint32_t win[G][(ZS_F
 template <bool LOG9, uint32_t G>
 __global__ void __launch_bounds__(64)
 k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-                  const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t nBlk, uint32_t cap, const uint32_t *__restrict__ seqLists)
+                  const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t nBlk, uint32_t cap, const uint32_t *__restrict__ seqLists, uint32_t seqCap)
 {
     // the blocks of this table class, listed by k_dec_prep (every block index of the call in one launch: blocks decode independently)
     const uint32_t listed = seqLists[LOG9 ? 1 : 0];
@@ -513,7 +516,7 @@ k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
     const uint32_t gi = min(g, G - 1u);
     uint32_t *winW = S.win[gi];
     const uint32_t *win = winW;
-    ZsFastSeq *outp = seqOutAll + (size_t)slot * ZS_FAST_MAXSEQ;
+    ZsFastSeq *outp = seqOutAll + (size_t)slot * seqCap;
     // what a lane's role fixes: its table, the constants of its code's extra-bit count (see k_dec_sequences; an offset code IS its count),
     // where its state bits sit below the other states' (LL on top, then ML, then OF, :1547-1550)
     const uint16_t *cellsB = S.cells[gi] + (r == 1 ? MLB : (r == 2 ? OFB : 0u)) - 512;
@@ -731,7 +734,8 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
 template <int F, int MW>
 __global__ void __launch_bounds__(64 * F, MW)
 k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-              ZsFastSeq *seqAll, uint8_t *__restrict__ litScratchAll, uint8_t *dstAll, uint32_t *__restrict__ dstSizes, uint32_t cap, uint32_t slots)
+              ZsFastSeq *seqAll, uint8_t *__restrict__ litScratchAll, uint8_t *dstAll, uint32_t *__restrict__ dstSizes, uint32_t cap, uint32_t slots,
+              uint32_t litStride, uint32_t seqCap)
 {
     __shared__ uint32_t tiles[F][3][64];
     __shared__ uint32_t codeTabs[36 + 53];                                      // base | extra bits << 24 of the LL / ML codes
@@ -765,11 +769,11 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     if (blk && !dp->fast) break;                                                // a one-block frame
     struct { uint32_t litType, litSize, litSrc, nbSeq, seqOff; } d;            // what this kernel needs of the block's descriptor (scalars)
     d.litType = dp->litType; d.litSize = dp->litSize; d.litSrc = dp->litSrc; d.nbSeq = dp->nbSeq; d.seqOff = dp->seqOff;
-    uint8_t *litBuf = litScratchAll + slot * ((1u << 17) + 64);
+    uint8_t *litBuf = litScratchAll + slot * litStride;
     const uint8_t *litPtr = litBuf;
     if (d.litType == 0) litPtr = srcAll + it.srcOff + d.litSrc;
     else if (d.litType == 1) { for (uint32_t j = lane; j < d.litSize; j += 64) litBuf[j] = (uint8_t)d.litSrc; wave_mem_sync(); }
-    ZsFastSeq *seqs = seqAll + slot * ZS_FAST_MAXSEQ;                           // (pass A writes each sequence back in place)
+    ZsFastSeq *seqs = seqAll + slot * seqCap;                           // (pass A writes each sequence back in place)
     const uint8_t *bits = srcAll + it.srcOff + d.seqOff;                        // the sequence bitstream, d.seqSize bytes
     // the 64 stream bits below bit position p, top aligned (bit p - 1 at bit 63); bits below the stream start read as 0
     auto bitsBelow = [&](int32_t p) -> uint64_t {

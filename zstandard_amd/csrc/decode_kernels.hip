@@ -1171,25 +1171,15 @@ __device__ __forceinline__ uint32_t decodeBlock(DLds &L, DState &st, uint8_t *ds
 // DICT: every frame of every item is decoded with the dictionary dict[0 .. dictBytes) (ZSTD_decompress_usingDict :2162): raw
 // content, or a formatted dictionary (magic 0xEC30A437) whose entropy tables and recent offsets are loaded in front of each frame
 // (ZSTD_decompressBegin_usingDict :2501, LoadEntropy :2378-2450) -- by every wavefront for itself: a dictionary is a few KiB.
-template <int F, bool DICT>
-__global__ void __launch_bounds__(64 * F)
-k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, uint8_t *dstAll,
-                uint32_t *__restrict__ dstSizes, uint8_t *__restrict__ litScratchAll, const uint32_t *__restrict__ doneFlags, uint32_t flagStride,
-                const uint8_t *__restrict__ dict, uint32_t dictBytes)
+#define ZS_DEC_LITBUF ((1u << 17) + 64u)                 // a wavefront's literal buffer: the largest block + slack
+template <bool DICT>
+__device__ __forceinline__ void zs_decode_item(DLds &L, const uint32_t item, const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint8_t *dstAll,
+                                               uint32_t *__restrict__ dstSizes, uint8_t *litBuf, const uint8_t *__restrict__ dict, uint32_t dictBytes)
 {
-    __shared__ DLds LS[F];
-    const uint32_t item = blockIdx.x * F + (threadIdx.x >> 6);
-    if (item >= nItems) return;
-    if (doneFlags && doneFlags[(size_t)item * flagStride]) return;        // the fast path (decode_fast.hip) has decoded this item
-    DLds &L = LS[threadIdx.x >> 6];
     const ZsDecItem it = items[item];
     const uint32_t lane = (uint32_t)zs_lane();
     const uint8_t *src = srcAll + it.srcOff;
     uint8_t *dstBase = dstAll + it.dstOff;
-    uint8_t *litBuf = litScratchAll + (size_t)item * ((1u << 17) + 64);
-    if (lane < 36) L.llTab[lane] = d_LL_base[lane] | ((uint32_t)d_LL_bits[lane] << 24);
-    if (lane < 53) L.mlTab[lane] = d_ML_base[lane] | ((uint32_t)d_ML_bits[lane] << 24);
-    wave_sync();
     uint64_t *g_prof = nullptr;
 #ifdef ZS_DEC_PROFILE
     if (lane == 0) { g_prof = reinterpret_cast<uint64_t *>(litBuf + (1u << 17)); for (int k = 0; k < 8; k++) g_prof[k] = 0; }
@@ -1312,4 +1302,45 @@ finish:
 #endif
     if (lane == 0) dstSizes[item] = result;
     #undef DONE
+}
+
+// The kernel: a POOL of wavefronts, each with its own literal buffer, takes the items one after the other from a queue (a counter in global
+// memory, zeroed before the launch): what the buffers cost is set by the wavefronts the chip holds, not by the items of a call (round 3 reserved
+// 128 KiB per ITEM: 7 GiB for 57344 frames of 32 KiB that the fast path had already decoded), and wavefronts that finish early take more.
+// After the fast path the queue runs over the LIST of the items it left (k_dec_collect), so an atomic is spent per item to decode, not per item of the call.
+__global__ void __launch_bounds__(256)
+k_dec_collect(const uint32_t *__restrict__ doneFlags, uint32_t flagStride, uint32_t nItems, uint32_t *__restrict__ list, uint32_t *__restrict__ listCount)
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, lane = threadIdx.x & 63u;
+    const bool todo = i < nItems && doneFlags[(size_t)i * flagStride] == 0;
+    const uint64_t m = __ballot(todo);
+    if (!m) return;
+    uint32_t base = 0;
+    if (lane == (uint32_t)__builtin_ctzll(m)) base = atomicAdd(listCount, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, __builtin_ctzll(m));
+    if (todo) list[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+template <int F, bool DICT>
+__global__ void __launch_bounds__(64 * F)
+k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, uint8_t *dstAll,
+                uint32_t *__restrict__ dstSizes, uint8_t *__restrict__ litScratchAll, const uint32_t *__restrict__ list, const uint32_t *__restrict__ listCount,
+                const uint8_t *__restrict__ dict, uint32_t dictBytes, uint32_t *__restrict__ queue)
+{
+    __shared__ DLds LS[F];
+    DLds &L = LS[threadIdx.x >> 6];
+    const uint32_t lane = (uint32_t)zs_lane();
+    uint8_t *litBuf = litScratchAll + (size_t)(blockIdx.x * F + (threadIdx.x >> 6)) * ZS_DEC_LITBUF;
+    if (lane < 36) L.llTab[lane] = d_LL_base[lane] | ((uint32_t)d_LL_bits[lane] << 24);
+    if (lane < 53) L.mlTab[lane] = d_ML_base[lane] | ((uint32_t)d_ML_bits[lane] << 24);
+    wave_sync();
+    const uint32_t total = list ? *listCount : nItems;                          // (list == nullptr: every item of the call)
+    for (;;) {
+        uint32_t at = 0;
+        if (lane == 0) at = atomicAdd(queue, 1u);
+        at = (uint32_t)__builtin_amdgcn_readfirstlane((int)at);
+        if (at >= total) break;                                                 // (every wavefront gets here: the queue only grows)
+        const uint32_t item = list ? list[at] : at;
+        zs_decode_item<DICT>(L, item, srcAll, items, dstAll, dstSizes, litBuf, dict, dictBytes);
+        wave_mem_sync();                                                        // the buffer and the LDS image are the next item's
+    }
 }

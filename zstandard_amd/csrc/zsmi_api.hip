@@ -143,7 +143,10 @@ struct zsmi_ctx {
     uint32_t maxItemsInFlight = 65536;   // ZSMI_ITEMS_IN_FLIGHT: items per decode launch (scratch: ~263 KiB per item and block slot, one slot unless an item can hold two 64 KiB blocks; cut down to half the free device memory).
                                          // Every decode kernel is a long dependent chain per item: a launch is one to three rounds of workgroups and its
                                          // last round is mostly tail, so big launches pay (16384 frames of 32 KiB: 82 GiB/s, 57344: 104 GiB/s)
-    PinBuf hItems;
+    PinBuf hItems2[2]; hipEvent_t hItemsEv[2] = { nullptr, nullptr }; bool hItemsBusy[2] = { false, false }; uint32_t decodeCalls = 0;    // the decode item list: two pinned buffers taken in turn
+    DevBuf dPoolLit;                         // the general decode kernel's literal buffers: one per wavefront of its pool
+    uint32_t decodePool = 3072;              // wavefronts of that pool (ZSMI_DEC_POOL): the chip holds 10 a CU x 256
+    size_t lastDecodeScratch = 0;            // bytes of scratch the last decode call needed (INTEGRATION.md states them)
     // staging for host-buffer calls
     DevBuf sSrc, sDst, sSizes, sDict, sPack, sPackOff;
     PinBuf hPack;
@@ -196,6 +199,7 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     }
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_DEC_FAST")) c->decodeFast = atoi(e) != 0;
+    if (const char *e = getenv("ZSMI_DEC_POOL")) { long v = atol(e); if (v >= 2 && v <= (1 << 20)) c->decodePool = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_ITEMS_IN_FLIGHT")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->maxItemsInFlight = (uint32_t)v; }
 #ifdef ZSMI_DEBUG_HOOKS
     if (const char *e = getenv("ZSMI_STOP_LIT")) c->stopLit = atoi(e);
@@ -215,7 +219,7 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
 {
     if (!c) return;
     (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dUnits, &c->dItems, &c->dLitScratch, &c->dFastDesc, &c->dHufTabs, &c->dSeqTabs, &c->dSeqOut, &c->dSeqLists, &c->sSrc, &c->sDst, &c->sSizes, &c->sDict, &c->sPack, &c->sPackOff }) b->release();
+    for (DevBuf *b : { &c->dBlocks, &c->dChunks, &c->dUnits, &c->dItems, &c->dPoolLit, &c->dLitScratch, &c->dFastDesc, &c->dHufTabs, &c->dSeqTabs, &c->dSeqOut, &c->dSeqLists, &c->sSrc, &c->sDst, &c->sSizes, &c->sDict, &c->sPack, &c->sPackOff }) b->release();
     for (int i = 0; i < zsmi_ctx::kMaxLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
         if (L.stream) (void)hipStreamSynchronize(L.stream);
@@ -224,7 +228,8 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
     if (c->evStart) (void)hipEventDestroy(c->evStart);
-    for (PinBuf *b : { &c->hBlocks, &c->hChunks, &c->hUnits, &c->hItems, &c->hPack }) b->release();
+    for (int i = 0; i < 2; i++) if (c->hItemsEv[i]) (void)hipEventDestroy(c->hItemsEv[i]);
+    for (PinBuf *b : { &c->hBlocks, &c->hChunks, &c->hUnits, &c->hItems2[0], &c->hItems2[1], &c->hPack }) b->release();
     for (auto &tl : c->launches) { (void)hipEventDestroy(tl.a); (void)hipEventDestroy(tl.b); }
     for (auto e : c->eventPool) (void)hipEventDestroy(e);
     if (c->ownStream) (void)hipStreamDestroy(c->stream);
@@ -392,43 +397,72 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
     if (!c) return ZSMI_error_init_missing;
     if (n == 0) return 0;
     if (hipSetDevice(c->device) != hipSuccess) return ZSMI_error_GENERIC;
-    if (!c->hItems.reserve(sizeof(ZsDecItem) * n) || !c->dItems.reserve(sizeof(ZsDecItem) * n)) return ZSMI_error_memory_allocation;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return ZSMI_error_GENERIC;
-    ZsDecItem *hi = (ZsDecItem *)c->hItems.p;
+    // the item list travels through one of two pinned buffers: a call waits only for the copy that last read the buffer it is about to fill
+    // (two calls back), not for the device to finish the call before it (round 3 began every call with hipStreamSynchronize)
+    const int hb = (int)(c->decodeCalls++ & 1u);
+    PinBuf &hItems = c->hItems2[hb];
+    if (c->hItemsBusy[hb]) { if (hipEventSynchronize(c->hItemsEv[hb]) != hipSuccess) return ZSMI_error_GENERIC; c->hItemsBusy[hb] = false; }
+    if (!hItems.reserve(sizeof(ZsDecItem) * n) || !c->dItems.reserve(sizeof(ZsDecItem) * n)) return ZSMI_error_memory_allocation;
+    ZsDecItem *hi = (ZsDecItem *)hItems.p;
     for (uint32_t i = 0; i < n; i++) { hi[i].srcOff = srcOffsets[i]; hi[i].dstOff = dstOffsets[i]; hi[i].srcSize = srcSizes[i]; hi[i].dstCap = dstCaps[i]; }
     if (hipMemcpyAsync(c->dItems.p, hi, sizeof(ZsDecItem) * n, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    if (!c->hItemsEv[hb] && hipEventCreateWithFlags(&c->hItemsEv[hb], hipEventDisableTiming) != hipSuccess) return ZSMI_error_GENERIC;
+    if (hipEventRecord(c->hItemsEv[hb], c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+    c->hItemsBusy[hb] = true;
     const bool useDict = dDict != nullptr && dictSize != 0;
     const bool fast = c->decodeFast && !useDict;                  // frames that name a dictionary go to the general kernel
-    // The fast path keeps its per-block scratch in slot = block index * cap + item.  The second slot (the second block of two-block
-    // frames: this codec's frames of 64 KiB < content <= 128 KiB) is reserved only when some item can hold more than one 64 KiB block;
-    // an item that has two smaller blocks then goes to the general kernel.  Scratch per item in flight: the general kernel's literal
-    // buffer 128 KiB; fast path: + Huffman and sequence tables + 16384 sequences of 8 bytes = ~263 KiB per slot.  The items in flight are
-    // cut down where that would take more than half of the device memory that is free (a shared or smaller device).
-    // (round 3) More slots - up to ZS_FAST_MAXBLOCKS, frames of up to 1 MiB - are reserved when at least a quarter of the call's items can hold
-    // more than two blocks (a call of large frames); a few large frames among many small ones go to the general kernel as before, so the small
-    // ones do not pay for slots and launches they do not use.
-    uint32_t maxBlocks = 1, bigItems = 0, needBlocks = 1;
+    // Scratch.  The general kernel's wavefronts form a POOL with a literal buffer each (ZS_DEC_LITBUF = 128 KiB + 64; as many as the chip holds at once),
+    // whatever the call's size.  The fast path keeps per-block scratch in slot = block index * cap + item, sized by the CALL'S LARGEST CAPACITY:
+    //   literal bytes a slot:  min(capacity, 128 KiB) + 64        (a block regenerates no more than its item may hold)
+    //   sequences a slot:      min(capacity, 128 KiB) / 3 + 64    (a sequence copies >= 3 bytes), 8 bytes each
+    //   + Huffman table 4 KiB + sequence tables 2.5 KiB + a descriptor                     -> 32 KiB items: ~125 KiB an item (round 3: 263 KiB whatever the capacity)
+    // A block that wants more than its slot holds cannot fit its item's capacity: k_dec_prep leaves it to the general kernel, which reports it.
+    // Block slots per item: 1; 2 when some item can hold more than one 64 KiB block; up to ZS_FAST_MAXBLOCKS when at least a quarter of the
+    // call's items can hold more than two (a call of large frames; a few large frames among many small ones go to the general kernel, so the
+    // small ones do not pay for slots and launches they do not use).  If the scratch does not fit half of the free device memory, first the
+    // slots per item go back to 2 and 1, then the items in flight are cut down (never below one sub-batch of 64, never above n).
+    uint32_t maxBlocks = 1, bigItems = 0, needBlocks = 1, maxCapBytes = 0;
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t nb = (uint32_t)(((uint64_t)dstCaps[i] + ZS_BLOCK_MAX - 1) / ZS_BLOCK_MAX);
+        maxCapBytes = std::max(maxCapBytes, dstCaps[i]);
         if (nb > 1) maxBlocks = 2;
         if (nb > 2) { bigItems++; needBlocks = std::max(needBlocks, std::min<uint32_t>(nb, ZS_FAST_MAXBLOCKS)); }
     }
     if (bigItems && (uint64_t)bigItems * 4 >= n) maxBlocks = needBlocks;
-    const uint32_t descSlots = std::max(2u, maxBlocks);
-    const size_t perItem = ((size_t)(1u << 17) + 64) * (fast ? maxBlocks : 1) + (fast ? descSlots * sizeof(ZsFastDesc) + (size_t)maxBlocks * (ZS_FAST_HUFTAB_BYTES + ZS_FAST_SEQTAB_BYTES + (size_t)ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)) : 0);
+    const uint32_t blockCap = std::min<uint32_t>(std::max<uint32_t>(maxCapBytes, 64u), 1u << 17);
+    const uint32_t litStride = ((blockCap + 63u) & ~63u) + 64u, litCap = litStride - 64u;
+    const uint32_t seqCap = std::min<uint32_t>(ZS_FAST_MAXSEQ, ((blockCap / 3u + 64u) & ~63u));
+    uint32_t pool = std::min<uint32_t>(std::max<uint32_t>(n, 1u), c->decodePool);
+    pool = ((pool + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP) * ZS_DEC_GROUP;
     uint32_t cap = std::min<uint32_t>(n, c->maxItemsInFlight);
+    uint32_t descSlots = std::max(2u, maxBlocks);
+    auto perItemBytes = [&](uint32_t mb) { return (size_t)std::max(2u, mb) * sizeof(ZsFastDesc) + (size_t)mb * ((size_t)litStride + ZS_FAST_HUFTAB_BYTES + ZS_FAST_SEQTAB_BYTES + (size_t)seqCap * sizeof(ZsFastSeq) + 2 * sizeof(uint32_t)) + sizeof(uint32_t); };
+    size_t perItem = fast ? perItemBytes(maxBlocks) : 0;
+    const size_t poolBytes = (size_t)pool * ZS_DEC_LITBUF;
     {
-        size_t freeB = 0, totalB = 0;
-        const size_t have = c->dLitScratch.cap + c->dFastDesc.cap + c->dHufTabs.cap + c->dSeqTabs.cap + c->dSeqOut.cap;     // what the context holds already counts as available
-        if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
-            const size_t budget = (freeB + have) / 2;
-            if ((size_t)cap * perItem > budget) cap = (uint32_t)std::max<size_t>(256, budget / perItem);
+        const size_t have = c->dLitScratch.cap + c->dFastDesc.cap + c->dHufTabs.cap + c->dSeqTabs.cap + c->dSeqOut.cap + c->dPoolLit.cap;     // what the context holds already counts as available
+        const size_t need = (size_t)cap * perItem + poolBytes;
+        if (need > have) {                                           // (a call the buffers already hold asks the runtime nothing: the one-shot path)
+            size_t freeB = 0, totalB = 0;
+            if (hipMemGetInfo(&freeB, &totalB) == hipSuccess) {
+                const size_t budget = (freeB + have) / 2;
+                while (fast && maxBlocks > 1 && (size_t)std::min<uint32_t>(cap, 64u) * perItemBytes(maxBlocks) + poolBytes > budget) { maxBlocks = maxBlocks > 2 ? 2 : 1; }
+                descSlots = std::max(2u, maxBlocks); perItem = fast ? perItemBytes(maxBlocks) : 0;
+                if (perItem && (size_t)cap * perItem + poolBytes > budget) {
+                    const size_t fit = budget > poolBytes ? (budget - poolBytes) / perItem : 0;
+                    cap = (uint32_t)std::min<size_t>(cap, std::max<size_t>(std::min<uint32_t>(64u, n), fit));
+                }
+            }
         }
+        // give back what an earlier, larger call left behind: a buffer more than twice (and 256 MiB) beyond this call's need is released first
+        auto fitBuf = [&](DevBuf &b, size_t want) { if (b.cap > 2 * want + ((size_t)256 << 20)) b.release(); return b.reserve(want); };
+        if (!fitBuf(c->dPoolLit, poolBytes)) return ZSMI_error_memory_allocation;
+        if (fast && (!fitBuf(c->dLitScratch, (size_t)cap * maxBlocks * litStride) || !fitBuf(c->dFastDesc, (size_t)cap * descSlots * sizeof(ZsFastDesc)) ||
+                     !fitBuf(c->dHufTabs, (size_t)cap * maxBlocks * ZS_FAST_HUFTAB_BYTES) || !fitBuf(c->dSeqTabs, (size_t)cap * maxBlocks * ZS_FAST_SEQTAB_BYTES) ||
+                     !fitBuf(c->dSeqOut, (size_t)cap * maxBlocks * seqCap * sizeof(ZsFastSeq)) || !fitBuf(c->dSeqLists, (8 + 2 * (size_t)cap * maxBlocks + cap) * sizeof(uint32_t)))) return ZSMI_error_memory_allocation;
+        if (!fast && !c->dSeqLists.reserve(8 * sizeof(uint32_t))) return ZSMI_error_memory_allocation;
+        c->lastDecodeScratch = (fast ? (size_t)cap * perItem : 0) + poolBytes;
     }
-    if (!c->dLitScratch.reserve((size_t)cap * (fast ? maxBlocks : 1) * ((1u << 17) + 64))) return ZSMI_error_memory_allocation;
-    if (fast && (!c->dFastDesc.reserve((size_t)cap * descSlots * sizeof(ZsFastDesc)) || !c->dHufTabs.reserve((size_t)cap * maxBlocks * ZS_FAST_HUFTAB_BYTES) ||
-                 !c->dSeqTabs.reserve((size_t)cap * maxBlocks * ZS_FAST_SEQTAB_BYTES) || !c->dSeqOut.reserve((size_t)cap * maxBlocks * ZS_FAST_MAXSEQ * sizeof(ZsFastSeq)) ||
-                 !c->dSeqLists.reserve((2 + 2 * (size_t)cap * maxBlocks) * sizeof(uint32_t)))) return ZSMI_error_memory_allocation;
     for (uint32_t i0 = 0; i0 < n; i0 += cap) {
         const uint32_t cnt = std::min(cap, n - i0);
         const ZsDecItem *dI = (const ZsDecItem *)c->dItems.p + i0;
@@ -438,41 +472,49 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
             // (decode_fast.hip); whatever those kernels do not take or reject is left to the general kernel below
             ZsFastDesc *dD = (ZsFastDesc *)c->dFastDesc.p;
             const uint32_t groups = (cnt + ZS_FAST_GROUP - 1) / ZS_FAST_GROUP;
-            uint32_t *dLists = (uint32_t *)c->dSeqLists.p;                // [0], [1]: blocks listed per sequence-table class; then the two lists
-            if (hipMemsetAsync(dLists, 0, 2 * sizeof(uint32_t), c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+            uint32_t *dLists = (uint32_t *)c->dSeqLists.p + 4;            // [0], [1]: blocks listed per sequence-table class; then the two lists.  (In front of them: the general kernel's queue)
+            if (hipMemsetAsync(c->dSeqLists.p, 0, 6 * sizeof(uint32_t), c->stream) != hipSuccess) return ZSMI_error_GENERIC;
             LAUNCH(c, "k_dec_prep", (k_dec_prep<ZS_DEC_GROUP>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc, dI, cnt, dD,
-                   (uint8_t *)c->dHufTabs.p, (uint8_t *)c->dSeqTabs.p, cap, maxBlocks, dLists);
+                   (uint8_t *)c->dHufTabs.p, (uint8_t *)c->dSeqTabs.p, cap, maxBlocks, dLists, litCap, seqCap);
             {   // every block index of the items in one launch per kernel class (the grid: maxBlocks runs of the items' groups; a wavefront whose items
                 // have no such block leaves at once)
                 const uint32_t mb = maxBlocks, vcnt = cnt * mb;                 // (item, block) pairs: what a launch's rounds of workgroups count
-                LAUNCH(c, "k_dec_huffman", (k_dec_huffman<false, ZS_FAST_GROUP>), dim3(groups * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, mb, cap);
-                LAUNCH(c, "k_dec_huffman", (k_dec_huffman<true, 8u>), dim3(((cnt + 7) / 8) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, mb, cap);
-                LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3(((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists);
+                LAUNCH(c, "k_dec_huffman", (k_dec_huffman<false, ZS_FAST_GROUP>), dim3(groups * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, mb, cap, litStride);
+                LAUNCH(c, "k_dec_huffman", (k_dec_huffman<true, 8u>), dim3(((cnt + 7) / 8) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, mb, cap, litStride);
+                LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3(((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists, seqCap);
                 // the 2.5 KiB table class: fuller wavefronts (16 items) win when a launch is several rounds of workgroups, emptier ones (4) when it
                 // is less than one (8192 frames of 128 KiB: 83 vs 77 GiB/s; 16384: 117 vs 128)
                 // (r3: and when 4 items a wavefront save a whole round of workgroups - 14 x 4 = 56 items a CU against 3 x 16 = 48 -: 57344 libzstd
                 //  frames of 32 KiB are 4 rounds instead of 5, 3.8 vs 5.2 ms)
                 const uint32_t rounds16 = (vcnt + 48u * 256u - 1) / (48u * 256u), rounds4 = (vcnt + 56u * 256u - 1) / (56u * 256u);
                 if (vcnt >= ZS_FAST_SEQGROUP_MANY && rounds4 >= rounds16)
-                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, ZS_FAST_SEQGROUP>), dim3(((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists);
+                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, ZS_FAST_SEQGROUP>), dim3(((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists, seqCap);
                 else
-                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, 4u>), dim3(((cnt + 3) / 4) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists);
+                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, 4u>), dim3(((cnt + 3) / 4) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists, seqCap);
             }
             if (maxBlocks == 1)
                 LAUNCH(c, "k_dec_execute", (k_dec_execute<4, 7>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (ZsFastSeq *)c->dSeqOut.p,
-                       (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap, descSlots);
+                       (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap, descSlots, litStride, seqCap);
             else
                 LAUNCH(c, "k_dec_execute", (k_dec_execute<4, 6>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (ZsFastSeq *)c->dSeqOut.p,
-                       (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap, descSlots);
+                       (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap, descSlots, litStride, seqCap);
             LAUNCH(c, "k_dec_checksum", k_dec_checksum, dim3((cnt + 63) / 64), dim3(64), 0, dI, cnt, (const ZsFastDesc *)dD, (const uint8_t *)dDst, dDstSizes + i0);
             doneFlags = &dD->fast;
         }
+        // the general kernel: a pool of wavefronts over a queue - of every item, or (behind the fast path) of the list of the items it left
+        uint32_t *dQueue = (uint32_t *)c->dSeqLists.p, *dLeftCount = dQueue + 1, *dLeft = nullptr;
+        if (!fast && hipMemsetAsync(dQueue, 0, 2 * sizeof(uint32_t), c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+        if (doneFlags) {
+            dLeft = dQueue + 8 + 2 * (size_t)cap * maxBlocks;
+            LAUNCH(c, "k_dec_collect", k_dec_collect, dim3((cnt + 255) / 256), dim3(256), 0, doneFlags, (uint32_t)(sizeof(ZsFastDesc) / sizeof(uint32_t)), cnt, dLeft, dLeftCount);
+        }
+        const uint32_t poolWgs = std::min<uint32_t>((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP, pool / ZS_DEC_GROUP);
         if (useDict)
-            LAUNCH(c, "k_decode_frames_dict", (k_decode_frames<ZS_DEC_GROUP, true>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc,
-                   dI, cnt, (uint8_t *)dDst, dDstSizes + i0, (uint8_t *)c->dLitScratch.p, doneFlags, (uint32_t)(sizeof(ZsFastDesc) / sizeof(uint32_t)), (const uint8_t *)dDict, dictSize);
+            LAUNCH(c, "k_decode_frames_dict", (k_decode_frames<ZS_DEC_GROUP, true>), dim3(poolWgs), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc,
+                   dI, cnt, (uint8_t *)dDst, dDstSizes + i0, (uint8_t *)c->dPoolLit.p, (const uint32_t *)dLeft, (const uint32_t *)dLeftCount, (const uint8_t *)dDict, dictSize, dQueue);
         else
-            LAUNCH(c, "k_decode_frames", (k_decode_frames<ZS_DEC_GROUP, false>), dim3((cnt + ZS_DEC_GROUP - 1) / ZS_DEC_GROUP), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc,
-                   dI, cnt, (uint8_t *)dDst, dDstSizes + i0, (uint8_t *)c->dLitScratch.p, doneFlags, (uint32_t)(sizeof(ZsFastDesc) / sizeof(uint32_t)), (const uint8_t *)nullptr, 0u);
+            LAUNCH(c, "k_decode_frames", (k_decode_frames<ZS_DEC_GROUP, false>), dim3(poolWgs), dim3(64 * ZS_DEC_GROUP), 0, (const uint8_t *)dSrc,
+                   dI, cnt, (uint8_t *)dDst, dDstSizes + i0, (uint8_t *)c->dPoolLit.p, (const uint32_t *)dLeft, (const uint32_t *)dLeftCount, (const uint8_t *)nullptr, 0u, dQueue);
     }
     return hipGetLastError() == hipSuccess ? 0 : ZSMI_error_GENERIC;
 }
@@ -677,21 +719,28 @@ struct OneShotPool {
         { std::lock_guard<std::mutex> lk(mu); dev[c->device].idle.push_back(c); }
         cv.notify_one();
     }
-    ~OneShotPool()
+    // No destructor work: at process exit or dlclose the order against the HIP runtime's own teardown is not defined, and HIP calls from an
+    // exit-time destructor are a known source of aborts.  The contexts are left to the process; an embedder that unloads the library
+    // calls zsmi_shutdown() first.
+    void drain()
     {
-        // library unload / process exit: the HIP runtime was loaded before this library and is still there; if it does not answer any
-        // more (a process torn down the hard way), the contexts are left to it
-        int n = 0;
-        if (hipGetDeviceCount(&n) != hipSuccess) return;
-        for (auto &kv : dev) for (zsmi_ctx *c : kv.second.idle) zsmi_freeCtx(c);
+        std::lock_guard<std::mutex> lk(mu);
+        for (auto &kv : dev) { for (zsmi_ctx *c : kv.second.idle) { zsmi_freeCtx(c); kv.second.created--; } kv.second.idle.clear(); }
     }
 };
-OneShotPool g_pool;
+OneShotPool &g_pool = *new OneShotPool();                  // (never destroyed: see above)
 struct Borrowed {
     zsmi_ctx *c;
     Borrowed() : c(g_pool.acquire()) {}
     ~Borrowed() { if (c) g_pool.release(c); }
 };
+}
+
+extern "C" void zsmi_shutdown(void) { g_pool.drain(); }
+extern "C" size_t zsmi_decodeScratchBytes(zsmi_ctx *c)
+{
+    if (!c) return 0;
+    return c->dPoolLit.cap + c->dLitScratch.cap + c->dFastDesc.cap + c->dHufTabs.cap + c->dSeqTabs.cap + c->dSeqOut.cap + c->dSeqLists.cap;
 }
 
 extern "C" size_t zsmi_compress(void *dst, size_t dstCapacity, const void *src, size_t srcSize, int level)
@@ -740,6 +789,12 @@ extern "C" size_t zsmi_decompress_usingDict(void *dst, size_t dstCapacity, const
 #ifdef ZSMI_DEBUG_HOOKS
 // ---- test hook (not in include/zsmi.h): copy a scratch buffer of the last compress sub-batch to the host.
 //      which: 0 dist (u16 x 65536 per block), 1 sequences (ZsSeqRec x 8 x 2048 per block), 2 range headers, 3 block results ----
+// words of a ZsFastDesc, and the word index of its fields `fast`, `why`, `nbSeq`, `litType`, `hufLog` (tools/fastpath_check.py, tools/dec_why.py)
+extern "C" void zsmi_dbg_descLayout(uint32_t out[6])
+{
+    out[0] = (uint32_t)(sizeof(ZsFastDesc) / 4); out[1] = (uint32_t)(offsetof(ZsFastDesc, fast) / 4); out[2] = (uint32_t)(offsetof(ZsFastDesc, why) / 4);
+    out[3] = (uint32_t)(offsetof(ZsFastDesc, nbSeq) / 4); out[4] = (uint32_t)(offsetof(ZsFastDesc, litType) / 4); out[5] = (uint32_t)(offsetof(ZsFastDesc, hufLog) / 4);
+}
 extern "C" int zsmi_dbg_copyScratch(zsmi_ctx *c, int which, void *hostDst, size_t bytes)
 {
     if (!c) return -1;
