@@ -516,6 +516,7 @@ typedef struct {
     BYTE llCode[BLOCK_MAX / 3 + 8], mlCode[BLOCK_MAX / 3 + 8], ofCode[BLOCK_MAX / 3 + 8];
     U32 ofValue[BLOCK_MAX / 3 + 8];           /* offset field value: 1..3 repcode, else offset+3 */
     BYTE tmp[BLOCK_MAX + 1024];
+    int matchless;                            /* the unit's candidates are too few to be worth a parse: its blocks get no sequences */
 } Work;
 
 /* stage 1, once per unit: two unit-wide hash tables, every position inserted in position order, the last writer
@@ -526,7 +527,12 @@ typedef struct {
  * Candidates are NOT compared with the bytes here (28 hash bits agree; the walk measures every match it uses).
  * On the GPU one wavefront per table takes 64 positions per LDS exchange instruction (ds_wrxchg_rtn_b32);
  * the LDS resolves lanes that hit the same slot in ascending lane order (probed: tools/probe/lds_xchg.hip), which
- * is exactly this loop. */
+ * is exactly this loop.
+ * MATCHLESS units (round 4): a unit with fewer than n / 2048 candidate positions (32 per 64 KiB; units below 2 KiB never) is not parsed at
+ * all: its blocks get no sequences and go straight to the literal / raw decision.  Incompressible input leaves a handful of chance
+ * candidates (28 hash bits agree by accident: ~4 per 64 KiB of noise) and used to pay the whole walk for them; what the rule can
+ * cost is those < 32 matches of an otherwise matchless unit. */
+#define MATCHLESS_SHIFT 11
 #define SLOT_EMPTY 0xFFFFFFFFu
 /* hashes made of 24 x 24 -> 32 bit multiplies (v_mul_u32_u24 / v_mad_u32_u24 run at full rate on CDNA, v_mul_lo_u32 at a quarter):
  * short: bytes 0-2 and 2-4; long: bytes 0-2, 3-5, 6-7 */
@@ -537,8 +543,9 @@ static U32 tableLogFor(U32 unitN) { return unitN > BLOCK_MAX ? MAX_TABLE_LOG : M
 static void findCandidates(Work *w, const BYTE *src, U32 n, const EParams *prm)
 {
     U32 const tlog = tableLogFor(n);
-    U32 p;
+    U32 p, found = 0;
     memset(w->dist, 0, n * sizeof(U32));
+    w->matchless = 0;
     if (n < 8) return;
     memset(w->tabS, 0xFF, sizeof(U32) << tlog);
     if (prm->useLong) memset(w->tabL, 0xFF, sizeof(U32) << tlog);
@@ -557,7 +564,9 @@ static void findCandidates(Work *w, const BYTE *src, U32 n, const EParams *prm)
             if (ol != SLOT_EMPTY && ((ol ^ el) >> 17) == 0) d = p - (ol & 0x1FFFFu);
         }
         w->dist[p] = d;
+        found += d != 0;
     }
+    w->matchless = found < (n >> MATCHLESS_SHIFT);
 }
 
 static U32 matchLen(const BYTE *src, U32 a, U32 b, U32 limit)   /* common prefix of src[a..] and src[b..], a > b, up to limit */
@@ -633,7 +642,7 @@ static U32 parseBlock(Work *w, const BYTE *src, U32 unitN, U32 blockOff, U32 n, 
         U32 const start = blockOff + (r << prm->walkLog);
         U32 const end = (start + WS < blockEnd) ? start + WS : blockEnd;
         U32 const limit = (end + CROSS_MAX < blockEnd) ? end + CROSS_MAX : blockEnd;
-        w->rangeN[r] = walkRange(w, src, unitN, start, end, limit, prm, w->rangeSeq + ((start - blockOff) >> 2));
+        w->rangeN[r] = w->matchless ? 0 : walkRange(w, src, unitN, start, end, limit, prm, w->rangeSeq + ((start - blockOff) >> 2));
     }
     for (r = 0; r < nRanges; r++) {
         ASeq *const rs = w->rangeSeq + (r << (prm->walkLog - 2));

@@ -538,6 +538,39 @@ def test_units_of_one_repeated_byte_skip_the_parse(codec, level):
     assert len(frames[0]) < 16 and len(frames[2]) < 24
 
 
+def _matchless_inputs():
+    """noise with 0 .. 12 planted 24-byte repeats (each leaves ~17 - 20 candidate positions: the rule's 32 / 64 per unit are crossed on the way),
+    skewed noise (Huffman pays, no match does), noise in front of text and text in front of noise inside one unit"""
+    rng = np.random.default_rng(23)
+    text = D.zipf_log(140000, seed_lo=77).tobytes()
+    out = {}
+    for size in (65536, 131072, 40000, 2047, 2048, 4096):
+        for plants in (0, 1, 2, 3, 4, 6, 8, 12):
+            c = bytearray(rng.integers(0, 256, size, dtype=np.uint8).tobytes())
+            for k in range(plants):
+                b = int(rng.integers(size // 2, size - 64)); a = b - int(rng.integers(100, min(2000, size // 2 - 64)))     # (near: a slot of the 2^13-slot tables is overwritten every ~8 KiB of noise)
+                c[b:b + 24] = c[a:a + 24]
+            out["noise_%d_%d" % (size, plants)] = bytes(c)
+    out["skewed_65536"] = np.minimum(rng.geometric(0.05, 65536), 255).astype(np.uint8).tobytes()
+    out["noise_then_text"] = rng.integers(0, 256, 65536, dtype=np.uint8).tobytes() + text[:65536]
+    out["text_then_noise"] = text[:50000] + rng.integers(0, 256, 81072, dtype=np.uint8).tobytes()
+    return out
+
+
+@pytest.mark.parametrize("level", [1, 3])
+def test_matchless_units_skip_the_parse(codec, level):
+    """a unit with fewer than n / 2048 candidate positions is not parsed (oracle E: findCandidates / parseBlock; k_lz_candidates counts, k_lz_walk
+    leaves the unit): the frames are oracle E's on both sides of the threshold and decode; pure noise becomes raw blocks"""
+    inputs = _matchless_inputs()
+    names = sorted(inputs)
+    frames = _compress_many(codec, [inputs[k] for k in names], level)
+    for k, f in zip(names, frames):
+        assert f == O.compress(inputs[k], level), k
+        assert O.decompress(f, len(inputs[k])) == inputs[k], k
+    assert len(frames[names.index("noise_65536_0")]) == 65536 + 4 + 1 + 2 + 3              # header + one raw block
+    assert len(frames[names.index("noise_then_text")]) < 65536 + 40000                      # the unit's second block still finds its matches
+
+
 def test_decode_wide_alphabets_flat_huffman_table(codec):
     """literals over all 256 byte values with a long tail of rare ones: more 9-bit prefixes hold 10 / 11-bit codes than the fast path's two-level
     Huffman table has sub-tables, so k_dec_prep emits the flat 2^11 table and k_dec_huffman's flat class decodes them (before round 3's end such

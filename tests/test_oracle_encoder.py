@@ -114,3 +114,19 @@ def test_piecewise_matches_are_joined():
             ours += len(f); zs += len(O.zstd_compress(c, level)) if O.libzstd() else 0
         if zs:
             assert ours <= 1.02 * zs, (level, cs, ours, zs)
+
+
+def test_matchless_units_are_not_parsed():
+    """round 4: a unit with fewer than n / 2048 candidate positions gets no sequences (findCandidates / parseBlock): noise with a few planted
+    repeats on both sides of the threshold round-trips; below it the planted repeats are not used (raw block), well above it they are"""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from test_gpu_codec import _matchless_inputs
+    inputs = _matchless_inputs()
+    for k, c in inputs.items():
+        for level in (1, 3):
+            f = O.compress(c, level)
+            assert O.decompress(f, len(c)) == c, (k, level)
+    assert len(O.compress(inputs["noise_65536_1"], 3)) == 65536 + 4 + 1 + 2 + 3          # one repeat: ~20 candidates < 32: raw block
+    assert len(O.compress(inputs["noise_65536_12"], 3)) < 65536                            # twelve: parsed, and they pay
+    assert len(O.compress(inputs["noise_2047_0"], 3)) == 2047 + 4 + 1 + 2 + 3

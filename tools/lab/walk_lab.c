@@ -41,9 +41,10 @@ void wl_stats(unsigned long long *o) { memcpy(o, &S, sizeof S); memset(&S, 0, si
 static void wlCandidates(Work *w, const BYTE *src, U32 n, const EParams *prm)
 {
     U32 const tlog = tableLogFor(n);
-    U32 p;
+    U32 p, found = 0;
     memset(wlLong, 0, n);
     memset(w->dist, 0, n * sizeof(U32));
+    w->matchless = 0;
     if (n < 8) return;
     memset(w->tabS, 0xFF, sizeof(U32) << tlog);
     if (prm->useLong) memset(w->tabL, 0xFF, sizeof(U32) << tlog);
@@ -62,7 +63,9 @@ static void wlCandidates(Work *w, const BYTE *src, U32 n, const EParams *prm)
             if (ol != SLOT_EMPTY && ((ol ^ el) >> 17) == 0) { d = p - (ol & 0x1FFFFu); wlLong[p] = 1; }
         }
         w->dist[p] = d;
+        found += d != 0;
     }
+    w->matchless = found < (n >> MATCHLESS_SHIFT);
 }
 
 static U32 wlWalk(Work *w, const BYTE *src, U32 n, U32 start, U32 end, U32 limit, const EParams *prm, ASeq *out, U32 *reps)
@@ -155,7 +158,7 @@ static size_t wlBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32 unitN
         U32 const limit = (end + (U32)P.crossMax < blockEnd) ? end + (U32)P.crossMax : blockEnd;
         if (!P.carryRep) reps[0] = reps[1] = 0;
         if (P.initRep && start > blockOff) { U32 b; for (b = 1; b <= 64 && start >= b + (P.initRep == 2 ? 0 : blockOff); b++) if (w->dist[start - b]) { reps[0] = w->dist[start - b]; break; } }
-        wlN[r] = wlWalk(w, src, unitN, start, end, limit, prm, wlSeq[r], reps);
+        wlN[r] = w->matchless ? 0 : wlWalk(w, src, unitN, start, end, limit, prm, wlSeq[r], reps);
     }
     {   /* the stitch, sequential statement (same result as oracle's stitch + concatenation when merge == 0) */
         U32 pos = blockOff;                 /* == reach throughout */

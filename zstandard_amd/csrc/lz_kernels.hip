@@ -54,7 +54,7 @@ __device__ __forceinline__ uint32_t zs_hash_long(uint32_t lo, uint32_t hi)
 template <int TLOG, int NT>
 __global__ void __launch_bounds__(64 * ZS_CAND_WAVES(NT))
 k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units, uint32_t block0,
-                uint16_t *__restrict__ distAll, uint8_t *__restrict__ distHiAll)
+                uint16_t *__restrict__ distAll, uint8_t *__restrict__ distHiAll, uint32_t *__restrict__ candCount)
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t candLds[];
     constexpr bool BIG = TLOG > ZS_TABLE_LOG_SMALL;
@@ -75,6 +75,9 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     uint8_t *distHi = distHiAll + slot * (ZS_BLOCK_MAX / 8);
     const uint32_t hashable = (n >= 8) ? n - 7 : 0;                   // positions [0, hashable) have 8 bytes
     const uint32_t nGroups = (hashable + GP - 1) / GP;
+    // candidate positions of the unit, counted by the mergers (a word each: candCount[2 slot + table]): k_lz_walk leaves a unit with fewer than
+    // n >> ZS_MATCHLESS_SHIFT of them alone (findCandidates in oracle/zso_encoder.c: matchless units)
+    if (threadIdx.x < 2) candCount[2 * slot + threadIdx.x] = 0;          // (written again by the mergers at their end: same wavefront order does not matter, they add nothing before)
     if (nGroups == 0) return;
     // A unit of one repeated byte needs no candidates: the walk kernel tests for exactly this (same condition) and skips its walk, the
     // blocks become RLE blocks.  Ordinary data fails the test on its first 16 bytes.
@@ -107,6 +110,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
         #pragma unroll
         for (uint32_t uu = 0; uu < H; uu++) { mS[uu] = xb[uu * ROW]; mL[uu] = (NT > 1) ? xb[GR + uu * ROW] : 0u; }
     };
+    uint32_t found = 0;                                                 // mergers: candidate positions among this wavefront's steps
     auto mergeStore = [&](uint32_t g, const uint32_t (&mS)[H], const uint32_t (&mL)[H]) {
         // bit 16 of the distances (big units): lane uu keeps step uu's word, so the plane takes one store of H * 8 contiguous bytes.
         // (What is stored for positions behind the hashable ones is never used: the walk cuts them off its window.)
@@ -116,6 +120,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
         for (uint32_t uu = 0; uu < H; uu++) {
             const uint32_t dm = (NT > 1) ? (mL[uu] ? mL[uu] : mS[uu]) : mS[uu];
             if (BIG) { const uint64_t hi = __ballot((dm >> 16) != 0); if (lane == uu) hiMine = hi; }
+            found += (uint32_t)__popcll(__ballot(dm != 0 && sbase + uu * 64 + lane < hashable));
             dist[sbase + uu * 64 + lane] = (uint16_t)dm;
         }
         if (BIG && lane < H) *reinterpret_cast<uint64_t *>(distHi + ((sbase + lane * 64) >> 3)) = hiMine;
@@ -129,6 +134,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
             mergeStore(i - 2, mS, mL);
             __syncthreads();
         }
+        if (lane == 0) candCount[2 * slot + tab] = found;
         return;
     }
 
@@ -373,7 +379,7 @@ template <int LPW, int WGRP, int LOOK, int REPWIN, bool BIG, int NT>
 __global__ void __launch_bounds__(NT, BIG ? 1 : ZS_WALK_MINW)
 k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units, uint32_t block0,
           const uint16_t *__restrict__ distAll, const uint8_t *__restrict__ distHiAll,
-          uint2 *__restrict__ recAll, uint32_t junkSlot, uint4 *__restrict__ resAll, int rangeLogArg)
+          uint2 *__restrict__ recAll, uint32_t junkSlot, uint4 *__restrict__ resAll, int rangeLogArg, const uint32_t *__restrict__ candCount)
 {
     constexpr uint32_t CAP = BIG ? ZS_UNIT_MAX : ZS_BLOCK_MAX;                  // unit capacity in bytes
     constexpr uint32_t CPL = LOOK / LPW, RPL = REPWIN / LPW, GPL = WGRP / LPW;   // candidates / recent-offset positions / groups of distances per lane and step
@@ -412,6 +418,13 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(wlast) :: "memory");
 #endif
 
+    // a MATCHLESS unit (fewer than n >> ZS_MATCHLESS_SHIFT candidate positions: incompressible input's chance candidates) is not walked: its ranges
+    // report no records, its blocks go on without sequences (findCandidates / parseBlock in oracle/zso_encoder.c)
+    if (candCount[2 * slot] + candCount[2 * slot + 1] < (n >> ZS_MATCHLESS_SHIFT)) {
+        const uint32_t nRanges = (n + R - 1) >> rangeLog, perBlockLog = 16u - rangeLog;
+        for (uint32_t r = tid; r < nRanges; r += NT) res[(r >> perBlockLog) * ZS_RES_PER_BLOCK + (r & ((1u << perBlockLog) - 1u))] = make_uint4(0, 0, 0, 0);
+        return;
+    }
     // ---- stage the unit ----
     uint32_t mixed = 0;                                                          // some byte of the unit differs from its first byte
     if (tid < (ZS_WALK_FRONT - ZS_WALK_SKEW) / 4) reinterpret_cast<uint32_t *>(walkLds + SRC - ZS_WALK_FRONT)[tid] = 0;

@@ -125,7 +125,7 @@ struct zsmi_ctx {
     uint32_t maxBlocksInFlight = 16384;   // ZSMI_BLOCKS_IN_FLIGHT: 64 KiB blocks per sub-batch (scratch ~0.6 MiB a block, reserved for what a call needs); 2 GiB of 128 KiB chunks: 8192: 86.5, 16384: 88.2, 32768: 89.4 GiB/s
     // compress workspace: plan (shared) + one scratch set per internal stream ("lane")
     DevBuf dBlocks, dChunks, dUnits;     // dUnits: small units (<= 64 KiB) first, then big ones, each in chunk order
-    struct Scratch { DevBuf dDist, dDistHi, dRecs, dRes, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
+    struct Scratch { DevBuf dDist, dDistHi, dCand, dRecs, dRes, dSeqs, dHdrs, dLits, dStreams, dLitSec, dSeqSec, dMetas; hipStream_t stream = nullptr; hipEvent_t done = nullptr; };
     static const int kMaxLanes = 8;
     Scratch lanes[kMaxLanes];
     int nLanes = 1;
@@ -223,7 +223,7 @@ extern "C" void zsmi_freeCtx(zsmi_ctx *c)
     for (int i = 0; i < zsmi_ctx::kMaxLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
         if (L.stream) (void)hipStreamSynchronize(L.stream);
-        for (DevBuf *b : { &L.dDist, &L.dDistHi, &L.dRecs, &L.dRes, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dLitSec, &L.dSeqSec, &L.dMetas }) b->release();
+        for (DevBuf *b : { &L.dDist, &L.dDistHi, &L.dCand, &L.dRecs, &L.dRes, &L.dSeqs, &L.dHdrs, &L.dLits, &L.dStreams, &L.dLitSec, &L.dSeqSec, &L.dMetas }) b->release();
         if (L.done) (void)hipEventDestroy(L.done);
         if (L.stream) (void)hipStreamDestroy(L.stream);
     }
@@ -338,7 +338,7 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
     if (cap < maxChunkBlocks) cap = maxChunkBlocks;
     for (int i = 0; i < nLanes; i++) {
         zsmi_ctx::Scratch &L = c->lanes[i];
-        if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2 + 256) || !L.dDistHi.reserve((size_t)cap * (ZS_BLOCK_MAX / 8) + 256) || !L.dRecs.reserve(((size_t)cap * (ZS_BLOCK_MAX / 4) + 64) * sizeof(uint2)) || !L.dRes.reserve((size_t)cap * ZS_RES_PER_BLOCK * sizeof(uint4) + ((size_t)8 << 20)) || !L.dSeqs.reserve((size_t)cap * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
+        if (!L.dDist.reserve((size_t)cap * ZS_BLOCK_MAX * 2 + 256) || !L.dDistHi.reserve((size_t)cap * (ZS_BLOCK_MAX / 8) + 256) || !L.dCand.reserve((size_t)cap * 2 * sizeof(uint32_t) + 64) || !L.dRecs.reserve(((size_t)cap * (ZS_BLOCK_MAX / 4) + 64) * sizeof(uint2)) || !L.dRes.reserve((size_t)cap * ZS_RES_PER_BLOCK * sizeof(uint4) + ((size_t)8 << 20)) || !L.dSeqs.reserve((size_t)cap * ZS_WALK_RANGES * ZS_SEQ_PER_RANGE * sizeof(ZsSeqRec)) ||
             !L.dHdrs.reserve((size_t)cap * ZS_WALK_RANGES * sizeof(ZsRangeHdr)) || !L.dLits.reserve((size_t)cap * (ZS_BLOCK_MAX + 64)) ||
             !L.dStreams.reserve((size_t)cap * 4 * ZS_STREAM_STRIDE) || !L.dLitSec.reserve((size_t)cap * ZS_LITSEC_STRIDE) ||
             !L.dSeqSec.reserve((size_t)cap * ZS_SEQSEC_STRIDE) || !L.dMetas.reserve((size_t)cap * sizeof(ZsBlockMeta))) return ZSMI_error_memory_allocation;
@@ -357,12 +357,12 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         const uint32_t s0 = c->smallBefore[chunk0], ns = c->smallBefore[chunk1] - s0, b0 = c->bigBefore[chunk0], nbig = c->bigBefore[chunk1] - b0;
         const ZsUnitDesc *dUS = (const ZsUnitDesc *)c->dUnits.p + s0, *dUB = (const ZsUnitDesc *)c->dUnits.p + c->planSmall + b0;
         #define CAND_LAUNCH(name, TL, NT, cnt, du) LAUNCH_ON(c, st, name, (k_lz_candidates<TL, NT>), dim3(cnt), dim3(64 * ZS_CAND_WAVES(NT)), ZS_CAND_LDS(TL, NT), (const uint8_t *)dSrc, du, block0, \
-                          (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p)
+                          (uint16_t *)L.dDist.p, (uint8_t *)L.dDistHi.p, (uint32_t *)L.dCand.p)
         if (ns) { if (useLong) CAND_LAUNCH("k_lz_candidates", ZS_TABLE_LOG_SMALL, 2, ns, dUS); else CAND_LAUNCH("k_lz_candidates", ZS_TABLE_LOG_SMALL, 1, ns, dUS); }
         if (nbig) { if (useLong) CAND_LAUNCH("k_lz_candidates_big", ZS_TABLE_LOG_BIG, 2, nbig, dUB); else CAND_LAUNCH("k_lz_candidates_big", ZS_TABLE_LOG_BIG, 1, nbig, dUB); }
         #undef CAND_LAUNCH
         #define WALK_LAUNCH(name, LOOK, REPW, BIG, WLOG, cnt, du) LAUNCH_ON(c, st, name, (ZS_WALK_KERNEL(LOOK, REPW, BIG, WLOG)), dim3(cnt), dim3(ZS_WALK_THREADS(BIG, WLOG)), ZS_WALK_LDS((BIG) ? ZS_UNIT_MAX : ZS_BLOCK_MAX), \
-                          (const uint8_t *)dSrc, du, block0, (const uint16_t *)L.dDist.p, (const uint8_t *)L.dDistHi.p, (uint2 *)L.dRecs.p, cap * (ZS_BLOCK_MAX / 4), (uint4 *)L.dRes.p, WLOG)
+                          (const uint8_t *)dSrc, du, block0, (const uint16_t *)L.dDist.p, (const uint8_t *)L.dDistHi.p, (uint2 *)L.dRecs.p, cap * (ZS_BLOCK_MAX / 4), (uint4 *)L.dRes.p, WLOG, (const uint32_t *)L.dCand.p)
         if (ns) { if (level <= 2) WALK_LAUNCH("k_lz_walk", 4, 8, false, 9, ns, dUS); else if (level == 3) WALK_LAUNCH("k_lz_walk", 4, 4, false, 8, ns, dUS); else WALK_LAUNCH("k_lz_walk", 8, 8, false, 8, ns, dUS); }
         if (nbig) { if (level <= 2) WALK_LAUNCH("k_lz_walk_big", 4, 8, true, 9, nbig, dUB); else if (level == 3) WALK_LAUNCH("k_lz_walk_big", 4, 4, true, 8, nbig, dUB); else WALK_LAUNCH("k_lz_walk_big", 8, 8, true, 8, nbig, dUB); }
         #undef WALK_LAUNCH

@@ -13,6 +13,7 @@
 #define ZS_WALK_RANGES 64u        // output ranges per block
 #define ZS_RES_PER_BLOCK 256u     // walk-range results per block (ranges of >= 256 bytes)
 #define ZS_CROSS_MAX   1024u      // a match may pass its walk range's end by this much (never the block's end)
+#define ZS_MATCHLESS_SHIFT 11      // a unit with fewer than n >> 11 candidate positions is not parsed (oracle: MATCHLESS_SHIFT)
 #define ZS_MINMATCH    5u         // shortest match kept
 #define ZS_REPMIN      4u         // shortest match at one of the walker's two recent offsets
 #define ZS_WINDOW      32u        // positions looked at per walk step
