@@ -73,33 +73,45 @@ def load_corpus(path, nbytes, rank):
 
 
 
-def throughput_by_class(bc, args, torch):
-    """GiB/s and ratio of the compress path at this level / chunk size per data class: every class of tests/_corpus.py (1 MiB generated,
-    tiled to the headline's batch size) plus all-zero, uniform-random and period-1000 inputs.  Same timing as the headline (device-resident input, events
-    excluded), fewer steps; not part of `value`."""
+def class_corpus(args):
+    """the data classes of throughput_by_class at >= 64 MiB of DISTINCT bytes each (round 3 tiled 1 MiB of a class 256 x: 16 chunks, permanently cache resident).
+    Built on a pool of forked processes, so it runs before anything touches the GPU."""
     import _corpus as C
+    t0 = time.time()
+    classes = dict(C.corpus_distinct(args.class_bytes, workers=usable_cores()))
+    rng = np.random.default_rng(7)
+    classes["zeros"] = bytes(1 << 20)
+    classes["random"] = rng.integers(0, 256, args.class_bytes, dtype=np.uint8).tobytes()
+    classes["period1000"] = rng.integers(0, 256, 1000, dtype=np.uint8).tobytes()
+    return classes, round(time.time() - t0, 1)
+
+
+def throughput_by_class(bc, args, torch, classes, gen_s):
+    """GiB/s and ratio of the compress path at this level / chunk size per data class: every class of tests/_corpus.py plus all-zero,
+    uniform-random and period-1000 inputs, each at `distinct_bytes` of distinct data tiled (on the device) to the batch.  Compress: the headline's batch
+    shape and timing (device-resident input, events excluded), fewer steps.  Decode: the class cut in frames of the decode leg's shape and count
+    (--decode-frames x --decode-frame-size), built by this codec, decoded in ONE call as the decode leg does - so the classes compare with the decode
+    leg and with each other.  Not part of `value`."""
     cs = args.chunk_size
     n = args.chunks                                  # the headline's batch size
     nbytes = n * cs
-    classes = dict(C.corpus(1 << 20))
-    rng = np.random.default_rng(7)
-    classes["zeros"] = bytes(1 << 20)
-    classes["random"] = rng.integers(0, 256, 1 << 20, dtype=np.uint8).tobytes()
-    per = rng.integers(0, 256, 1000, dtype=np.uint8).tobytes()
-    classes["period1000"] = None
+    nf, fs = (args.decode_frames or 57344), args.decode_frame_size
     offs = np.arange(n, dtype=np.uint64) * cs; sizes = np.full(n, cs, dtype=np.uint32)
     bound = int(bc.L.zsmi_compressBound(cs)); stride = (bound + 255) // 256 * 256
     doffs = np.arange(n, dtype=np.uint64) * stride
     d_dst = torch.empty(n * stride, dtype=torch.uint8, device="cuda"); d_sizes = torch.zeros(n, dtype=torch.int32, device="cuda")
-    d_out = torch.empty(nbytes, dtype=torch.uint8, device="cuda"); d_osz = torch.zeros(n, dtype=torch.int32, device="cuda")
+    foffs_in = np.arange(nf, dtype=np.uint64) * fs; fsizes = np.full(nf, fs, dtype=np.uint32)
+    fbound = int(bc.L.zsmi_compressBound(fs)); fstride = (fbound + 255) // 256 * 256
+    ffo = np.arange(nf, dtype=np.uint64) * fstride
+    d_frames = torch.empty(nf * fstride, dtype=torch.uint8, device="cuda"); d_fsz = torch.zeros(nf, dtype=torch.int32, device="cuda")
+    d_out = torch.empty(nf * fs, dtype=torch.uint8, device="cuda"); d_osz = torch.zeros(nf, dtype=torch.int32, device="cuda")
     out = {}
+    def tiled(d_one, total):
+        reps = (total + d_one.numel() - 1) // d_one.numel()
+        return d_one.repeat(reps)[:total].contiguous()
     for name, data in classes.items():
-        if name == "period1000":
-            host = np.frombuffer((per * (nbytes // 1000 + 1))[:nbytes], dtype=np.uint8)
-        else:
-            one = np.frombuffer(data, dtype=np.uint8)
-            host = np.tile(one, (nbytes + len(one) - 1) // len(one))[:nbytes]
-        d_src = torch.from_numpy(host.copy()).cuda()
+        d_one = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda()
+        d_src = tiled(d_one, nbytes)
         step = lambda: bc.compress_device(d_src.data_ptr(), offs, sizes, d_dst.data_ptr(), doffs, d_sizes.data_ptr(), args.level)
         step(); torch.cuda.synchronize()
         k = 5
@@ -110,20 +122,28 @@ def throughput_by_class(bc, args, torch):
         dt = time.perf_counter() - t0
         csz = d_sizes.cpu().numpy().astype(np.uint32)
         assert (csz < 0xFFFFFF88).all(), name
-        out[name] = {"GiB/s": round(nbytes * k / dt / (1 << 30), 1), "ratio": round(nbytes / float(csz.astype(np.uint64).sum()), 3)}
-        # the same frames decoded back (one call of n frames of cs bytes: a smaller call than the decode leg's, so the classes compare with each other, not with it)
-        dstep = lambda: bc.decompress_device(d_dst.data_ptr(), doffs, csz, d_out.data_ptr(), offs, sizes, d_osz.data_ptr())
+        out[name] = {"GiB/s": round(nbytes * k / dt / (1 << 30), 1), "ratio": round(nbytes / float(csz.astype(np.uint64).sum()), 3), "distinct_bytes": len(data)}
+        del d_src
+        # decode: nf frames of fs bytes of the class, built here (untimed), decoded in one call
+        d_in = tiled(d_one, nf * fs)
+        bc.compress_device(d_in.data_ptr(), foffs_in, fsizes, d_frames.data_ptr(), ffo, d_fsz.data_ptr(), args.level); torch.cuda.synchronize()
+        fsz = d_fsz.cpu().numpy().astype(np.uint32)
+        assert (fsz < 0xFFFFFF88).all(), name
+        dstep = lambda: bc.decompress_device(d_frames.data_ptr(), ffo, fsz, d_out.data_ptr(), foffs_in, fsizes, d_osz.data_ptr())
         dstep(); torch.cuda.synchronize()
+        kd = 3
         t0 = time.perf_counter()
-        for _ in range(k):
+        for _ in range(kd):
             dstep()
         torch.cuda.synchronize()
         ddt = time.perf_counter() - t0
-        assert (d_osz.cpu().numpy() == cs).all() and torch.equal(d_out, d_src), "decode of class %s" % name
-        out[name]["decode GiB/s"] = round(nbytes * k / ddt / (1 << 30), 1)
-        del d_src
-    return {"per_class": out, "note": "%d x %d B chunks per class (1 MiB of the class tiled to %d MiB; period1000: one random 1000-byte string repeated), level %d, %d steps after one warm-up; decode: the frames just built, decoded back in one call and compared with the input"
-            % (n, cs, nbytes >> 20, args.level, 5)}
+        assert (d_osz.cpu().numpy() == fs).all() and torch.equal(d_out, d_in), "decode of class %s" % name
+        out[name]["decode GiB/s"] = round(nf * fs * kd / ddt / (1 << 30), 1)
+        del d_in, d_one
+    return {"per_class": out, "class_generation_s": gen_s,
+            "note": "compress: %d x %d B chunks per class, level %d, 5 steps after one warm-up; decode: %d frames of %d B of the class built by this codec, one call a step, 3 steps after "
+                    "one warm-up, output compared with the input; each class is distinct_bytes of distinct data (generators of tests/_corpus.py in 1 MiB segments, the file classes as much as "
+                    "the box holds) tiled on the device to the batch; zeros: all-zero; period1000: one random 1000-byte string repeated" % (n, cs, args.level, nf, fs)}
 
 
 def libzstd_frames_decode(bc, args, torch, host, nf, fs):
@@ -320,13 +340,17 @@ def main():
     ap.add_argument("--decode-frames", type=int, default=57344, help="frames of --decode-frame-size bytes decoded per step of the decode leg (0: no decode leg)")
     ap.add_argument("--decode-frame-size", type=int, default=32768)
     ap.add_argument("--no-extras", action="store_true", help="skip ratio_by_class and libzstd_yardstick")
+    ap.add_argument("--class-bytes", type=int, default=64 << 20, help="distinct bytes per data class of throughput_by_class")
     ap.add_argument("--dry-run-gloo", action="store_true", help="CPU rehearsal of the launch path: gloo process group, no GPU work; prints the ranks that ran")
     args = ap.parse_args()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))
 
-    import torch
     rank = int(os.environ.get("RANK", "0")); local_rank = int(os.environ.get("LOCAL_RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
+    class_data, class_gen_s = (None, 0.0)
+    if rank == 0 and not args.no_extras and not args.dry_run_gloo:
+        class_data, class_gen_s = class_corpus(args)          # (a pool of forked processes: before torch / HIP are initialised)
+    import torch
     assert world == args.gpus or (args.gpus == 1 and args.force_dist), f"--gpus {args.gpus} but WORLD_SIZE={world}: launch one rank per GPU"
     distributed = world > 1 or args.force_dist
     if args.dry_run_gloo:
@@ -528,7 +552,7 @@ def main():
         if decode:
             out["decode"] = decode
         if not args.no_extras:
-            out["throughput_by_class"] = throughput_by_class(bc, args, torch)
+            out["throughput_by_class"] = throughput_by_class(bc, args, torch, class_data, class_gen_s)
         Z = O.libzstd()
         if Z and not args.no_extras:
             # the ratio contract per data class (tests/_corpus.py), HIP encoder vs upstream libzstd at this level and chunk size

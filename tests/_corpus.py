@@ -184,3 +184,33 @@ def corpus(nbytes=DEFAULT_BYTES):
         if len(b) >= 65536:
             out[k] = b
     return out
+
+
+_SEEDED = {"json": (json_records, 11), "jsonflat": (json_flat, 21), "repetitive": (repetitive, 22), "csv": (csv_records, 12), "xml": (xml_records, 13)}
+
+
+def _segment(job):
+    name, k, seg = job
+    f, seed = _SEEDED[name]
+    return f(seg, seed=seed + 1000 * k)
+
+
+def corpus_distinct(nbytes=64 << 20, workers=8, seg=1 << 20):
+    """name -> bytes with (up to) `nbytes` of DISTINCT data per class, for throughput numbers whose source must not sit in a cache: the record
+    generators run as independent segments of `seg` bytes (seed + 1000 k) on a pool of processes (started by fork: call this BEFORE the GPU is
+    touched), the Zipf log and the binary table at full size, the file classes (Python sources, C headers, ELF, libamdhip64.so) as much as the box holds."""
+    import multiprocessing as mp
+    out = {}
+    nseg = (nbytes + seg - 1) // seg
+    jobs = [(name, k, seg) for name in _SEEDED for k in range(nseg)]
+    with mp.get_context("fork").Pool(max(1, workers)) as pool:
+        parts = pool.map(_segment, jobs, chunksize=1)
+    for i, name in enumerate(_SEEDED):
+        out[name] = b"".join(parts[i * nseg:(i + 1) * nseg])[:nbytes]
+    out["zipf"] = D.zipf_log(nbytes, seed_lo=0xC1A55).tobytes()
+    out["bintable"] = binary_table(nbytes)
+    for name, f in (("pysrc", pysrc), ("cheaders", cheaders), ("elf", elf), ("hipso", hipso)):
+        b = f(nbytes)
+        if len(b) >= 65536:
+            out[name] = b
+    return {k: out[k] for k in CLASSES if k in out}

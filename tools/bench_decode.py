@@ -12,6 +12,7 @@ import _data as D, _oracle as O
 ap = argparse.ArgumentParser(); ap.add_argument("--frames", type=int, default=57344); ap.add_argument("--chunk", type=int, default=32768)
 ap.add_argument("--steps", type=int, default=5); ap.add_argument("--warmup", type=int, default=2)
 ap.add_argument("--libzstd", action="store_true", help="frames built by upstream libzstd (level 3) on the host instead of this codec's encoder")
+ap.add_argument("--no-kernel-timing", action="store_true", help="with --times-only: no events around the launches, the step time alone")
 ap.add_argument("--times-only", action="store_true", help="per-kernel times, no output check, no CPU leg (timing-aid builds: ZSMI_LIB_FILE)"); a = ap.parse_args()
 n, cs = a.frames, a.chunk
 host = D.zipf_log(n * cs, threads=32)
@@ -34,7 +35,7 @@ else:
 d_out = torch.empty(n * cs, dtype=torch.uint8, device="cuda"); d_osz = torch.zeros(n, dtype=torch.int32, device="cuda")
 def step(): bc.decompress_device(d_frames.data_ptr(), foffs, fsz, d_out.data_ptr(), offs, sizes, d_osz.data_ptr())
 for _ in range(a.warmup): step()
-torch.cuda.synchronize(); bc.enable_timing(True); t0 = time.perf_counter()
+torch.cuda.synchronize(); bc.enable_timing(not a.no_kernel_timing); t0 = time.perf_counter()
 for _ in range(a.steps): step()
 torch.cuda.synchronize(); dt = time.perf_counter() - t0
 kt = bc.kernel_times()

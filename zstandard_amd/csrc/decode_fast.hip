@@ -346,17 +346,15 @@ template <bool FLAT, uint32_t G>
 struct HufLds { uint16_t huf[G][FLAT ? (1u << ZS_FAST_HUFLOG) : ZS_HUF2_ENTRIES]; uint32_t win[4 * G][(ZS_FAST_HUFWIN + 8) / 4 + 2]; };
 
 template <bool FLAT, uint32_t G>
-__global__ void __launch_bounds__(64)
-k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
+__device__ __forceinline__ void zs_dec_huffman_body(HufLds<FLAT, G> &H, const uint32_t bid, const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
               const uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ litScratchAll, uint32_t nBlk, uint32_t cap, uint32_t litStride)
 {
-    __shared__ __attribute__((aligned(16))) HufLds<FLAT, G> H;
     const uint32_t lane = (uint32_t)zs_lane();
     const uint32_t g = lane >> 2, k = lane & 3u;
     // one launch for every block index of the call (nBlk of them): the grid is nBlk runs of the items' groups - blocks decode independently of
     // each other, and a launch per block index was a launch of few wavefronts each when the items are large frames (r3: 16 launches -> 1)
     const uint32_t groupsPerBlk = (nItems + G - 1) / G;
-    const uint32_t blk = blockIdx.x / groupsPerBlk, bx = blockIdx.x - blk * groupsPerBlk;
+    const uint32_t blk = bid / groupsPerBlk, bx = bid - blk * groupsPerBlk;
     (void)nBlk;
     const uint32_t item = bx * G + g;
     bool mine = false; uint32_t dtLog = 1, n = 0, size = 0;
@@ -467,20 +465,18 @@ struct SeqDecLds { uint16_t cells[G][(LOG9 ? 1280 : 768)]; uint32_t win[G][(ZS_F
 // ---------------------------------------------------------------------------------------------------------------------
 #define ZS_QUAD(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true))      // (bound_ctrl: no "old" value to set up; a quad_perm reads valid lanes only)
 template <bool LOG9, uint32_t G>
-__global__ void __launch_bounds__(64)
-k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
+__device__ __forceinline__ void zs_dec_sequences_body(SeqDecLds<LOG9, G> &S, const uint32_t bid, const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
                   const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t nBlk, uint32_t cap, const uint32_t *__restrict__ seqLists, uint32_t seqCap)
 {
     // the blocks of this table class, listed by k_dec_prep (every block index of the call in one launch: blocks decode independently)
     const uint32_t listed = seqLists[LOG9 ? 1 : 0];
-    if (blockIdx.x * G >= listed) return;
+    if (bid * G >= listed) return;
     const uint32_t *list = seqLists + 2 + (LOG9 ? (size_t)cap * nBlk : 0);
     static_assert(G <= 16, "four lanes an item");
-    __shared__ __attribute__((aligned(16))) SeqDecLds<LOG9, G> S;
     constexpr uint32_t LLC = LOG9 ? 512 : 256, OFB = LLC, MLB = LLC + 256;        // cells of the LL table; where OF and ML start
     const uint32_t lane = (uint32_t)zs_lane();
     const uint32_t g = lane >> 2, r = lane & 3u;
-    const uint32_t v = blockIdx.x * G + g;
+    const uint32_t v = bid * G + g;
     const uint32_t slot = (g < G && v < listed) ? list[v] : 0u;                 // block index * cap + item
     const uint32_t item = slot % cap;
     bool mine = false; uint32_t nbSeq = 0, size = 0, llLog = 0, ofLog = 0, mlLog = 0;
@@ -724,6 +720,42 @@ __device__ __forceinline__ void execTileMatchesFast(uint32_t mdst, uint32_t ml, 
         }
     }
 }
+
+// the kernels over the two bodies: each class of the Huffman and of the sequences decoding as a launch of its own ...
+template <bool FLAT, uint32_t G>
+__global__ void __launch_bounds__(64)
+k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
+              const uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ litScratchAll, uint32_t nBlk, uint32_t cap, uint32_t litStride)
+{
+    __shared__ __attribute__((aligned(16))) HufLds<FLAT, G> H;
+    zs_dec_huffman_body<FLAT, G>(H, blockIdx.x, srcAll, items, nItems, descs, hufTabs, litScratchAll, nBlk, cap, litStride);
+}
+template <bool LOG9, uint32_t G>
+__global__ void __launch_bounds__(64)
+k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
+                const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t nBlk, uint32_t cap, const uint32_t *__restrict__ seqLists, uint32_t seqCap)
+{
+    __shared__ __attribute__((aligned(16))) SeqDecLds<LOG9, G> S;
+    zs_dec_sequences_body<LOG9, G>(S, blockIdx.x, srcAll, items, nItems, descs, seqTabs, seqOutAll, nBlk, cap, seqLists, seqCap);
+}
+// ... and ALL FOUR as one launch, for calls of a round of workgroups or less (<= ~16 K blocks): there each of the four is as long as one item's
+// chain whatever the call's size (0.46 + 0.49 ms at 8192 frames of 32 KiB, the CUs at two wavefronts each), and the Huffman and the sequence
+// streams do not depend on each other - side by side they take the longer chain's time.  (Two streams for the same: 0.4 ms SLOWER, the
+// cross-stream waits cost more than the overlap brought.)  The grid is the four grids one behind the other; the LDS is the largest of the four
+// images (45 KiB: fewer workgroups a CU than the Huffman kernel's 30 KiB allows, which is why large calls keep the separate launches).
+__global__ void __launch_bounds__(64)
+k_dec_entropy(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
+              const uint8_t *__restrict__ hufTabs, uint8_t *__restrict__ litScratchAll, const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll,
+              uint32_t nBlk, uint32_t cap, const uint32_t *__restrict__ seqLists, uint32_t litStride, uint32_t seqCap, uint32_t gridH0, uint32_t gridH1, uint32_t gridS0)
+{
+    __shared__ __attribute__((aligned(16))) union U_ { HufLds<false, ZS_FAST_GROUP> h0; HufLds<true, 8u> h1; SeqDecLds<false, ZS_FAST_SEQGROUP_SMALL> s0; SeqDecLds<true, 4u> s1; } U;
+    const uint32_t b = blockIdx.x;
+    if (b < gridH0) zs_dec_huffman_body<false, ZS_FAST_GROUP>(U.h0, b, srcAll, items, nItems, descs, hufTabs, litScratchAll, nBlk, cap, litStride);
+    else if (b < gridH0 + gridH1) zs_dec_huffman_body<true, 8u>(U.h1, b - gridH0, srcAll, items, nItems, descs, hufTabs, litScratchAll, nBlk, cap, litStride);
+    else if (b < gridH0 + gridH1 + gridS0) zs_dec_sequences_body<false, ZS_FAST_SEQGROUP_SMALL>(U.s0, b - gridH0 - gridH1, srcAll, items, nItems, descs, seqTabs, seqOutAll, nBlk, cap, seqLists, seqCap);
+    else zs_dec_sequences_body<true, 4u>(U.s1, b - gridH0 - gridH1 - gridS0, srcAll, items, nItems, descs, seqTabs, seqOutAll, nBlk, cap, seqLists, seqCap);
+}
+
 
 // ---------------------------------------------------------------------------------------------------------------------
 // k_dec_execute : one wavefront per item: pass A over the decoded sequences (64 at a time), the block's literals, its matches; size check.
