@@ -804,7 +804,7 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
     uint8_t *litBuf = litScratchAll + slot * litStride;
     const uint8_t *litPtr = litBuf;
     if (d.litType == 0) litPtr = srcAll + it.srcOff + d.litSrc;
-    else if (d.litType == 1) { for (uint32_t j = lane; j < d.litSize; j += 64) litBuf[j] = (uint8_t)d.litSrc; wave_mem_sync(); }
+    else if (d.litType == 1 && d.nbSeq != 0) { for (uint32_t j = lane; j < d.litSize; j += 64) litBuf[j] = (uint8_t)d.litSrc; wave_mem_sync(); }
     ZsFastSeq *seqs = seqAll + slot * seqCap;                           // (pass A writes each sequence back in place)
     const uint8_t *bits = srcAll + it.srcOff + d.seqOff;                        // the sequence bitstream, d.seqSize bytes
     // the 64 stream bits below bit position p, top aligned (bit p - 1 at bit 63); bits below the stream start read as 0
@@ -936,6 +936,19 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
             wave_mem_sync();                                              // pass A's records are read back below
             // ---- the literals: window by window a bit per output byte, toggled at the ends of every match (clipped to the window), prefix xor =
             //      inside a match; then 16 output bytes a lane and round: the next popcount(literal bits) literals, spread by v_perm ----
+            if (d.nbSeq == 0) {
+                // a block of literals only (a raw or RLE block, a compressed block without sequences): a straight copy / fill, 16 bytes a lane and round
+                // (round 4: frames of raw / RLE blocks only are on this path - BASELINE config 1's 1 MiB of zeros is 16 RLE blocks)
+                uint8_t *o = dstBase + blockStart;
+                const uint64_t fill = 0x0101010101010101ull * (uint64_t)(d.litSrc & 0xFFu);
+                for (uint32_t j = 16 * lane; j < lastLL; j += 1024) {
+                    if (j + 16 <= lastLL) {
+                        uint64_t A = fill, B = fill;
+                        if (d.litType != 1) { A = zs_load64(litPtr + j); B = zs_load64(litPtr + j + 8); }
+                        __builtin_memcpy(o + j, &A, 8); __builtin_memcpy(o + j + 8, &B, 8);
+                    } else for (uint32_t q = j; q < lastLL; q++) o[q] = (d.litType == 1) ? (uint8_t)d.litSrc : litPtr[q];
+                }
+            } else
 #if defined(ZS_EXEC_STOP) && ZS_EXEC_STOP == 1
             if (0)                                                        // timing aid: pass A only
 #endif
