@@ -259,7 +259,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
 // entropy kernels read: seqAll[block][64 output ranges][256 records] + hdrAll (nseq, trailing, litSum, first = 0).
 // ---------------------------------------------------------------------------------------------
 #ifndef ZS_WALK_MASK
-#define ZS_WALK_MASK 1             // 1: lanes without a candidate / walkers at rest take no part in the step's LDS reads
+#define ZS_WALK_MASK 2             // lanes without a candidate, walkers at rest: 0 read along, 1 masked out of the LDS reads (branches), 2 read their own exchange slot (no branch, no conflict)
 #endif
 #ifndef ZS_WALK_MINW
 #define ZS_WALK_MINW 1             // waves per SIMD the small-unit kernel is compiled for (register budget)
@@ -363,7 +363,8 @@ __device__ __forceinline__ uint32_t zs_nonzero8(const uint4 d)
 {
     typedef uint16_t u16x2 __attribute__((ext_vector_type(2)));
     const u16x2 one = { 1, 1 };
-    auto nz = [&](uint32_t w) { return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_bit_cast(u16x2, w), one)); };   // v_pk_min_u16: 1 per half that is not zero
+    (void)one;
+    auto nz = [&](uint32_t w) { uint32_t r; asm("v_pk_min_u16 %0, %1, %2" : "=v"(r) : "v"(w), "v"(0x00010001u)); return r; };   // 1 per half that is not zero (asked for by name: the generic form became compares, selects and v_perm, ~25 instructions a group of 8)
     const uint32_t v = nz(d.x) | (nz(d.y) << 2) | (nz(d.z) << 4) | (nz(d.w) << 6);       // low halves at bits 0, 2, 4, 6; high halves at bits 16, 18, 20, 22
     return (v | (v >> 15)) & 0xFFu;
 }
@@ -408,6 +409,7 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
     const uint8_t *distHi = distHiAll + (size_t)slot * (ZS_BLOCK_MAX / 8);
     uint4 *xbuf = reinterpret_cast<uint4 *>(walkLds);                              // exchange buffer: wavefront w's region holds GPL x 64 slots of 8 distances: lane t's k-th group at [(64 w) GPL + 64 k + t]
     const uint32_t xw = (tid & ~63u) * GPL;                                      // my wavefront's first slot
+    const uint32_t safeAddr = (xw + lane) * 16u;                                 // LDS address of my own first slot: where a lane with nothing to read reads (its own banks, no conflict)
     uint32_t *queue = reinterpret_cast<uint32_t *>(walkLds + SRC + ZS_WALK_SRCBYTES(CAP));
     uint4 *res = resAll + (size_t)slot * ZS_RES_PER_BLOCK;                       // per walk range (R >= 256: at most 256 a block): records, last match end in its block, last offset
     uint8_t *xhi = reinterpret_cast<uint8_t *>(queue + 4);                        // BIG: lane t's byte of bit 16 of its 8 distances
@@ -542,12 +544,14 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
                 const uint32_t p0 = ip + sub * RPL;
                 constexpr int SP = (RPL + 3 + 3) / 4;                            // dwords that hold RPL + 3 bytes
                 uint32_t a[SP] = {}, b[SP] = {}, c[SP] = {};
-                // (lanes with nothing to try stay out of the reads: an LDS instruction costs what its busiest bank takes, and walkers at rest
-                // all sit at a range end - the same bank)
-                if (!ZS_WALK_MASK || t0 || t1) {
-                    lds_span<SP>(lpos(p0), a);
-                    lds_span<SP>(lpos(t0 ? p0 - rep0 : p0), b);
-                    lds_span<SP>(lpos(t1 ? p0 - rep1 : p0), c);
+                // (lanes with nothing to try stay out of the source's banks - an LDS instruction costs what its busiest bank takes, and walkers at rest
+                // all sit at a range end, the same bank - : ZS_WALK_MASK 1 by the exec mask (branches around the reads), 2 by reading their own
+                // slot of the exchange buffer instead (no branch: the reads of a step stay one batch))
+                if (ZS_WALK_MASK != 1 || t0 || t1) {
+                    const bool tr = ZS_WALK_MASK != 2 || t0 || t1;
+                    lds_span<SP>(tr ? lpos(p0) : safeAddr, a);
+                    lds_span<SP>(tr ? lpos(t0 ? p0 - rep0 : p0) : safeAddr, b);
+                    lds_span<SP>(tr ? lpos(t1 ? p0 - rep1 : p0) : safeAddr, c);
                 }
                 auto tryAt = [&](auto iTag) {
                     constexpr int I = decltype(iTag)::value;
@@ -582,34 +586,51 @@ k_lz_walk(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ units,
                 if constexpr ((((LPW - 1) * CPL) & 2) != 0 || (LPW == 4 && CPL == 2)) { uint32_t t = m & (m - 1); t &= t - 1; m = (skip & 2u) ? t : m; }
                 if constexpr ((CPL & 1) != 0) { const uint32_t t = m & (m - 1); m = (skip & 1u) ? t : m; }
             }
-            uint32_t idx[CPL], off[CPL]; bool have[CPL], isRep[CPL];
+            uint32_t idx[CPL], off[CPL], dv[CPL]; bool have[CPL], isRep[CPL];
             #pragma unroll
             for (uint32_t c = 0; c < CPL; c++) {
                 have[c] = m != 0;
                 idx[c] = have[c] ? (uint32_t)__builtin_ctz(m) : 0u;
                 m &= m - 1;
                 const uint32_t q = ip + idx[c];
-                const bool r0 = ((rm0 >> idx[c]) & 1u) != 0, r1 = ((rm1 >> idx[c]) & 1u) != 0;
-                isRep[c] = have[c] && (r0 || r1);
                 // the distance: group (q >> 3) - (ip >> 3) of the walker, that lane's slot of the exchange buffer (same wavefront: in order behind the stores above)
                 const uint32_t j = (q >> 3) - (ip >> 3);                         // its group: lane j % LPW of the walker, that lane's group j / LPW
                 const uint32_t owner = xw + 64u * (j / LPW) + (lane & ~(LPW - 1u)) + (j % LPW);
-                uint32_t d = reinterpret_cast<const uint16_t *>(xbuf + owner)[q & 7u];
-                if (BIG) d |= (((uint32_t)xhi[owner] >> (q & 7u)) & 1u) << 16;
-                off[c] = r0 ? rep0 : (r1 ? rep1 : d);
+                dv[c] = reinterpret_cast<const uint16_t *>(xbuf + owner)[q & 7u];
+                if (BIG) dv[c] |= (((uint32_t)xhi[owner] >> (q & 7u)) & 1u) << 16;
+            }
+            #pragma unroll
+            for (uint32_t c = 0; c < CPL; c++) asm volatile("" : "+v"(dv[c]));      // every candidate's distance is read before the first is used: one LDS round trip, not one a candidate
+            #pragma unroll
+            for (uint32_t c = 0; c < CPL; c++) {
+                const bool r0 = ((rm0 >> idx[c]) & 1u) != 0, r1 = ((rm1 >> idx[c]) & 1u) != 0;
+                isRep[c] = have[c] && (r0 || r1);
+                off[c] = r0 ? rep0 : (r1 ? rep1 : dv[c]);
                 if (!have[c]) off[c] = 0;
             }
             WPROF_STAMP(3)
             // ---- score: 8 bytes forward, 4 bytes backward, from LDS ----
             int bestKey = 0; uint32_t bestPack = 0, bestOff = 0;
+            uint32_t sa[CPL][3], sb[CPL][3];                                     // bytes [q - 4, q + 8) of both sides, every candidate's requested before the first is looked at
             #pragma unroll
             for (uint32_t c = 0; c < CPL; c++) {
                 const uint32_t q = ip + idx[c];
-                uint32_t a[3] = {}, b[3] = {};                                   // bytes [q - 4, q + 8) of both sides
-                if (!ZS_WALK_MASK || have[c]) {
-                    lds_span<3>(lpos(q - 4), a);
-                    lds_span<3>(lpos(q - off[c] - 4), b);
+                #pragma unroll
+                for (int k = 0; k < 3; k++) { sa[c][k] = 0; sb[c][k] = 0; }
+                if (ZS_WALK_MASK != 1 || have[c]) {
+                    const bool tr = ZS_WALK_MASK != 2 || have[c];
+                    lds_span<3>(tr ? lpos(q - 4) : safeAddr, sa[c]);
+                    lds_span<3>(tr ? lpos(q - off[c] - 4) : safeAddr, sb[c]);
                 }
+            }
+            if (ZS_WALK_MASK != 1) {
+                #pragma unroll
+                for (uint32_t c = 0; c < CPL; c++) asm volatile("" : "+v"(sa[c][0]), "+v"(sa[c][1]), "+v"(sa[c][2]), "+v"(sb[c][0]), "+v"(sb[c][1]), "+v"(sb[c][2]));
+            }
+            #pragma unroll
+            for (uint32_t c = 0; c < CPL; c++) {
+                const uint32_t q = ip + idx[c];
+                const uint32_t (&a)[3] = sa[c], (&b)[3] = sb[c];
                 const uint32_t xb = a[0] ^ b[0], x0 = a[1] ^ b[1], x1 = a[2] ^ b[2];
                 const uint32_t f0 = x0 ? (uint32_t)__builtin_ctz(x0) : 32u, f1 = x1 ? (uint32_t)__builtin_ctz(x1) : 32u;
                 const uint32_t fwd = min(((x0 ? f0 : 32u + f1)) >> 3, limit - q);
