@@ -120,7 +120,9 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
         for (uint32_t uu = 0; uu < H; uu++) {
             const uint32_t dm = (NT > 1) ? (mL[uu] ? mL[uu] : mS[uu]) : mS[uu];
             if (BIG) { const uint64_t hi = __ballot((dm >> 16) != 0); if (lane == uu) hiMine = hi; }
-            found += (uint32_t)__popcll(__ballot(dm != 0 && sbase + uu * 64 + lane < hashable));
+            // (only a unit's last group reaches behind the hashable positions: the test is uniform for every other)
+            if ((g + 1u) * GP <= hashable) found += (uint32_t)__popcll(__ballot(dm != 0));
+            else found += (uint32_t)__popcll(__ballot(dm != 0 && sbase + uu * 64 + lane < hashable));
             dist[sbase + uu * 64 + lane] = (uint16_t)dm;
         }
         if (BIG && lane < H) *reinterpret_cast<uint64_t *>(distHi + ((sbase + lane * 64) >> 3)) = hiMine;
@@ -282,7 +284,9 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
 // nearly the same offset inside ranges that are 256 bytes apart - bank (a / 4) mod 32 made every "own side" read of a step a 4 - 16-way
 // conflict (tools/lab/lds_sim.c prices the kernel's reads with the bank rules: 309 LDS cycles a wave step, measured 293; with the skew
 // and idle lanes masked 171).  24 bytes = 6 banks a row: 16 walkers (32 lanes = a dword-read group) land on 16 different bank pairs.
+#ifndef ZS_WALK_SKEW
 #define ZS_WALK_SKEW  24u
+#endif
 #define ZS_WALK_FRONT 48u          // row -1 of the staged source: 24 zero bytes (positions -24 .. -1: backward reads near position 0) + the copy of row 0's head
 #define ZS_WALK_TAIL  144u         // zero bytes behind the unit (forward reads near the end)
 #define ZS_WALK_SRCBYTES(CAPB) ((((CAPB) + ZS_WALK_TAIL + ZS_WALK_SKEW * (((CAPB) + ZS_WALK_TAIL) / 256u + 1u)) + 15u) & ~15u)
