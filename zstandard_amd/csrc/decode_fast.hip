@@ -1034,7 +1034,7 @@ k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// k_dec_checksum : lane = item.  Items the fast kernels decoded and whose frame carries a content checksum: XXH64 of the
+// k_dec_checksum : four lanes an item (round 3: one).  Items the fast kernels decoded and whose frame carries a content checksum: XXH64 of the
 // output, low 32 bits against the stored value (ZStdDecompress.cs:2076-2083); a mismatch is the item's result (checksum_wrong).
 // Launched only when a call's frames may carry checksums; items without one cost their lane a flag read.
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1042,12 +1042,13 @@ __global__ void __launch_bounds__(64)
 k_dec_checksum(const ZsDecItem *__restrict__ items, uint32_t nItems, const ZsFastDesc *__restrict__ descs, const uint8_t *__restrict__ dstAll,
                uint32_t *__restrict__ dstSizes)
 {
-    const uint32_t item = blockIdx.x * 64 + threadIdx.x;
-    if (item >= nItems) return;
+    // four lanes an item (round 4): XXH64's four stripe accumulators side by side
+    const uint32_t item = min(blockIdx.x * 16 + (threadIdx.x >> 2), nItems - 1u);
+    const bool real = blockIdx.x * 16 + (threadIdx.x >> 2) < nItems;
     const ZsFastDesc *d = descs + item;
-    if (!d->fast || !d->hasChecksum) return;
-    const uint32_t size = dstSizes[item];
-    if (size > 0xFFFFFF88u) return;
-    const uint64_t h = xxh64(dstAll + items[item].dstOff, size);
-    if ((uint32_t)h != d->checksum) dstSizes[item] = ZE(E_checksum_wrong);
+    uint32_t size = (real && d->fast && d->hasChecksum) ? dstSizes[item] : 0xFFFFFFFFu;
+    const bool work = size <= 0xFFFFFF88u;
+    if (!__ballot(work)) return;
+    const uint64_t h = xxh64_quad(dstAll + items[item].dstOff, work ? size : 0u);     // (whole quads take part: a quad without work hashes nothing)
+    if (work && (threadIdx.x & 3u) == 0 && (uint32_t)h != d->checksum) dstSizes[item] = ZE(E_checksum_wrong);
 }

@@ -751,6 +751,38 @@ __device__ static uint64_t xxh64(const uint8_t *p, uint64_t len)
     return h64;
 }
 
+// The same by FOUR lanes (a quad of the wavefront, r = lane & 3): the stripe loop is four independent accumulators, lane r runs the r-th (the 8 bytes at 8 r of
+// every 32-byte stripe), the quad's first lane merges them and finishes the tail.  Every lane of the quad must call; the result is valid in its first lane.
+// (k_dec_checksum hashed an item's whole output on one lane: 1 MiB frames are 32768 dependent rounds there.)
+__device__ __forceinline__ uint64_t xxh64_quad(const uint8_t *p, uint64_t len)
+{
+    const uint64_t P1 = 11400714785074694791ULL, P2 = 14029467366897019727ULL, P3 = 1609587929392839161ULL, P4 = 9650029242287828579ULL, P5 = 2870177450012600261ULL;
+    const uint32_t r = (uint32_t)zs_lane() & 3u;
+    const uint8_t *const bEnd = p + len; uint64_t h64 = P5;
+    #define XXR(acc, in) { acc += (in) * P2; acc = rotl64(acc, 31); acc *= P1; }
+    const uint64_t stripes = len >> 5;
+    if (stripes) {
+        uint64_t v = r == 0 ? P1 + P2 : (r == 1 ? P2 : (r == 2 ? 0ull : 0ull - P1));
+        const uint8_t *q = p + 8u * r;
+        for (uint64_t i = 0; i < stripes; i++) { XXR(v, zs_load64(q)); q += 32; }
+        const int base = zs_lane() & ~3;
+        uint64_t vv[4];
+        #pragma unroll
+        for (int k = 0; k < 4; k++) vv[k] = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), base + k) << 32) | (uint32_t)__shfl((int)(uint32_t)v, base + k);
+        h64 = rotl64(vv[0], 1) + rotl64(vv[1], 7) + rotl64(vv[2], 12) + rotl64(vv[3], 18);
+        #pragma unroll
+        for (int k = 0; k < 4; k++) { uint64_t t_ = 0; XXR(t_, vv[k]); h64 ^= t_; h64 = h64 * P1 + P4; }
+        p += stripes << 5;
+    }
+    h64 += len;
+    while (p + 8 <= bEnd) { uint64_t k1 = 0; XXR(k1, zs_load64(p)); h64 ^= k1; h64 = rotl64(h64, 27) * P1 + P4; p += 8; }
+    if (p + 4 <= bEnd) { h64 ^= (uint64_t)zs_load32(p) * P1; h64 = rotl64(h64, 23) * P2 + P3; p += 4; }
+    while (p < bEnd) { h64 ^= (*p) * P5; h64 = rotl64(h64, 11) * P1; p++; }
+    #undef XXR
+    h64 ^= h64 >> 33; h64 *= P2; h64 ^= h64 >> 29; h64 *= P3; h64 ^= h64 >> 32;
+    return h64;
+}
+
 struct DState { uint32_t rep[3]; uint32_t litEntropy, fseEntropy; uint32_t llRepeatOk; uint32_t hufX4; };   // hufX4: the reference built the current Huffman table for its double-symbol decoder
 
 // ---- one tile of <= 64 decoded sequences (L.u.sq.tile*) -> output bytes.  Returns 0 or an error; advances op / litPos. ----
@@ -1288,7 +1320,7 @@ __device__ __forceinline__ void zs_decode_item(DLds &L, const uint32_t item, con
         if (fcs != ~0ull && (op - frameStart) != fcs) DONE(ZE(E_corruption_detected));
         if (checksumFlag) {
             if (srcSize - ipos < 4) DONE(ZE(E_checksum_wrong));
-            if (lane == 0) L.misc[2] = (uint32_t)xxh64(dstBase + frameStart, op - frameStart);
+            { const uint64_t hq = xxh64_quad(dstBase + frameStart, op - frameStart); if (lane == 0) L.misc[2] = (uint32_t)hq; }     // (every lane calls: the quads hash the same bytes, lane 0's counts)
             wave_sync();
             if (rd32(src + ipos) != L.misc[2]) DONE(ZE(E_checksum_wrong));
             ipos += 4;

@@ -507,7 +507,7 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
             else
                 LAUNCH(c, "k_dec_execute", (k_dec_execute<4, 6>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (ZsFastSeq *)c->dSeqOut.p,
                        (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap, descSlots, litStride, seqCap);
-            LAUNCH(c, "k_dec_checksum", k_dec_checksum, dim3((cnt + 63) / 64), dim3(64), 0, dI, cnt, (const ZsFastDesc *)dD, (const uint8_t *)dDst, dDstSizes + i0);
+            LAUNCH(c, "k_dec_checksum", k_dec_checksum, dim3((cnt + 15) / 16), dim3(64), 0, dI, cnt, (const ZsFastDesc *)dD, (const uint8_t *)dDst, dDstSizes + i0);
             doneFlags = &dD->fast;
         }
         // the general kernel: a pool of wavefronts over a queue - of every item, or (behind the fast path) of the list of the items it left
