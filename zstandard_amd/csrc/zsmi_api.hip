@@ -481,8 +481,10 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
             {   // every block index of the items in one launch per kernel class (the grid: maxBlocks runs of the items' groups; a wavefront whose items
                 // have no such block leaves at once)
                 const uint32_t mb = maxBlocks, vcnt = cnt * mb;                 // (item, block) pairs: what a launch's rounds of workgroups count
-                if (vcnt <= c->decodeFuseBelow) {
-                    // a round of workgroups or less: the four entropy launches as one (k_dec_entropy), the 2.5 KiB sequence class at 4 items a wavefront as below
+                if (vcnt <= c->decodeFuseBelow && mb == 1) {
+                    // a round of workgroups or less of one-block items: the four entropy launches as one (k_dec_entropy), the 2.5 KiB sequence class at 4 items a wavefront as below
+                    // (items of several blocks - 128 KiB frames: 64 KiB blocks, the 2.5 KiB table class at 16 a wavefront - keep the separate launches: 8192 two-block frames of text
+                    //  decoded at 100 GiB/s fused against 135 apart)
                     const uint32_t gH0 = groups * mb, gH1 = ((cnt + 7) / 8) * mb, gS0 = ((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL) * mb, gS1 = ((cnt + 3) / 4) * mb;
                     LAUNCH(c, "k_dec_entropy", k_dec_entropy, dim3(gH0 + gH1 + gS0 + gS1), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p,
                            (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists, litStride, seqCap, gH0, gH1, gS0);
