@@ -281,11 +281,11 @@ def decode_leg(bc, args, rank, world, distributed, barrier, torch, dist):
             "frac": round(per_launch / (secs / launches) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None, "algorithmic_bytes_per_launch": int(per_launch),
             "avg_launch_ms": round(secs / launches * 1e3, 4), "kernels_ms_per_step": {k: round(v[0] / args.steps * 1e3, 4) for k, v in kt_all.items()}}
     try:                                            # HBM bytes per launch of the dominant kernel from the committed PMC passes, scaled to this launch size
-        tjf = json.load(open(os.path.join(ROOT, "profiles", "r3_decode_traffic.json")))
+        tjf = json.load(open(os.path.join(ROOT, "profiles", "r4_decode_traffic.json")))
         if tjf.get("kernel_source_sha256") == source_fingerprint() and name in tjf["kernels"]:
             roof["traffic"] = int(tjf["kernels"][name]["hbm_bytes"] * nf / tjf["kernels"][name]["frames_per_launch"])
         else:
-            roof["traffic_note"] = "profiles/r3_decode_traffic.json was measured at other kernel sources (%s): not reported" % tjf.get("kernel_source_sha256")
+            roof["traffic_note"] = "profiles/r4_decode_traffic.json was measured at other kernel sources (%s): not reported" % tjf.get("kernel_source_sha256")
     except Exception as e:
         roof["traffic_note"] = "no traffic file: %s" % type(e).__name__
     out = {"metric": f"GiB/s decompress (output bytes), frames of {fs} B", "value": round(nf * fs * world * args.steps / elapsed / (1 << 30), 3), "unit": "GiB/s",
@@ -493,9 +493,9 @@ def main():
             # The file names the kernel sources it was measured at: other sources -> null.
             traffic = None; traffic_note = None
             try:
-                tjf = json.load(open(os.path.join(ROOT, "profiles", "r3_traffic.json")))
+                tjf = json.load(open(os.path.join(ROOT, "profiles", "r4_traffic.json")))
                 if tjf.get("kernel_source_sha256") != source_fingerprint():
-                    traffic_note = "profiles/r3_traffic.json was measured at other kernel sources (%s): not reported" % tjf.get("kernel_source_sha256")
+                    traffic_note = "profiles/r4_traffic.json was measured at other kernel sources (%s): not reported" % tjf.get("kernel_source_sha256")
                 else:
                     tj = tjf["kernels"].get(name)
                     if tj:
