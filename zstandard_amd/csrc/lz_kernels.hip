@@ -110,7 +110,8 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
         #pragma unroll
         for (uint32_t uu = 0; uu < H; uu++) { mS[uu] = xb[uu * ROW]; mL[uu] = (NT > 1) ? xb[GR + uu * ROW] : 0u; }
     };
-    uint32_t found = 0;                                                 // mergers: candidate positions among this wavefront's steps
+    uint32_t found = 0;                                                 // mergers: candidate positions among this wavefront's steps (exact below matchlessBelow, which is all k_lz_walk asks)
+    const uint32_t matchlessBelow = n >> ZS_MATCHLESS_SHIFT;
     auto mergeStore = [&](uint32_t g, const uint32_t (&mS)[H], const uint32_t (&mL)[H]) {
         // bit 16 of the distances (big units): lane uu keeps step uu's word, so the plane takes one store of H * 8 contiguous bytes.
         // (What is stored for positions behind the hashable ones is never used: the walk cuts them off its window.)
@@ -120,9 +121,12 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
         for (uint32_t uu = 0; uu < H; uu++) {
             const uint32_t dm = (NT > 1) ? (mL[uu] ? mL[uu] : mS[uu]) : mS[uu];
             if (BIG) { const uint64_t hi = __ballot((dm >> 16) != 0); if (lane == uu) hiMine = hi; }
-            // (only a unit's last group reaches behind the hashable positions: the test is uniform for every other)
-            if ((g + 1u) * GP <= hashable) found += (uint32_t)__popcll(__ballot(dm != 0));
-            else found += (uint32_t)__popcll(__ballot(dm != 0 && sbase + uu * 64 + lane < hashable));
+            // (counted only until the unit cannot be matchless any more - on ordinary data that is its first group -; only a unit's last group reaches behind
+            //  the hashable positions: the test is uniform for every other)
+            if (found < matchlessBelow) {
+                if ((g + 1u) * GP <= hashable) found += (uint32_t)__popcll(__ballot(dm != 0));
+                else found += (uint32_t)__popcll(__ballot(dm != 0 && sbase + uu * 64 + lane < hashable));
+            }
             dist[sbase + uu * 64 + lane] = (uint16_t)dm;
         }
         if (BIG && lane < H) *reinterpret_cast<uint64_t *>(distHi + ((sbase + lane * 64) >> 3)) = hiMine;
