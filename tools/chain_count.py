@@ -6,7 +6,13 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _data as D
 from zstandard_amd import BatchCodec, _lib
 n, cs = 1024, 65536
-data = D.zipf_log(n * cs)
+cls = os.environ.get("CLS", "zipf")
+if cls == "zipf":
+    data = D.zipf_log(n * cs)
+else:
+    import _corpus as C
+    one = np.frombuffer(C.CLASSES[cls](16 << 20), dtype=np.uint8)
+    data = np.tile(one, (n * cs + len(one) - 1) // len(one))[:n * cs].copy()
 dsrc = torch.from_numpy(data).cuda()
 bc = BatchCodec(0); Z = _lib.lib()
 off = np.arange(n, dtype=np.uint64) * cs; sz = np.full(n, cs, dtype=np.uint32)
@@ -16,7 +22,7 @@ bc.compress_device(dsrc.data_ptr(), off, sz, ddst.data_ptr(), doff, dsz.data_ptr
 buf = np.zeros(n * 32, dtype=np.uint8)
 rc = Z.zsmi_dbg_copyScratch(bc.ctx, 3, buf.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(len(buf))); assert rc == 0, rc
 m = buf.view(np.uint32).reshape(n, 8)
-fails = m[:, 6] & 0xFFFF; rounds = m[:, 6] >> 16
+fails = m[:, 6] & 0xFFFF; rounds = m[:, 6] >> 16      # (fails: not counted by the kernel - lane 0's ballot; rounds of repair are)
 K = m[:, 7] & 0xFF; Sb = (m[:, 7] >> 8) & 0xFF; ns = m[:, 7] >> 16
-print("blocks", n, "K", np.bincount(K), "Sb mean", Sb.mean(), "nseq mean", ns.mean())
+print(cls, "blocks", n, "K", np.bincount(K), "Sb mean", Sb.mean(), "nseq mean", ns.mean())
 print("failed seams per block: mean %.2f max %d; repair rounds mean %.2f max %d; blocks with none: %d" % (fails.mean(), fails.max(), rounds.mean(), rounds.max(), (fails == 0).sum()))

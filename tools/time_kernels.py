@@ -10,7 +10,13 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import _data as D
 from zstandard_amd import BatchCodec, _lib
 n, cs, steps = 4096, 65536, 5
-data = D.zipf_log(n * cs)
+cls = os.environ.get("CLS", "zipf")          # a class of tests/_corpus.py (16 MiB of it, tiled) instead of the Zipf log
+if cls == "zipf":
+    data = D.zipf_log(n * cs)
+else:
+    import _corpus as C
+    one = np.frombuffer(C.CLASSES[cls](16 << 20), dtype=np.uint8)
+    data = np.tile(one, (n * cs + len(one) - 1) // len(one))[:n * cs].copy()
 dev = torch.device("cuda:0")
 dsrc = torch.from_numpy(data).to(dev)
 bc = BatchCodec(device=0); Z = _lib.lib()
@@ -21,4 +27,4 @@ for _ in range(2): bc.compress_device(dsrc.data_ptr(), off, sz, ddst.data_ptr(),
 bc.sync(); bc.enable_timing(True)
 for _ in range(steps): bc.compress_device(dsrc.data_ptr(), off, sz, ddst.data_ptr(), doff, dsz.data_ptr(), 3)
 bc.sync()
-print({k: round(v[0] / steps * 1e3, 4) for k, v in bc.kernel_times().items()})
+print(cls, {k: round(v[0] / steps * 1e3, 4) for k, v in bc.kernel_times().items()})
