@@ -1515,12 +1515,16 @@ k_encode_sequences(const ZsBlockDesc *__restrict__ blocks, uint32_t nBlocks, con
 #ifdef ZS_CHAIN_COUNT
                 if (lane == 0) metas[blk].pad[0] += (uint32_t)__popcll(__ballot(bad)) | (1u << 16);      // development aid: seams that failed / rounds of repair
 #endif
+                // (a repair is the chain run serially with one to three lanes: its wavefront issues ahead of the others on its SIMD, as the shared chain
+                //  wavefront of rounds 1 - 3 did)
+                __builtin_amdgcn_s_setprio(3);
                 if (bad) {
                     uint32_t dummy = 0;
                     state = prevExit;
                     runBlocks(firstOut, bEnd, firstOut, 0xFFFFFFFFu, state, dummy, bEnd - firstOut);
                     if (lastSeg && tail) runTail(state);
                 }
+                __builtin_amdgcn_s_setprio(0);
             }
         }
         #undef CHAIN_STEP
