@@ -648,3 +648,42 @@ def test_intended_shapes_stay_on_the_decode_fast_path():
     for label, (fast, n) in res.items():
         assert fast >= 0, (label, "wrong output")
         assert fast == n, (label, fast, n)
+
+
+def test_decode_scratch_follows_the_capacities_and_is_given_back():
+    """round 4: the fast path's slots are sized by the call's largest capacity (literals min(cap, 128 KiB), sequences cap / 3) and the general kernel's literal
+    buffers belong to a pool of wavefronts: a call with 32 KiB capacities holds far less than 263 KiB an item, a call with generous capacities more, and a
+    later small call gives the excess back (zsmi_decodeScratchBytes); the output is right every time"""
+    from zstandard_amd import BatchCodec
+    bc = BatchCodec()
+    try:
+        text = D.zipf_log(2048 * 32768, seed_lo=5).tobytes()
+        chunks = [text[i * 32768:(i + 1) * 32768] for i in range(2048)]
+        frames = _compress_many(bc, chunks, 3)
+        def scratch_after(caps):
+            out = _decompress_many(bc, frames, caps)
+            assert all(sz == 32768 and data == c for (sz, data), c in zip(out, chunks))
+            return int(bc.L.zsmi_decodeScratchBytes(bc.ctx))
+        small = scratch_after([32768] * 2048)
+        pool = 2048 * ((1 << 17) + 64)                                       # the general kernel's pool: at most one buffer a wavefront, never more wavefronts than items
+        assert small <= 2048 * 140 * 1024 + pool + (64 << 20), small            # ~125 KiB an item + pool (+ reserve slack); round 3: 263 KiB an item
+        big = scratch_after([1 << 20] * 2048)                                # generous capacities: slots for 16 blocks of 128 KiB
+        assert big > 4 * small, (small, big)
+        again = scratch_after([32768] * 2048)
+        assert again < big // 2, (big, again)                                # the excess went back
+    finally:
+        bc.close()
+
+
+def test_shutdown_releases_the_one_shot_contexts_and_they_come_back():
+    """zsmi_shutdown (for embedders that unload the library: nothing is released from an exit-time destructor) frees the per-device contexts of the
+    one-shot calls; the next one-shot call makes a new one"""
+    from zstandard_amd import ZStdDecompress, _lib
+    frame = open(os.path.join(D.GOLDEN, "csharp_alphabet.zst"), "rb").read()
+    want = open(os.path.join(D.GOLDEN, "csharp_alphabet.bin"), "rb").read()
+    for _ in range(2):
+        dst = bytearray(len(want))
+        assert ZStdDecompress.Decompress(dst, frame) == len(want) and bytes(dst) == want
+        _lib.lib().zsmi_shutdown()
+    dst = bytearray(len(want))
+    assert ZStdDecompress.Decompress(dst, frame) == len(want) and bytes(dst) == want
