@@ -15,7 +15,13 @@ ap.add_argument("--libzstd", action="store_true", help="frames built by upstream
 ap.add_argument("--no-kernel-timing", action="store_true", help="with --times-only: no events around the launches, the step time alone")
 ap.add_argument("--times-only", action="store_true", help="per-kernel times, no output check, no CPU leg (timing-aid builds: ZSMI_LIB_FILE)"); a = ap.parse_args()
 n, cs = a.frames, a.chunk
-host = D.zipf_log(n * cs, threads=32)
+cls = os.environ.get("CLS", "zipf")          # a class of tests/_corpus.py (32 MiB of it, tiled) instead of the Zipf log
+if cls == "zipf":
+    host = D.zipf_log(n * cs, threads=32)
+else:
+    import _corpus as C
+    one = np.frombuffer(C.CLASSES[cls](32 << 20), dtype=np.uint8)
+    host = np.tile(one, (n * cs + len(one) - 1) // len(one))[:n * cs].copy()
 bc = BatchCodec(0, torch.cuda.current_stream().cuda_stream)
 d_src = torch.from_numpy(host).cuda()
 bound = int(bc.L.zsmi_compressBound(cs)); stride = (bound + 255) // 256 * 256

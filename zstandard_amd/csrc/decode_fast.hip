@@ -466,11 +466,12 @@ struct SeqDecLds { uint16_t cells[G][(LOG9 ? 1280 : 768)]; uint32_t win[G][(ZS_F
 #define ZS_QUAD(v, ctrl) ((uint32_t)__builtin_amdgcn_update_dpp(0, (int)(v), (ctrl), 0xF, 0xF, true))      // (bound_ctrl: no "old" value to set up; a quad_perm reads valid lanes only)
 template <bool LOG9, uint32_t G>
 __device__ __forceinline__ void zs_dec_sequences_body(SeqDecLds<LOG9, G> &S, const uint32_t bid, const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-                  const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t nBlk, uint32_t cap, const uint32_t *__restrict__ seqLists, uint32_t seqCap)
+                  const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t nBlk, uint32_t cap, const uint32_t *__restrict__ seqLists, uint32_t seqCap,
+                  uint32_t listedMin = 0, uint32_t listedMax = 0xFFFFFFFFu)
 {
     // the blocks of this table class, listed by k_dec_prep (every block index of the call in one launch: blocks decode independently)
     const uint32_t listed = seqLists[LOG9 ? 1 : 0];
-    if (bid * G >= listed) return;
+    if (bid * G >= listed || listed < listedMin || listed >= listedMax) return;      // (listedMin / Max: the launch serves the class only when it holds that many blocks - the host cannot know)
     const uint32_t *list = seqLists + 2 + (LOG9 ? (size_t)cap * nBlk : 0);
     static_assert(G <= 16, "four lanes an item");
     constexpr uint32_t LLC = LOG9 ? 512 : 256, OFB = LLC, MLB = LLC + 256;        // cells of the LL table; where OF and ML start
@@ -733,10 +734,11 @@ k_dec_huffman(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
 template <bool LOG9, uint32_t G>
 __global__ void __launch_bounds__(64)
 k_dec_sequences(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,
-                const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t nBlk, uint32_t cap, const uint32_t *__restrict__ seqLists, uint32_t seqCap)
+                const uint8_t *__restrict__ seqTabs, ZsFastSeq *__restrict__ seqOutAll, uint32_t nBlk, uint32_t cap, const uint32_t *__restrict__ seqLists, uint32_t seqCap,
+                uint32_t listedMin, uint32_t listedMax)
 {
     __shared__ __attribute__((aligned(16))) SeqDecLds<LOG9, G> S;
-    zs_dec_sequences_body<LOG9, G>(S, blockIdx.x, srcAll, items, nItems, descs, seqTabs, seqOutAll, nBlk, cap, seqLists, seqCap);
+    zs_dec_sequences_body<LOG9, G>(S, blockIdx.x, srcAll, items, nItems, descs, seqTabs, seqOutAll, nBlk, cap, seqLists, seqCap, listedMin, listedMax);
 }
 // ... and ALL FOUR as one launch, for calls of a round of workgroups or less (<= ~16 K blocks): there each of the four is as long as one item's
 // chain whatever the call's size (0.46 + 0.49 ms at 8192 frames of 32 KiB, the CUs at two wavefronts each), and the Huffman and the sequence

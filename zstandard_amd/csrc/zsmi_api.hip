@@ -145,6 +145,7 @@ struct zsmi_ctx {
                                          // last round is mostly tail, so big launches pay (16384 frames of 32 KiB: 82 GiB/s, 57344: 104 GiB/s)
     PinBuf hItems2[2]; hipEvent_t hItemsEv[2] = { nullptr, nullptr }; bool hItemsBusy[2] = { false, false }; uint32_t decodeCalls = 0;    // the decode item list: two pinned buffers taken in turn
     DevBuf dPoolLit;                         // the general decode kernel's literal buffers: one per wavefront of its pool
+    uint32_t seqLog9Group = 0;               // experiment: force the 2.5 KiB sequence-table class to 16 or 4 items a wavefront (ZSMI_SEQ_LOG9_G; 0: the heuristic)
     uint32_t decodeFuseBelow = 24576;        // (item, block) pairs of a call up to which the entropy kernels are one launch (ZSMI_DEC_FUSE_BELOW; 0: never)
     uint32_t decodePool = 3072;              // wavefronts of that pool (ZSMI_DEC_POOL): the chip holds 10 a CU x 256
     size_t lastDecodeScratch = 0;            // bytes of scratch the last decode call needed (INTEGRATION.md states them)
@@ -200,6 +201,7 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     }
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_DEC_FAST")) c->decodeFast = atoi(e) != 0;
+    if (const char *e = getenv("ZSMI_SEQ_LOG9_G")) c->seqLog9Group = (uint32_t)atol(e);
     if (const char *e = getenv("ZSMI_DEC_FUSE_BELOW")) c->decodeFuseBelow = (uint32_t)atol(e);
     if (const char *e = getenv("ZSMI_DEC_POOL")) { long v = atol(e); if (v >= 2 && v <= (1 << 20)) c->decodePool = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_ITEMS_IN_FLIGHT")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->maxItemsInFlight = (uint32_t)v; }
@@ -491,16 +493,15 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
                 } else {
                     LAUNCH(c, "k_dec_huffman", (k_dec_huffman<false, ZS_FAST_GROUP>), dim3(groups * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, mb, cap, litStride);
                     LAUNCH(c, "k_dec_huffman", (k_dec_huffman<true, 8u>), dim3(((cnt + 7) / 8) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dHufTabs.p, (uint8_t *)c->dLitScratch.p, mb, cap, litStride);
-                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3(((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists, seqCap);
-                    // the 2.5 KiB table class: fuller wavefronts (16 items) win when a launch is several rounds of workgroups, emptier ones (4) when it
-                    // is less than one (8192 frames of 128 KiB: 83 vs 77 GiB/s; 16384: 117 vs 128)
-                    // (r3: and when 4 items a wavefront save a whole round of workgroups - 14 x 4 = 56 items a CU against 3 x 16 = 48 -: 57344 libzstd
-                    //  frames of 32 KiB are 4 rounds instead of 5, 3.8 vs 5.2 ms)
-                    const uint32_t rounds16 = (vcnt + 48u * 256u - 1) / (48u * 256u), rounds4 = (vcnt + 56u * 256u - 1) / (56u * 256u);
-                    if (vcnt >= ZS_FAST_SEQGROUP_MANY && rounds4 >= rounds16)
-                        LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, ZS_FAST_SEQGROUP>), dim3(((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists, seqCap);
-                    else
-                        LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, 4u>), dim3(((cnt + 3) / 4) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists, seqCap);
+                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<false, ZS_FAST_SEQGROUP_SMALL>), dim3(((cnt + ZS_FAST_SEQGROUP_SMALL - 1) / ZS_FAST_SEQGROUP_SMALL) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists, seqCap, 0u, 0xFFFFFFFFu);
+                    // the 2.5 KiB table class (blocks of > 2048 sequences: sources, tables, binaries at 32 KiB; the 64 KiB blocks of 128 KiB frames).  How many blocks of a call
+                    // are in it only the device knows (k_dec_prep's list), and it decides the shape: 16 items a wavefront when the class holds most of a large call (the
+                    // wavefront's instructions are what the kernel costs: 57344 frames of Python sources 4.00 -> 3.78 ms, of a binary table 4.99 -> 4.00), 4 a wavefront
+                    // when it is a fraction of it (libzstd's 32 KiB frames: 9 % of the blocks; fewer, emptier wavefronts finish sooner: 3.8 vs 5.2 ms) or the call is small.
+                    // Both shapes are launched; each looks at the list's length and leaves at once when the other one serves it.
+                    const uint32_t many = c->seqLog9Group == 16 ? 0u : (c->seqLog9Group == 4 ? 0xFFFFFFFFu : ZS_FAST_SEQGROUP_MANY);
+                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, ZS_FAST_SEQGROUP>), dim3(((cnt + ZS_FAST_SEQGROUP - 1) / ZS_FAST_SEQGROUP) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists, seqCap, many, 0xFFFFFFFFu);
+                    LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, 4u>), dim3(((cnt + 3) / 4) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists, seqCap, 0u, many);
                 }
             }
             if (maxBlocks == 1)
