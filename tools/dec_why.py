@@ -8,9 +8,9 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, torch
 import _corpus as C
 from zstandard_amd import BatchCodec, _lib
-cs, n = 65536, 4096
+cs, n = int(os.environ.get("CS", "65536")), int(os.environ.get("N", "4096"))
 bc = BatchCodec(0, torch.cuda.current_stream().cuda_stream); Z = _lib.lib()
-classes = dict(C.corpus(1 << 20))
+classes = dict(C.corpus(int(os.environ.get("BYTES", str(1 << 20)))))
 _lay = (ctypes.c_uint32 * 6)(); Z.zsmi_dbg_descLayout(_lay)
 DESC_WORDS, FAST_AT, WHY_AT, NBSEQ_AT, LITTYPE_AT, HUFLOG_AT = (int(x) for x in _lay)     # the library's own layout of a ZsFastDesc
 WHY = {0: "-", 1: "Huffman stream did not end exactly", 2: "sequence stream exhausted", 3: "offset code > 28", 4: "a sequence failed pass A's checks", 5: "last literals do not fit", 6: "content size differs", 7: "execute (other)"}

@@ -54,6 +54,8 @@ def main():
     run("own 128 KiB", [text[i * 40000:i * 40000 + 131072] for i in range(32)])
     run("own 1 MiB", [text[i * 70000:i * 70000 + (1 << 20)] for i in range(16)])
     run("own, raw and RLE blocks among compressed ones", [text[i * 50000:i * 50000 + 200000] + noise[i * 1000:i * 1000 + 70000] + bytes(70000) + text[:100000] for i in range(16)])
+    skew = np.minimum(rng.geometric(0.05, 1 << 20), 255).astype(np.uint8).tobytes()
+    run("own, compressed blocks of literals only (no sequences: Huffman pays, no match does)", [skew[i * 65536:(i + 1) * 65536] for i in range(16)])
     run("own, raw blocks only", [noise[i * 100:i * 100 + 65536] for i in range(16)])
     run("own, RLE blocks only: 1 MiB of zeros (BASELINE config 1)", [bytes(1 << 20)])
     run("own, raw blocks only, 300 KB", [noise[i * 100:i * 100 + 300000] for i in range(8)])

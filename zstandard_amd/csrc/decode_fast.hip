@@ -99,6 +99,8 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
     // descriptor fields go to global memory as they become known (lane 0), the fast flags last: nothing of a descriptor is kept in
     // registers (27 of them otherwise: the kernel's occupancy)
     #define DSET(field, value) do { if (lane == 0) dp->field = (value); } while (0)
+    uint32_t prepWhy = 0;                                      // source line of the test that left the fast path (ZsFastDesc.why = 1000 + line: tools/dec_why.py)
+    #define ZS_PREP_WHY(line) do { prepWhy = 1000u + (uint32_t)(line); } while (0)
     if (lane < 36) L.llTab[lane] = d_LL_base[lane] | ((uint32_t)d_LL_bits[lane] << 24);
     if (lane < 53) L.mlTab[lane] = d_ML_base[lane] | ((uint32_t)d_ML_bits[lane] << 24);
     wave_sync();
@@ -109,19 +111,19 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
     bool ok = false; uint32_t nBlocks = 0;
     do {
         // ---- frame header (:389-499): one frame, no dictionary ----
-        if (srcSize < 5 + 1 + 3 || rd32(src) != 0xFD2FB528u) break;
+        if (srcSize < 5 + 1 + 3 || rd32(src) != 0xFD2FB528u) { ZS_PREP_WHY(__LINE__); break; }
         const uint32_t fhd = src[4];
         const uint32_t dictIDCode = fhd & 3, checksumFlag = (fhd >> 2) & 1, singleSegment = (fhd >> 5) & 1, fcsID = fhd >> 6;
-        if (dictIDCode || (fhd & 0x08)) break;
+        if (dictIDCode || (fhd & 0x08)) { ZS_PREP_WHY(__LINE__); break; }
         const uint32_t tail = checksumFlag ? 4u : 0u;              // the checksum behind the last block
         const uint32_t fcsSize = fcsID == 0 ? 0 : (fcsID == 1 ? 2 : (fcsID == 2 ? 4 : 8));
         const uint32_t fhs = 5 + !singleSegment + fcsSize + (singleSegment && !fcsID);
-        if (srcSize < fhs + 3 + tail) break;
+        if (srcSize < fhs + 3 + tail) { ZS_PREP_WHY(__LINE__); break; }
         uint32_t pos = 5;
-        if (!singleSegment) { const uint32_t wl = src[pos++]; if ((wl >> 3) + 10 > 30) break; }
+        if (!singleSegment) { const uint32_t wl = src[pos++]; if ((wl >> 3) + 10 > 30) { ZS_PREP_WHY(__LINE__); break; } }
         uint64_t fcs = ~0ull;
         if (fcsID == 0) { if (singleSegment) fcs = src[pos]; } else if (fcsID == 1) fcs = rd16(src + pos) + 256; else if (fcsID == 2) fcs = rd32(src + pos); else fcs = zs_load64(src + pos);
-        if (fcs != ~0ull && fcs > 0xFFFFFFFFull) break;
+        if (fcs != ~0ull && fcs > 0xFFFFFFFFull) { ZS_PREP_WHY(__LINE__); break; }
         const uint32_t hasContentSize = fcs != ~0ull, contentSize = (uint32_t)fcs;
         uint32_t b0 = fhs;                                          // offset of the next block header in the item
         bool fail = false;
@@ -140,18 +142,18 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
             ZsFastDesc *dp = descs + slot;
             if (blk == 0) { DSET(why, 0u); DSET(hasContentSize, hasContentSize); DSET(contentSize, contentSize); DSET(hasChecksum, checksumFlag); DSET(checksum, checksumFlag ? rd32(src + srcSize - 4) : 0u); }
             // ---- a block (:646-659): compressed; the last one fills the rest of the item ----
-            if ((uint64_t)b0 + 3 + tail > srcSize) break;
+            if ((uint64_t)b0 + 3 + tail > srcSize) { ZS_PREP_WHY(__LINE__); break; }
             const uint32_t bh = rd24(src + b0);
             const uint32_t lastBlock = bh & 1, btype = (bh >> 1) & 3, cSize = bh >> 3;
-            if (btype == 3) break;
+            if (btype == 3) { ZS_PREP_WHY(__LINE__); break; }
             if (btype != 2) {
                 // a raw or RLE block among the compressed ones (:2043-2056): to the kernels behind this one a block of nothing but literals - raw
                 // literals at the block's bytes, or RLE literals of its byte - and no sequences; the entropy tables a later block may repeat stay
                 const uint32_t csz = btype == 1 ? 1u : cSize;
-                if (cSize > (1u << 17) || (btype == 1 && cSize > litCap)) break;       // (an RLE block is spread through the slot's literal buffer)
-                if ((uint64_t)b0 + 3 + csz + tail > srcSize) break;
-                if (lastBlock && (uint64_t)b0 + 3 + csz + tail != srcSize) break;
-                if (!lastBlock && blk + 1 == maxBlocks) break;
+                if (cSize > (1u << 17) || (btype == 1 && cSize > litCap)) { ZS_PREP_WHY(__LINE__); break; }       // (an RLE block is spread through the slot's literal buffer)
+                if ((uint64_t)b0 + 3 + csz + tail > srcSize) { ZS_PREP_WHY(__LINE__); break; }
+                if (lastBlock && (uint64_t)b0 + 3 + csz + tail != srcSize) { ZS_PREP_WHY(__LINE__); break; }
+                if (!lastBlock && blk + 1 == maxBlocks) { ZS_PREP_WHY(__LINE__); break; }
                 b0 += 3;
                 DSET(litType, btype == 0 ? 0u : 1u); DSET(litSrc, btype == 0 ? b0 : (uint32_t)src[b0]); DSET(litSize, cSize); DSET(nStreams, 0u);
                 DSET(nbSeq, 0u); DSET(seqOff, 0u); DSET(seqSize, 0u); DSET(llLog, 0u); DSET(ofLog, 0u); DSET(mlLog, 0u); DSET(hufFlat, 0u);
@@ -162,33 +164,33 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                 if (lastBlock) break;
                 continue;
             }
-            if (cSize >= (1u << 17) || cSize < 3) break;
-            if ((uint64_t)b0 + 3 + cSize + tail > srcSize) break;
-            if (lastBlock && (uint64_t)b0 + 3 + cSize + tail != srcSize) break;
-            if (!lastBlock && blk + 1 == maxBlocks) break;           // more blocks than slots: general kernel
+            if (cSize >= (1u << 17) || cSize < 3) { ZS_PREP_WHY(__LINE__); break; }
+            if ((uint64_t)b0 + 3 + cSize + tail > srcSize) { ZS_PREP_WHY(__LINE__); break; }
+            if (lastBlock && (uint64_t)b0 + 3 + cSize + tail != srcSize) { ZS_PREP_WHY(__LINE__); break; }
+            if (!lastBlock && blk + 1 == maxBlocks) { ZS_PREP_WHY(__LINE__); break; }           // more blocks than slots: general kernel
             b0 += 3;                                                // block payload offset in the item
             const uint8_t *bs = src + b0;
             // ---- literals section header (:683-821) ----
             uint32_t litCSizeTot;
             {
                 const uint32_t type = bs[0] & 3, lhl = (bs[0] >> 2) & 3;
-                if (type == 3 && L.misc[11] == 0) break;            // a repeated Huffman table without one before it: the general kernel says what is wrong
+                if (type == 3 && L.misc[11] == 0) { ZS_PREP_WHY(__LINE__); break; }            // a repeated Huffman table without one before it: the general kernel says what is wrong
                 if (type >= 2) {
-                    if (cSize < 5) break;
+                    if (cSize < 5) { ZS_PREP_WHY(__LINE__); break; }
                     const uint32_t lhc = rd32(bs);
                     uint32_t lhSize, litSize, litCSize; bool single = false;
                     if (lhl < 2) { single = !lhl; lhSize = 3; litSize = (lhc >> 4) & 0x3FF; litCSize = (lhc >> 14) & 0x3FF; }
                     else if (lhl == 2) { lhSize = 4; litSize = (lhc >> 4) & 0x3FFF; litCSize = lhc >> 18; }
                     else { lhSize = 5; litSize = (lhc >> 4) & 0x3FFFF; litCSize = (lhc >> 22) + ((uint32_t)bs[4] << 10); }
-                    if (litSize > litCap || litCSize + lhSize > cSize) break;
-                    if (!single && (litSize == 0 || litCSize == 0)) break;
+                    if (litSize > litCap || litCSize + lhSize > cSize) { ZS_PREP_WHY(__LINE__); break; }
+                    if (!single && (litSize == 0 || litCSize == 0)) { ZS_PREP_WHY(__LINE__); break; }
                     uint16_t *ht = reinterpret_cast<uint16_t *>(hufTabs + slot * ZS_FAST_HUFTAB_BYTES);
                     uint32_t h = 0;
                     if (type == 2) {
                         h = readHufTableT<true>(L, bs + lhSize, litCSize, ht, ZS_FAST_HUFLOG);
-                        if (isErr(h)) break;
+                        if (isErr(h)) { ZS_PREP_WHY(__LINE__); break; }
                         const uint32_t flat = h >> 30; h &= 0x3FFFFFFFu;       // (readHufTableT<true> marks a flat table in bit 30)
-                        if (h >= litCSize || L.hufLog > ZS_FAST_HUFLOG) break;
+                        if (h >= litCSize || L.hufLog > ZS_FAST_HUFLOG) { ZS_PREP_WHY(__LINE__); break; }
                         if (lane == 0) L.misc[13] = L.hufLog | (flat << 8);
                     } else {
                         // the table of the block that built it, into this block's slot (the whole 4 KiB: 16 bytes a lane, 4 rounds)
@@ -209,12 +211,12 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                     DSET(litType, 2u); DSET(litSize, litSize); DSET(hufLog, L.misc[13] & 0xFFu);
                     if (single) { DSET(nStreams, 1u); DSET(sOff[0], cs0); DSET(sLen[0], csz); DSET(sCnt[0], litSize); DSET(sOut[0], 0u); }
                     else {
-                        if (csz < 10) break;
+                        if (csz < 10) { ZS_PREP_WHY(__LINE__); break; }
                         const uint8_t *cs = src + cs0;
                         const uint32_t l1 = rd16(cs), l2 = rd16(cs + 2), l3 = rd16(cs + 4);
-                        if (l1 + l2 + l3 + 6 > csz) break;
+                        if (l1 + l2 + l3 + 6 > csz) { ZS_PREP_WHY(__LINE__); break; }
                         const uint32_t seg = (litSize + 3) / 4;
-                        if (3 * seg > litSize) break;
+                        if (3 * seg > litSize) { ZS_PREP_WHY(__LINE__); break; }
                         if (lane == 0) {
                             dp->nStreams = 4;
                             dp->sOff[0] = cs0 + 6; dp->sOff[1] = cs0 + 6 + l1; dp->sOff[2] = cs0 + 6 + l1 + l2; dp->sOff[3] = cs0 + 6 + l1 + l2 + l3;
@@ -228,12 +230,12 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
                     if (lhl == 1) { lhSize = 2; litSize = rd16(bs) >> 4; }
                     else if (lhl == 3) { lhSize = 3; litSize = rd24(bs) >> 4; }
                     else { lhSize = 1; litSize = bs[0] >> 3; }
-                    if (type == 0) { if (litSize + lhSize > cSize) break; DSET(litType, 0u); DSET(litSrc, b0 + lhSize); litCSizeTot = lhSize + litSize; }
-                    else { if (lhSize + 1 > cSize || litSize > litCap) break; DSET(litType, 1u); DSET(litSrc, (uint32_t)bs[lhSize]); litCSizeTot = lhSize + 1; }
+                    if (type == 0) { if (litSize + lhSize > cSize) { ZS_PREP_WHY(__LINE__); break; } DSET(litType, 0u); DSET(litSrc, b0 + lhSize); litCSizeTot = lhSize + litSize; }
+                    else { if (lhSize + 1 > cSize || litSize > litCap) { ZS_PREP_WHY(__LINE__); break; } DSET(litType, 1u); DSET(litSrc, (uint32_t)bs[lhSize]); litCSizeTot = lhSize + 1; }
                     DSET(litSize, litSize); DSET(nStreams, 0u);
                 }
             }
-            if (litCSizeTot > cSize) break;
+            if (litCSizeTot > cSize) { ZS_PREP_WHY(__LINE__); break; }
             // ---- sequence headers + tables (:1110-1180), then the tables leave for the sequences kernel.  st.fseEntropy stays 0: a
             //      table repeated from the block before (mode 3) is an error here and sends the item to the general kernel ----
             const uint8_t *ip = bs + litCSizeTot; uint32_t remaining = cSize - litCSizeTot, nbSeq = 0;
@@ -241,9 +243,9 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
             DState st; st.rep[0] = 1; st.rep[1] = 4; st.rep[2] = 8; st.litEntropy = 0; st.fseEntropy = seqPrev != 0; st.llRepeatOk = 0; st.hufX4 = 0;
             uint16_t *stab = reinterpret_cast<uint16_t *>(seqTabs + slot * ZS_FAST_SEQTAB_BYTES);
             const uint16_t *stabPrev = seqPrev ? reinterpret_cast<const uint16_t *>(seqTabs + ((size_t)(seqPrev - 1u) * cap + item) * ZS_FAST_SEQTAB_BYTES) : nullptr;
-            if (seqHeadersT<true>(L, st, ip, remaining, nbSeq, stab, &L.misc[8], stabPrev)) break;      // (misc[8..10]: a repeated table keeps the log it had)
-            if (nbSeq > seqCap) break;
-            if (nbSeq == 0 && remaining != 0) break;
+            if (seqHeadersT<true>(L, st, ip, remaining, nbSeq, stab, &L.misc[8], stabPrev)) { ZS_PREP_WHY(__LINE__); break; }      // (misc[8..10]: a repeated table keeps the log it had)
+            if (nbSeq > seqCap) { ZS_PREP_WHY(__LINE__); break; }
+            if (nbSeq == 0 && remaining != 0) { ZS_PREP_WHY(__LINE__); break; }
             DSET(nbSeq, nbSeq); DSET(seqOff, (uint32_t)(ip - src)); DSET(seqSize, remaining);
             DSET(llLog, nbSeq ? L.misc[8] : 0u); DSET(ofLog, nbSeq ? L.misc[9] : 0u); DSET(mlLog, nbSeq ? L.misc[10] : 0u);
             if (nbSeq && lane == 0) {
@@ -275,7 +277,9 @@ k_dec_prep(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ ite
     if (lane == 0) {
         const uint32_t slots = max(2u, maxBlocks);                               // (a descriptor slot 1 exists even when the call reserved one block slot)
         for (uint32_t b = ok ? nBlocks : 0u; b < slots; b++) descs[(size_t)b * cap + item].fast = 0;
+        if (!ok) descs[item].why = prepWhy;
     }
+    #undef ZS_PREP_WHY
     #undef DSET
 }
 

@@ -1017,8 +1017,9 @@ __device__ __forceinline__ uint32_t seqHeadersT(DLds &L, const DState &st, const
                 }
             }
             ip += consumed;
-            remaining = (uint32_t)(iend - ip);
         }
+        remaining = (uint32_t)(iend - ip);                             // (also for a block without sequences: round 3 left it at the section's size there, and k_dec_prep, which
+                                                                       //  wants nothing behind a zero count, sent every literals-only block to the general kernel: 1 % of ELF-class frames)
     }
     return 0;
 }
