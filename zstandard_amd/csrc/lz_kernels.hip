@@ -35,14 +35,18 @@
 // HBM traffic per unit: reads n (twice through L2: both hashers), writes 2 n + n / 8 (+ n / 8).
 // ---------------------------------------------------------------------------------------------
 #ifndef ZS_CAND_G
-#define ZS_CAND_G 8                // steps of 64 positions per group
+#define ZS_CAND_G 8                // steps of 64 positions per group, units <= 64 KiB (16: 85 KiB of LDS, one workgroup a CU: 1.54 vs 0.48 ms)
 #endif
+#ifndef ZS_CAND_G_BIG
+#define ZS_CAND_G_BIG 16           // the same for units > 64 KiB: their 2^14-slot tables allow one workgroup a CU anyway (128 + 25 KiB), and an interval's three LDS round trips and its barrier
+#endif                             // then cover 1024 positions instead of 512
+#define ZS_CAND_GOF(TLOG) ((TLOG) > ZS_TABLE_LOG_SMALL ? ZS_CAND_G_BIG : ZS_CAND_G)
 #ifndef ZS_CAND_DEPTH
 #define ZS_CAND_DEPTH 2            // a register set holds the source loads of this many groups (two sets: 2 .. 4 groups in flight; 4: 0.64 vs 0.52 ms, the unrolled body grows)
 #endif
 #define ZS_CAND_WAVES(NT) (3 * (NT))
 #define ZS_CAND_ROW 65u            // words per step in the operand ring (64 + 1 of padding)
-#define ZS_CAND_LDS(TLOG, NT) ((size_t)(NT) * (4u << (TLOG)) + 3u * (NT) * ZS_CAND_G * ZS_CAND_ROW * 4u + (NT) * 256u)   // tables, operand ring, a dummy word per owner lane
+#define ZS_CAND_LDS(TLOG, NT) ((size_t)(NT) * (4u << (TLOG)) + 3u * (NT) * ZS_CAND_GOF(TLOG) * ZS_CAND_ROW * 4u + (NT) * 256u)   // tables, operand ring, a dummy word per owner lane
 #define ZS_SLOT_EMPTY 0xFFFFFFFFu
 // hashes made of 24 x 24 -> 32 bit multiplies (v_mul_u32_u24 / v_mad_u32_u24: full rate; a v_mul_lo_u32 is quarter rate and the first
 // version's two per long hash were a quarter of the kernel's issue slots).  short: bytes 0-2 and 2-4; long: bytes 0-2, 3-5, 6-7
@@ -58,9 +62,11 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
 {
     extern __shared__ __attribute__((aligned(16))) uint32_t candLds[];
     constexpr bool BIG = TLOG > ZS_TABLE_LOG_SMALL;
-    constexpr uint32_t G = ZS_CAND_G, GP = G * 64u, H = G / NT;         // H: steps of a group a hasher merges and stores
+    constexpr uint32_t G = ZS_CAND_GOF(TLOG), GP = G * 64u, H = G / NT;  // H: steps of a group a hasher merges and stores
     constexpr uint32_t M = ZS_CAND_DEPTH;
-    static_assert(G == 8, "a hasher lane takes 8 consecutive positions of a group");
+    constexpr uint32_t LPS = 64u / G;                                   // hasher lanes per step of 64 positions: a lane takes G consecutive positions of the group
+    constexpr uint32_t WD = G / 4u + 2u;                                // dwords that hold a lane's G positions and the 7 bytes behind them
+    static_assert(G == 8 || G == 16, "a hasher lane takes G consecutive positions of a group: 8 or 16");
     const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
     const uint32_t tab = (wave < NT) ? wave : ((wave < 2 * NT) ? wave - NT : wave - 2 * NT);   // wavefronts [0, NT): owners, [NT, 2 NT): hashers, [2 NT, 3 NT): mergers
     uint32_t *T = candLds + ((size_t)tab << TLOG);
@@ -187,34 +193,36 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     // cannot count loads across the back edge): there it only meets the loads of A issued M intervals earlier.
     auto run = [&](auto roleTag) {
         constexpr bool LONG = decltype(roleTag)::value;
-        const uint32_t stepOfLane = lane >> 3, l0 = (lane & 7u) * 8u;    // the lane's positions 8 lane + u = step (lane >> 3), owner lane l0 + u
+        const uint32_t stepOfLane = lane / LPS, l0 = (lane % LPS) * G;    // the lane's positions G lane + u = step (lane / LPS), owner lane l0 + u
         const uint32_t wbase = stepOfLane * ROW + l0;
         const uint32_t last8 = n - 8;                                    // loads are clamped, never branched around
-        auto loadGroup = [&](uint32_t g, uint32_t (&w)[4]) {
-            // bytes [o, o + 16) of the unit; a piece that would pass the unit's end is read at the last whole 8 bytes and shifted down
+        auto loadGroup = [&](uint32_t g, uint32_t (&w)[WD]) {
+            // bytes [o, o + 4 WD) of the unit; a piece that would pass the unit's end is read at the last whole 8 bytes and shifted down
             // (the bytes below the end stay right, nothing behind the end is touched)
-            const uint32_t o = g * GP + lane * 8u;
-            const uint32_t oa = min(o, last8), ob = min(o + 8u, last8);
-            const uint64_t a = zs_load64(s + oa) >> (8u * min(o - oa, 7u));
-            const uint64_t b = zs_load64(s + ob) >> (8u * min(o + 8u - ob, 7u));
-            w[0] = (uint32_t)a; w[1] = (uint32_t)(a >> 32); w[2] = (uint32_t)b; w[3] = (uint32_t)(b >> 32);
+            const uint32_t o = g * GP + lane * G;
+            #pragma unroll
+            for (uint32_t k = 0; k < WD / 2; k++) {
+                const uint32_t ok = o + 8u * k, oc = min(ok, last8);
+                const uint64_t v = zs_load64(s + oc) >> (8u * min(ok - oc, 7u));
+                w[2 * k] = (uint32_t)v; w[2 * k + 1] = (uint32_t)(v >> 32);
+            }
         };
-        uint32_t bufA[M][4], bufB[M][4];
-        auto loadM = [&](uint32_t g0, uint32_t (&buf)[M][4]) {
+        uint32_t bufA[M][WD], bufB[M][WD];
+        auto loadM = [&](uint32_t g0, uint32_t (&buf)[M][WD]) {
             #pragma unroll
             for (uint32_t k = 0; k < M; k++) loadGroup(min(g0 + k, nGroups), buf[k]);
         };
-        auto iter = [&](auto wholeTag, uint32_t i, const uint32_t (&w)[4]) {
+        auto iter = [&](auto wholeTag, uint32_t i, const uint32_t (&w)[WD]) {
             constexpr bool WHOLE = decltype(wholeTag)::value;            // group i lies wholly inside the hashable positions
             const uint32_t ringSlot = i % 3u;
             if (i < nGroups) {
                 uint32_t *ob = opnd + ((size_t)ringSlot * NT + tab) * GR + wbase;
-                const uint32_t pbase = i * GP + lane * 8u;
+                const uint32_t pbase = i * GP + lane * G;
                 #pragma unroll
                 for (uint32_t u = 0; u < G; u++) {
                     const uint32_t k = u >> 2, sh = u & 3u;
                     const uint32_t lo = sh ? __builtin_amdgcn_alignbyte(w[k + 1], w[k], sh) : w[k];
-                    const uint32_t hi = sh ? __builtin_amdgcn_alignbyte(w[(k + 2) & 3], w[k + 1], sh) : w[k + 1];   // u == 4 needs no fourth dword beyond w[3]
+                    const uint32_t hi = sh ? __builtin_amdgcn_alignbyte(w[min(k + 2, WD - 1)], w[k + 1], sh) : w[k + 1];   // (sh == 0 at the last k needs no dword beyond w[WD - 1])
                     uint32_t h = LONG ? zs_hash_long(lo, hi) : zs_hash_short(lo, hi);
                     asm volatile("" : "+v"(h));                          // (keeps the compiler from folding the shifts below into two more multiplies)
                     // tag << 17 | index: the hash rotated left by TLOG holds both (bits 31..17 and TLOG-1..0)
@@ -224,7 +232,7 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
             }
             __syncthreads();
         };
-        auto step = [&](uint32_t i, const uint32_t (&w)[4]) {
+        auto step = [&](uint32_t i, const uint32_t (&w)[WD]) {
             if (i > nGroups + 1) return;
             if ((i + 1) * GP + 8u <= n) iter(std::true_type{}, i, w); else iter(std::false_type{}, i, w);
         };
