@@ -1,3 +1,7 @@
+#!/usr/bin/env python3
+"""Development aid (GPU box): how often a segment of the sequences kernel's FSE state chains fails its seam check and is run again (k_encode_sequences,
+entropy_kernels.hip), per data class.  Needs a library built with -DZSMI_DEBUG_HOOKS -DZS_CHAIN_COUNT (the kernel then leaves its rounds of repair in
+ZsBlockMeta.pad[0] >> 16 and K | Sb << 8 | nseq << 16 in pad[1]): ZSMI_LIB_FILE=<that library> [CLS=<class of tests/_corpus.py>] python tools/chain_count.py"""
 import os, sys, ctypes
 os.environ["ZSMI_DEBUG_LIB"] = "1"
 import numpy as np, torch
