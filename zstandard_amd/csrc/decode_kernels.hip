@@ -1360,13 +1360,14 @@ k_decode_frames(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict_
                 const uint8_t *__restrict__ dict, uint32_t dictBytes, uint32_t *__restrict__ queue)
 {
     __shared__ DLds LS[F];
+    const uint32_t total = list ? *listCount : nItems;                          // (list == nullptr: every item of the call)
+    if (blockIdx.x * F >= total) return;                                        // nothing left for this workgroup (behind the fast path usually for all of them: the launch is then a few microseconds, not the 0.04 ms of 3072 wavefronts setting up)
     DLds &L = LS[threadIdx.x >> 6];
     const uint32_t lane = (uint32_t)zs_lane();
     uint8_t *litBuf = litScratchAll + (size_t)(blockIdx.x * F + (threadIdx.x >> 6)) * ZS_DEC_LITBUF;
     if (lane < 36) L.llTab[lane] = d_LL_base[lane] | ((uint32_t)d_LL_bits[lane] << 24);
     if (lane < 53) L.mlTab[lane] = d_ML_base[lane] | ((uint32_t)d_ML_bits[lane] << 24);
     wave_sync();
-    const uint32_t total = list ? *listCount : nItems;                          // (list == nullptr: every item of the call)
     for (;;) {
         uint32_t at = 0;
         if (lane == 0) at = atomicAdd(queue, 1u);
