@@ -571,6 +571,42 @@ def test_matchless_units_skip_the_parse(codec, level):
     assert len(frames[names.index("noise_then_text")]) < 65536 + 40000                      # the unit's second block still finds its matches
 
 
+def _byte_run_inputs():
+    """runs of one byte of every length and alignment against the candidate kernel's shapes: 8 (16) positions a hasher lane, 64 a step, 512 (1024)
+    a group; runs of the same byte next to each other, runs that meet a unit's end, runs inside text and inside noise"""
+    import _corpus as C
+    rng = np.random.default_rng(41)
+    text = C.CLASSES["json"](1 << 18)
+    out = {}
+    for size in (65536, 131072, 50000):
+        for kind in ("text", "noise"):
+            b = bytearray(text[:size]) if kind == "text" else bytearray(rng.integers(0, 256, size, dtype=np.uint8).tobytes())
+            pos = int(rng.integers(0, 40))
+            while pos < size:
+                ln = int(rng.choice([3, 7, 8, 9, 15, 16, 17, 23, 24, 31, 33, 63, 64, 65, 100, 127, 129, 500, 511, 513, 1025, 3000]))
+                val = int(rng.choice([0, 0, 32, 255, int(rng.integers(0, 256))]))
+                b[pos:pos + ln] = bytes([val]) * min(ln, size - pos)
+                pos += ln + int(rng.choice([0, 1, 2, 5, 8, 40, 300]))                 # (0: the next run follows at once, often with another byte)
+            out["%s_%d" % (kind, size)] = bytes(b)
+    z = bytearray(65536); z[65535] = 1; out["zeros_but_the_last"] = bytes(z)
+    z = bytearray(65536); z[0] = 1; out["zeros_but_the_first"] = bytes(z)
+    z = bytearray(131072); z[70000] = 9; out["big_zeros_but_one"] = bytes(z)
+    out["two_bytes_alternating_runs"] = (b"\x00" * 37 + b"\x01" * 91) * 512
+    return out
+
+
+@pytest.mark.parametrize("level", [1, 3])
+def test_runs_of_one_byte_are_parsed_as_in_the_oracle(codec, level):
+    """k_lz_candidates keeps the inner positions of a run of one byte away from the run's hash slot (they would meet there in one LDS exchange,
+    64 lanes on one address) and gives them the distance 1 the sequential loop of oracle E's findCandidates finds: the frames are oracle E's"""
+    inputs = _byte_run_inputs()
+    names = sorted(inputs)
+    frames = _compress_many(codec, [inputs[k] for k in names], level)
+    for k, f in zip(names, frames):
+        assert f == O.compress(inputs[k], level), k
+        assert O.decompress(f, len(inputs[k])) == inputs[k], k
+
+
 def test_decode_wide_alphabets_flat_huffman_table(codec):
     """literals over all 256 byte values with a long tail of rare ones: more 9-bit prefixes hold 10 / 11-bit codes than the fast path's two-level
     Huffman table has sub-tables, so k_dec_prep emits the flat 2^11 table and k_dec_huffman's flat class decodes them (before round 3's end such

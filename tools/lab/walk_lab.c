@@ -28,7 +28,8 @@ typedef struct {
 } WP;
 static WP P = { 10, 16384, 0, 0, 64, 8, 0, 0, 0, 0, 0, 8, 5, 4, 5, 1, 1, 0, 8, 8, 0, 0, 0 };
 static BYTE wlLong[UNIT_MAX];
-static struct { unsigned long long steps, emptySteps, scored, emitted, kept, extBytes, ranges, merged; } S;
+static struct { unsigned long long steps, emptySteps, scored, emitted, kept, extBytes, ranges, merged, waveMax32, waveMax16, waveMax64; } S;
+static U32 wlSteps[1024];
 void wl_set(const char *k, int v)
 {
 #define K(name) if (!strcmp(k, #name)) { P.name = v; return; }
@@ -68,6 +69,7 @@ static void wlCandidates(Work *w, const BYTE *src, U32 n, const EParams *prm)
     w->matchless = found < (n >> MATCHLESS_SHIFT);
 }
 
+static U32 wlLastSteps;
 static U32 wlWalk(Work *w, const BYTE *src, U32 n, U32 start, U32 end, U32 limit, const EParams *prm, ASeq *out, U32 *reps)
 {
     U32 ip = start, anchor = start, nseq = 0, rep0 = reps[0], rep1 = reps[1];
@@ -138,6 +140,7 @@ static U32 wlWalk(Work *w, const BYTE *src, U32 n, U32 start, U32 end, U32 limit
     }
     reps[0] = rep0; reps[1] = rep1;
     S.emitted += nseq; S.ranges++;
+    wlLastSteps = mySteps;
     return nseq;
 }
 
@@ -158,7 +161,15 @@ static size_t wlBlock(Work *w, BYTE *dst, size_t cap, const BYTE *src, U32 unitN
         U32 const limit = (end + (U32)P.crossMax < blockEnd) ? end + (U32)P.crossMax : blockEnd;
         if (!P.carryRep) reps[0] = reps[1] = 0;
         if (P.initRep && start > blockOff) { U32 b; for (b = 1; b <= 64 && start >= b + (P.initRep == 2 ? 0 : blockOff); b++) if (w->dist[start - b]) { reps[0] = w->dist[start - b]; break; } }
+        wlLastSteps = 0;
         wlN[r] = w->matchless ? 0 : wlWalk(w, src, unitN, start, end, limit, prm, wlSeq[r], reps);
+        wlSteps[r] = wlLastSteps;
+    }
+    {   /* wave imbalance: consecutive ranges side by side in a wavefront, which runs as long as its slowest walker */
+        U32 g, k;
+        for (g = 0; g < nRanges; g += 16) { U32 m = 0; for (k = g; k < g + 16 && k < nRanges; k++) if (wlSteps[k] > m) m = wlSteps[k]; S.waveMax16 += m; }
+        for (g = 0; g < nRanges; g += 32) { U32 m = 0; for (k = g; k < g + 32 && k < nRanges; k++) if (wlSteps[k] > m) m = wlSteps[k]; S.waveMax32 += m; }
+        for (g = 0; g < nRanges; g += 64) { U32 m = 0; for (k = g; k < g + 64 && k < nRanges; k++) if (wlSteps[k] > m) m = wlSteps[k]; S.waveMax64 += m; }
     }
     {   /* the stitch, sequential statement (same result as oracle's stitch + concatenation when merge == 0) */
         U32 pos = blockOff;                 /* == reach throughout */

@@ -45,7 +45,7 @@ for spec in a.sets or ["base:"]:
         if t: k, v = t.split("="); prm[k] = int(v)
     for k, v in prm.items(): L.wl_set(k.encode(), v)
     row, worst, tot = "%-24s" % nm, 0, 0
-    st = (ctypes.c_ulonglong * 9)(); L.wl_stats(st)
+    st = (ctypes.c_ulonglong * 12)(); L.wl_stats(st)
     for name, data in cor.items():
         e = 0
         for i in range(0, len(data), cs):
@@ -58,4 +58,4 @@ for spec in a.sets or ["base:"]:
         row += "%8.4f" % (e / zs[name]); worst = max(worst, e / zs[name])
     L.wl_stats(st)
     k = tot / 1024
-    print(row + "%8.4f | %7.1f %7.1f %7.1f %7.1f %7.2f" % (worst, st[0] / k, st[2] / k, st[3] / k, st[4] / k, st[8] / k), flush=True)
+    print(row + "%8.4f | %7.1f %7.1f %7.1f %7.1f %7.2f" % (worst, st[0] / k, st[2] / k, st[3] / k, st[4] / k, st[7] / k) + "  | wave efficiency (steps / lanes x slowest) 16: %.3f 32: %.3f 64: %.3f, empty steps %.3f" % (st[0] / max(1, 16 * st[9]) if False else st[0] / max(1, 16 * st[9]), st[0] / max(1, 32 * st[8]), st[0] / max(1, 64 * st[10]), st[1] / max(1, st[0])), flush=True)

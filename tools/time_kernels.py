@@ -13,6 +13,10 @@ n, cs, steps = 4096, 65536, 5
 cls = os.environ.get("CLS", "zipf")          # a class of tests/_corpus.py (16 MiB of it, tiled) instead of the Zipf log
 if cls == "zipf":
     data = D.zipf_log(n * cs)
+elif cls == "random":
+    data = np.random.default_rng(7).integers(0, 256, n * cs, dtype=np.uint8)
+elif cls == "zeros":
+    data = np.zeros(n * cs, dtype=np.uint8)
 else:
     import _corpus as C
     one = np.frombuffer(C.CLASSES[cls](16 << 20), dtype=np.uint8)

@@ -32,6 +32,17 @@
 // One barrier per interval.  The operand ring holds 3 groups per table; a step's 64 words are ZS_CAND_ROW = 65 words apart, which
 // spreads both the hashers' writes (8 consecutive positions a lane) and the owners' reads (64 consecutive) over all banks and keeps
 // every address of the form base + constant.
+// Runs of one byte (round 4, ZS_CAND_RUNS): zeros in a binary or a line of blanks give consecutive positions the SAME operand - up to 64 lanes
+// of one exchange on one slot, which the LDS serves one after the other (repetitive class: 1.33 ms against 0.46).  What such a run's lanes
+// get is known without asking: every lane but the run's first the entry of the lane below, distance 1, and the slot keeps the run's last
+// entry.  The hasher sees the runs in its bytes (a lane whose G positions + 7 bytes are one byte, and the lanes next to it): it MARKS the
+// run's positions but the first (a bit a position, next to the ring, and a word a group that says whether any is marked), and sends the
+// marked positions that have a marked one above them to the owner lane's dummy word instead of the slot.  So only a run's first lane (the
+// slot's old content) and last lane (leaves its entry; served after the first: ascending lane order, as everywhere here) meet at the slot,
+// and the merger gives a marked position the distance 1.  The owner - the wavefront the other two wait for - runs the same instructions as
+// without any of this (finding the runs there cost 0.13 ms of 0.46 on data without runs; a flag word a group read there 0.06; marks carried
+// through its result words 0.10: each role's instructions count), a group without a flat lane costs the hasher the test and the merger a
+// word's read.  Runs are cut at a step's border: its lane 0 asks the slot, which holds the step before's last entry.
 // HBM traffic per unit: reads n (twice through L2: both hashers), writes 2 n + n / 8 (+ n / 8).
 // ---------------------------------------------------------------------------------------------
 #ifndef ZS_CAND_G
@@ -44,9 +55,12 @@
 #ifndef ZS_CAND_DEPTH
 #define ZS_CAND_DEPTH 2            // a register set holds the source loads of this many groups (two sets: 2 .. 4 groups in flight; 4: 0.64 vs 0.52 ms, the unrolled body grows)
 #endif
+#ifndef ZS_CAND_RUNS
+#define ZS_CAND_RUNS 1             // runs of one byte: the inner positions' exchanges are kept off the run's slot (below); 0: every position exchanges there
+#endif
 #define ZS_CAND_WAVES(NT) (3 * (NT))
 #define ZS_CAND_ROW 65u            // words per step in the operand ring (64 + 1 of padding)
-#define ZS_CAND_LDS(TLOG, NT) ((size_t)(NT) * (4u << (TLOG)) + 3u * (NT) * ZS_CAND_GOF(TLOG) * ZS_CAND_ROW * 4u + (NT) * 256u)   // tables, operand ring, a dummy word per owner lane
+#define ZS_CAND_LDS(TLOG, NT) ((size_t)(NT) * (4u << (TLOG)) + 3u * (NT) * ZS_CAND_GOF(TLOG) * ZS_CAND_ROW * 4u + (NT) * 256u + 3u * 16u * 8u + 32u)   // tables, operand ring, a dummy word per owner lane, the run marks of the groups in the ring (a bit a position) and a flag a group
 #define ZS_SLOT_EMPTY 0xFFFFFFFFu
 // hashes made of 24 x 24 -> 32 bit multiplies (v_mul_u32_u24 / v_mad_u32_u24: full rate; a v_mul_lo_u32 is quarter rate and the first
 // version's two per long hash were a quarter of the kernel's issue slots).  short: bytes 0-2 and 2-4; long: bytes 0-2, 3-5, 6-7
@@ -73,6 +87,8 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
     uint32_t *opnd = candLds + ((size_t)NT << TLOG);                     // [3][NT][GP]
     constexpr uint32_t ROW = ZS_CAND_ROW, GR = G * ROW;                  // words of a group in the ring, per table
     constexpr uint32_t RING = 3u * NT * GR;
+    uint64_t *runMarks = reinterpret_cast<uint64_t *>(opnd + RING + NT * 64u);   // [3][16]: per group in the ring and step, the marked positions (ZS_CAND_RUNS; both tables' hashers see the same: table 0's writes)
+    uint32_t *runFlag = opnd + RING + NT * 64u + 3u * 16u * 2u;           // [3][2]: the group has marked positions, a word a merger (set by table 0's hasher, cleared by the merger)
     const ZsUnitDesc ud = units[blockIdx.x];
     const uint8_t *s = src + ud.srcOff;
     const uint32_t n = ud.size;
@@ -143,6 +159,16 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
         for (uint32_t i = 2; i <= nGroups + 1; i++) {
             uint32_t mS[H], mL[H];
             mergeRead(i - 2, mS, mL);
+#if ZS_CAND_RUNS
+            if (__builtin_amdgcn_readfirstlane((int)runFlag[((i - 2) % 3u) * 2u + tab])) {
+                if (lane == 0) runFlag[((i - 2) % 3u) * 2u + tab] = 0;
+                #pragma unroll
+                for (uint32_t uu = 0; uu < H; uu++) {
+                    const uint64_t marks = runMarks[((i - 2) % 3u) * 16u + ((NT > 1) ? tab * H : 0u) + uu];
+                    if ((marks >> lane) & 1ull) { if (NT > 1) mL[uu] = 1u; else mS[uu] = 1u; }
+                }
+            }
+#endif
             mergeStore(i - 2, mS, mL);
             __syncthreads();
         }
@@ -229,6 +255,44 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
                     const uint32_t r = __builtin_amdgcn_alignbit(h, h, 32 - TLOG);
                     ob[u] = (WHOLE || pbase + u < hashable) ? (r & (0xFFFE0000u | ((1u << TLOG) - 1u))) : ((r & 0xFFFE0000u) | (dummyBase + l0 + u));
                 }
+#if ZS_CAND_RUNS
+                // flat: the lane's bytes (its G positions and the 7 behind) are one byte - its positions but the first hash what the position
+                // below them hashes; the first too if the lane below is flat with the same byte (and belongs to the same step of 64 positions).
+                // Groups with such lanes (rare on ordinary data: this wavefront's instructions are the kernel's time as much as the owner's)
+                // get the operands of their inner positions written again, with the dummy word's index.
+                // (first a one-instruction test that every flat lane passes: the full test only in groups where some lane does)
+                bool flat = false;
+                uint64_t flatLanes = 0;
+                if (WHOLE && __ballot(w[0] == w[1])) {
+                    uint32_t diff = w[0] ^ __builtin_amdgcn_alignbyte(w[0], w[0], 1);
+                    #pragma unroll
+                    for (uint32_t k = 1; k < WD; k++) diff |= w[k] ^ w[k - 1];
+                    flat = diff == 0;
+                    flatLanes = __ballot(flat);
+                }
+                if (flatLanes) {
+                    const uint32_t key = flat ? ((w[0] & 0xFFu) | 0x100u) : 0u;       // (never 0 for a flat lane)
+                    const uint32_t keyBelow = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x138, 0xF, 0xF, true);   // wave_shr:1 (lane 0 reads 0)
+                    const uint32_t keyAbove = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x130, 0xF, 0xF, true);   // wave_shl:1 (lane 63 reads 0)
+                    const bool markFirst = flat && keyBelow == key && (lane % LPS) != 0u;
+                    const bool innerLast = flat && keyAbove == key && (lane % LPS) != LPS - 1u;   // the position above the lane's last one is marked too
+                    if (flat) {
+                        uint32_t h = LONG ? zs_hash_long(w[0], w[1]) : zs_hash_short(w[0], w[1]);     // every position of the lane hashes the same bytes
+                        asm volatile("" : "+v"(h));
+                        const uint32_t away = (__builtin_amdgcn_alignbit(h, h, 32 - TLOG) & 0xFFFE0000u) | (dummyBase + l0);
+                        if (markFirst) ob[0] = away;
+                        #pragma unroll
+                        for (uint32_t u = 1; u + 1 < G; u++) ob[u] = away + u;
+                        if (innerLast) ob[G - 1] = away + (G - 1);
+                    }
+                    if (!LONG) {                                             // the marks: G bits a lane, LPS lanes a step; a flag a merger
+                        if (lane < NT) runFlag[ringSlot * 2u + lane] = 1u;
+                        const uint32_t bits = flat ? (((1u << G) - 2u) | (markFirst ? 1u : 0u)) : 0u;
+                        if (G == 8) reinterpret_cast<uint8_t *>(runMarks + ringSlot * 16u)[lane] = (uint8_t)bits;
+                        else reinterpret_cast<uint16_t *>(runMarks + ringSlot * 16u)[lane] = (uint16_t)bits;
+                    }
+                }
+#endif
             }
             __syncthreads();
         };
@@ -236,6 +300,9 @@ k_lz_candidates(const uint8_t *__restrict__ src, const ZsUnitDesc *__restrict__ 
             if (i > nGroups + 1) return;
             if ((i + 1) * GP + 8u <= n) iter(std::true_type{}, i, w); else iter(std::false_type{}, i, w);
         };
+#if ZS_CAND_RUNS
+        if (!LONG && lane < 6u) runFlag[lane] = 0;                         // (this wavefront's LDS instructions execute in order; the mergers read after two barriers)
+#endif
         loadM(0, bufA);
         for (uint32_t g0 = 0; g0 <= nGroups + 1; g0 += 2 * M) {
             loadM(g0 + M, bufB);
