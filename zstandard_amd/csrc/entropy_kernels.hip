@@ -780,12 +780,15 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     // them are issued together, then their source loads, then the stores.  A tile alone is two dependent memory round
     // trips, and the loop was bound by exactly that latency.
     uint32_t *hist = L.u.hist[lane & 7u];                                  // this lane's private histogram
+    // a block without a match (a matchless unit: noise, packed data) has its literals where they are: no gather, the source is read in its place
+    const bool ungathered = nlit == n;
+    const uint8_t *litp = ungathered ? s : lits;
 #if ZS_LIT_BITMAP
     // The literals of a block are its bytes outside every match, in order.  So: a bit per byte, toggled at every match start and
     // end (LDS atomics, lane = sequence); a prefix xor turns the toggles into "inside a match"; the rest is a stream compaction of
     // the source, 16 bytes a lane and round, every lane busy with contiguous, coalesced bytes.  (Taking the literal runs sequence by
     // sequence - a run of ~3 bytes per lane, its own load and store pieces - was ~300 instructions per 64 sequences, issue-bound.)
-    {
+    if (!ungathered) {
         uint32_t *T = L.u.gm.T;
         for (uint32_t i = tid; i < 2052; i += 256) T[i] = 0;
         if (tid < 16) {                                                   // byte selectors of v_perm for a 4-bit mask: the set bytes in order, then zeros
@@ -903,8 +906,10 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
     __syncthreads();
     // 4. histogram of the gathered literals, four bytes a thread and round
     for (uint32_t j = 4 * tid; j < nlit; j += 1024) {
-        const uint32_t w = zs_load32(lits + j);                           // (the buffer has 64 bytes of slack)
         const uint32_t k = min(4u, nlit - j);
+        uint32_t w;
+        if (k == 4 || !ungathered) w = zs_load32(litp + j);               // (the literal buffer has 64 bytes of slack; the source has none)
+        else { w = 0; for (uint32_t q = 0; q < k; q++) w |= (uint32_t)litp[j + q] << (8 * q); }
         atomicAdd(&hist[w & 0xFFu], 1u);
         if (k > 1) atomicAdd(&hist[(w >> 8) & 0xFFu], 1u);
         if (k > 2) atomicAdd(&hist[(w >> 16) & 0xFFu], 1u);
@@ -1005,22 +1010,27 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
 
     // ---- literals section (inverse of DecodeLiteralsBlock, ZStdDecompress.cs:683-821) ----
     if (wave == 0) {
-        uint32_t maxSym = 0, largest = 0;
+        uint32_t maxSym = 0, largest = 0, smallest = 0xFFFFFFFFu;
         for (uint32_t b = 0; b < 256; b += 64) {
             const uint32_t c = L.count[b + lane];
             const uint64_t present = __ballot(c != 0);
             if (present) maxSym = b + 63u - (uint32_t)__builtin_clzll(present);
             largest = max(largest, wave_max(c));
+            smallest = min(smallest, ~wave_max(~c));
         }
-        if (lane == 0) { L.misc[3] = maxSym; L.misc[4] = largest; }
+        if (lane == 0) { L.misc[3] = maxSym; L.misc[4] = largest; L.misc[5] = smallest; }
     }
     __syncthreads();
     const uint32_t maxSym = L.misc[3], largest = L.misc[4];
+    // all 256 byte values occur and the most frequent less than twice as often as the rarest (noise, packed data in blocks of 64 KiB): every
+    // Huffman merge then pairs two nodes of one level before any node of the next - the code is the complete tree, 8 bits a symbol, and
+    // the section cannot be smaller than the literals: no code is built
+    const bool flatCounts = L.misc[5] != 0 && largest < 2u * L.misc[5];
     uint32_t litSecSize = 0;
     bool done = false;
     if (nlit > 0 && largest == nlit && nlit > 4) {
         if (tid == 0) {
-            const uint8_t b0 = lits[0];
+            const uint8_t b0 = litp[0];
             if (nlit < 32) { payload[0] = (uint8_t)(1 + (nlit << 3)); payload[1] = b0; }
             else if (nlit < 4096) { const uint32_t h = 1 + (1 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = b0; }
             else { const uint32_t h = 1 + (3 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); payload[3] = b0; }
@@ -1028,11 +1038,24 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
         litSecSize = (nlit < 32) ? 2 : (nlit < 4096 ? 3 : 4);
         done = true;
     }
-    if (!done && nlit >= 64) {
+    if (!done && nlit >= 64 && !flatCounts) {
         const uint32_t tableLog = huffLengths(L, maxSym, ZS_HUF_MAXBITS);
         if (ZS_STOP_AT(2)) FINISH(0, 0, 0);    // stop after the code lengths
         const uint32_t lhSize = 3 + (nlit >= 1024) + (nlit >= 16384);
         const bool single = nlit < 256;
+        // The code lengths say how many bits the streams will hold: when the section cannot come out smaller than the literals themselves
+        // (noise, packed data: 8 bits a symbol) the codes, the table description and the four streams are not made at all - the same
+        // outcome as the size test behind them (the streams are at least their bits, the description at least a byte), 0.37 -> 0.15 ms a
+        // launch of 4096 blocks of noise
+        {
+            const uint32_t mine = (tid <= maxSym) ? L.count[tid] * (uint32_t)L.nbBits[tid] : 0u;
+            const uint32_t ws = wave_sum(mine);
+            if (lane == 0) L.misc[12 + wave] = ws;
+            __syncthreads();
+        }
+        const uint32_t codeBits = L.misc[12] + L.misc[13] + L.misc[14] + L.misc[15];
+        const bool hopeless = lhSize + 1u + (single ? 0u : 6u) + (codeBits >> 3) >= nlit + (3 - (nlit < 32) - (nlit < 4096));
+        if (!hopeless) {
         huffCodesAndWeights(L, maxSym, tableLog);
         if (wave == 0) { const uint32_t hs_ = writeHuffHeaderWave(L, payload + lhSize, cap - lhSize, maxSym, tableLog); if (lane == 0) L.misc[0] = hs_; }
         __syncthreads();
@@ -1040,10 +1063,10 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
         if (ZS_STOP_AT(3)) FINISH(0, 0, 0);    // stop after codes + table description
         if (hsz) {
             const uint32_t seg = (nlit + 3) / 4;
-            if (single) { if (wave == 0) { const uint32_t z = huffEncodeStream(L, L.u.tile[0], streams, lits, 0, nlit); if (lane == 0) L.misc[8] = z; } }
+            if (single) { if (wave == 0) { const uint32_t z = huffEncodeStream(L, L.u.tile[0], streams, litp, 0, nlit); if (lane == 0) L.misc[8] = z; } }
             else {
                 const uint32_t len = (wave < 3) ? seg : nlit - 3 * seg;
-                const uint32_t z = huffEncodeStream(L, L.u.tile[wave], streams + wave * ZS_STREAM_STRIDE, lits, wave * seg, len);
+                const uint32_t z = huffEncodeStream(L, L.u.tile[wave], streams + wave * ZS_STREAM_STRIDE, litp, wave * seg, len);
                 if (lane == 0) L.misc[8 + wave] = z;
             }
             __syncthreads();
@@ -1071,6 +1094,7 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
                 done = true;
             }
         }
+        }
     }
     if (!done) {
         const uint32_t lh = 1 + (nlit > 31) + (nlit > 4095);
@@ -1079,7 +1103,7 @@ k_encode_literals(const uint8_t *__restrict__ src, const ZsBlockDesc *__restrict
             else if (lh == 2) { const uint32_t h = (1 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); }
             else { const uint32_t h = (3 << 2) + (nlit << 4); payload[0] = (uint8_t)h; payload[1] = (uint8_t)(h >> 8); payload[2] = (uint8_t)(h >> 16); }
         }
-        zs_block_copy(payload + lh, lits, nlit, tid, 256);
+        zs_block_copy(payload + lh, litp, nlit, tid, 256);
         litSecSize = lh + nlit;
     }
     FINISH(2, litSecSize, 0);
