@@ -29,4 +29,6 @@ m = buf.view(np.uint32).reshape(n, 8)
 fails = m[:, 6] & 0xFFFF; rounds = m[:, 6] >> 16      # (fails: not counted by the kernel - lane 0's ballot; rounds of repair are)
 K = m[:, 7] & 0xFF; Sb = (m[:, 7] >> 8) & 0xFF; ns = m[:, 7] >> 16
 print(cls, "blocks", n, "K", np.bincount(K), "Sb mean", Sb.mean(), "nseq mean", ns.mean())
+print("repair rounds histogram:", np.bincount(rounds, minlength=22).tolist())
+print("nseq of blocks with >= 8 rounds:", np.sort(ns[rounds >= 8])[::max(1, int((rounds >= 8).sum()) // 12)].tolist())
 print("failed seams per block: mean %.2f max %d; repair rounds mean %.2f max %d; blocks with none: %d" % (fails.mean(), fails.max(), rounds.mean(), rounds.max(), (fails == 0).sum()))
