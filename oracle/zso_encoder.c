@@ -54,7 +54,9 @@ typedef uint64_t U64;
 #define UNIT_MAX    131072u         /* bytes per LZ unit (match window): two blocks */
 #define WALK_LOG_MIN 8              /* the walk cuts a block in ranges of 256 bytes (level >= 3) or 512 bytes (level <= 2) */
 #define OUT_LOG     10              /* the ranges are handed on in groups of 1 KiB (the HIP walk kernel's output layout) */
+#ifndef CROSS_MAX
 #define CROSS_MAX   1024u           /* a match may pass its range's end by this much (and never the block's end) */
+#endif
 #define MINMATCH    5               /* shortest match kept; a recent-offset match may be 4 */
 #define MAX_TABLE_LOG 14
 #define HUF_MAXBITS 11

@@ -12,7 +12,9 @@
 #define ZS_OUT_LOG     10         // the walk kernel hands the sequences on in output ranges of 1 KiB
 #define ZS_WALK_RANGES 64u        // output ranges per block
 #define ZS_RES_PER_BLOCK 256u     // walk-range results per block (ranges of >= 256 bytes)
+#ifndef ZS_CROSS_MAX
 #define ZS_CROSS_MAX   1024u      // a match may pass its walk range's end by this much (never the block's end)
+#endif
 #define ZS_MATCHLESS_SHIFT 11      // a unit with fewer than n >> 11 candidate positions is not parsed (oracle: MATCHLESS_SHIFT)
 #define ZS_MINMATCH    5u         // shortest match kept
 #define ZS_REPMIN      4u         // shortest match at one of the walker's two recent offsets
