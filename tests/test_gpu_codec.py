@@ -552,6 +552,16 @@ def _matchless_inputs():
                 c[b:b + 24] = c[a:a + 24]
             out["noise_%d_%d" % (size, plants)] = bytes(c)
     out["skewed_65536"] = np.minimum(rng.geometric(0.05, 65536), 255).astype(np.uint8).tobytes()
+    # the literals kernel's short cuts around the Huffman build, on both sides of their tests: almost flat counts (the most frequent value just under /
+    # over twice the rarest), noise over 200 values and a few rare ones (no flat counts, but code bits >= literal count), over 128 values (7 bits: pays),
+    # and noise behind the last byte of the source buffer's block (literals read in place: no bytes behind the block may be touched)
+    for name, top in (("nearly_flat_under", 1.9), ("nearly_flat_over", 2.3)):
+        cnt = np.full(256, 200); cnt[7] = int(200 * top); v = np.repeat(np.arange(256, dtype=np.uint8), cnt)
+        out[name] = rng.permutation(v)[:65536].tobytes() if len(v) >= 65536 else rng.permutation(np.concatenate([v, rng.integers(0, 256, 65536 - len(v), dtype=np.uint8)])).tobytes()
+    a = rng.integers(0, 200, 65536, dtype=np.uint8); a[rng.integers(0, 65536, 40)] = rng.integers(200, 256, 40, dtype=np.uint8); out["noise_200_values"] = a.tobytes()
+    out["noise_128_values"] = rng.integers(0, 128, 65536, dtype=np.uint8).tobytes()
+    for size in (65, 300, 1023, 4099, 16385, 65533):
+        out["noise_tail_%d" % size] = rng.integers(0, 256, size, dtype=np.uint8).tobytes()
     out["noise_then_text"] = rng.integers(0, 256, 65536, dtype=np.uint8).tobytes() + text[:65536]
     out["text_then_noise"] = text[:50000] + rng.integers(0, 256, 81072, dtype=np.uint8).tobytes()
     return out
