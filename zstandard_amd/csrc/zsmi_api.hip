@@ -284,12 +284,15 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
     const bool useLong = level >= 3;
     const int walkLog = level <= 2 ? 9 : 8;
     // plan: chunks -> blocks.  The device-side plan is reused when the chunk layout repeats (steady-state batches).
-    std::vector<uint64_t> key((size_t)n * 3 + 1);
-    key[0] = n;
-    for (uint32_t i = 0; i < n; i++) { key[1 + i] = srcOffsets[i]; key[1 + n + i] = dstOffsets[i]; key[1 + 2 * (size_t)n + i] = srcSizes[i]; }
+    // (compared in place: a call of a repeating layout allocates and copies nothing)
+    bool samePlan = c->planKey.size() == (size_t)n * 3 + 1 && c->planKey[0] == n;
+    for (uint32_t i = 0; samePlan && i < n; i++) samePlan = c->planKey[1 + i] == srcOffsets[i] && c->planKey[1 + n + i] == dstOffsets[i] && c->planKey[1 + 2 * (size_t)n + i] == srcSizes[i];
     uint64_t nBlocks; uint32_t maxChunkBlocks;
-    if (key == c->planKey) { nBlocks = c->planBlocks; maxChunkBlocks = c->planMaxChunkBlocks; }
+    if (samePlan) { nBlocks = c->planBlocks; maxChunkBlocks = c->planMaxChunkBlocks; }
     else {
+        std::vector<uint64_t> key((size_t)n * 3 + 1);
+        key[0] = n;
+        for (uint32_t i = 0; i < n; i++) { key[1 + i] = srcOffsets[i]; key[1 + n + i] = dstOffsets[i]; key[1 + 2 * (size_t)n + i] = srcSizes[i]; }
         nBlocks = 0;
         for (uint32_t i = 0; i < n; i++) nBlocks += srcSizes[i] ? (srcSizes[i] + ZS_BLOCK_MAX - 1) / ZS_BLOCK_MAX : 1;
         if (nBlocks > 0x7FFFFFFFull) return ZSMI_error_srcSize_wrong;
@@ -347,8 +350,14 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
             !L.dStreams.reserve((size_t)cap * 4 * ZS_STREAM_STRIDE) || !L.dLitSec.reserve((size_t)cap * ZS_LITSEC_STRIDE) ||
             !L.dSeqSec.reserve((size_t)cap * ZS_SEQSEC_STRIDE) || !L.dMetas.reserve((size_t)cap * sizeof(ZsBlockMeta))) return ZSMI_error_memory_allocation;
     }
-    if (hipEventRecord(c->evStart, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
-    for (int i = 0; i < nLanes; i++) if (hipStreamWaitEvent(c->lanes[i].stream, c->evStart, 0) != hipSuccess) return ZSMI_error_GENERIC;
+    // One lane (the default): its kernels go to the caller's stream itself.  (Through a stream of the lane's own - an event from the caller's
+    // stream in front, one back behind - every call crossed from one hardware queue to another twice: ~0.01 ms a crossing on most boxes of
+    // the pool, ~0.09 on some - a bench line of 126 GiB/s where the same binary's kernels added up to 137.)
+    const bool direct = nLanes == 1;
+    if (!direct) {
+        if (hipEventRecord(c->evStart, c->stream) != hipSuccess) return ZSMI_error_GENERIC;
+        for (int i = 0; i < nLanes; i++) if (hipStreamWaitEvent(c->lanes[i].stream, c->evStart, 0) != hipSuccess) return ZSMI_error_GENERIC;
+    }
     uint32_t chunk0 = 0; int turn = 0;
     while (chunk0 < n) {
         uint32_t chunk1 = chunk0, nb = 0;
@@ -356,7 +365,7 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
         const uint32_t block0 = hc[chunk0].firstBlock;
         const ZsBlockDesc *dB = (const ZsBlockDesc *)c->dBlocks.p + block0;
         zsmi_ctx::Scratch &L = c->lanes[turn % nLanes]; turn++;
-        hipStream_t st = L.stream;
+        hipStream_t st = direct ? c->stream : L.stream;
         // match search per LZ unit: small units (one block) and big units (two blocks) have their own kernel shapes
         const uint32_t s0 = c->smallBefore[chunk0], ns = c->smallBefore[chunk1] - s0, b0 = c->bigBefore[chunk0], nbig = c->bigBefore[chunk1] - b0;
         const ZsUnitDesc *dUS = (const ZsUnitDesc *)c->dUnits.p + s0, *dUB = (const ZsUnitDesc *)c->dUnits.p + c->planSmall + b0;
@@ -384,7 +393,7 @@ extern "C" int zsmi_compressBatchDevice(zsmi_ctx *c, const void *dSrc, const uin
                       (const ZsBlockDesc *)c->dBlocks.p, (const ZsBlockMeta *)L.dMetas.p, (const uint8_t *)L.dLitSec.p, (const uint8_t *)L.dSeqSec.p, block0, (uint8_t *)dDst, dDstSizes, chunk0);
         chunk0 = chunk1;
     }
-    for (int i = 0; i < nLanes; i++) {
+    for (int i = 0; !direct && i < nLanes; i++) {
         if (hipEventRecord(c->lanes[i].done, c->lanes[i].stream) != hipSuccess) return ZSMI_error_GENERIC;
         if (hipStreamWaitEvent(c->stream, c->lanes[i].done, 0) != hipSuccess) return ZSMI_error_GENERIC;
     }
