@@ -63,3 +63,8 @@ cp $(ls gpurun_out/prof_${tag}_dec/*/*_kernel_stats.csv | head -1) gpurun_out/${
 # 128 KiB chunks and level 1 (BASELINE configs 3 and 5 shapes)
 timeout -k 5 240 python bench.py --chunks 2048 --chunk-size 131072 --no-cpu-baseline --no-extras --decode-frames 0 > gpurun_out/${tag}_bench_128k.json 2>/dev/null || true
 timeout -k 5 240 python bench.py --chunks 2048 --chunk-size 131072 --level 1 --no-cpu-baseline --no-extras --decode-frames 0 > gpurun_out/${tag}_bench_128k_l1.json 2>/dev/null || true
+# last: the bench line once more with this run's traffic files in place (bench.py reports roofline.traffic only from files measured at the
+# built library's sources), so that the committed line carries it
+round=${tag%%_*}
+cp gpurun_out/${tag}_traffic.json profiles/${round}_traffic.json && cp gpurun_out/${tag}_decode_traffic.json profiles/${round}_decode_traffic.json
+timeout -k 5 900 python bench.py > gpurun_out/${tag}_bench.json 2> gpurun_out/${tag}_bench.err || exit 1
