@@ -19,6 +19,12 @@ def content(rng, total):
     parts.append(rng.choice(np.array([65, 66, 67, 10], dtype=np.uint8), total // 8, p=[0.7, 0.2, 0.05, 0.05]))   # skewed
     pz = 1.0 / np.arange(1, 257) ** 1.1
     parts.append(rng.choice(256, total // 8, p=pz / pz.sum()).astype(np.uint8))          # long tail of rare symbols: 10- and 11-bit Huffman codes
+    if os.environ.get("FUZZ_CORPUS"):                                                     # pieces of the mixed corpus' binary / run-heavy classes
+        import _corpus as C
+        for name in ("elf", "repetitive", "bintable", "hipso"):
+            one = np.frombuffer(C.CLASSES[name](4 << 20), dtype=np.uint8)
+            a = int(rng.integers(0, len(one) - total // 8)) if len(one) > total // 8 else 0
+            parts.append(one[a:a + total // 8])
     return np.concatenate(parts)
 
 def sizes_for(rng, n):
@@ -32,7 +38,7 @@ def main():
     bc = BatchCodec(0)
     bad = 0
     for rd in range(rounds):
-        rng = np.random.default_rng(1000 + rd)
+        rng = np.random.default_rng(int(os.environ.get("FUZZ_SEED", "1000")) + rd)
         n = int(rng.integers(50, 400))
         sizes = sizes_for(rng, n)
         data = content(rng, int(sizes.sum()) + 400000)
