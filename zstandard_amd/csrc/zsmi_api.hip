@@ -146,7 +146,9 @@ struct zsmi_ctx {
     PinBuf hItems2[2]; hipEvent_t hItemsEv[2] = { nullptr, nullptr }; bool hItemsBusy[2] = { false, false }; uint32_t decodeCalls = 0;    // the decode item list: two pinned buffers taken in turn
     DevBuf dPoolLit;                         // the general decode kernel's literal buffers: one per wavefront of its pool
     uint32_t seqLog9Group = 0;               // experiment: force the 2.5 KiB sequence-table class to 16 or 4 items a wavefront (ZSMI_SEQ_LOG9_G; 0: the heuristic)
-    uint32_t decodeFuseBelow = 24576;        // (item, block) pairs of a call up to which the entropy kernels are one launch (ZSMI_DEC_FUSE_BELOW; 0: never)
+    uint32_t decodeFuseBelow = 0;            // ZSMI_DEC_FUSE_BELOW given: (item, block) pairs of a call up to which the entropy kernels are one launch (0: never) - instead of the rule below
+    bool decodeFuseSet = false;
+    uint32_t cus = 256;                      // compute units of the device (rounds of workgroups a launch takes)
     uint32_t decodePool = 3072;              // wavefronts of that pool (ZSMI_DEC_POOL): the chip holds 10 a CU x 256
     size_t lastDecodeScratch = 0;            // bytes of scratch the last decode call needed (INTEGRATION.md states them)
     // staging for host-buffer calls
@@ -202,7 +204,8 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     if (const char *e = getenv("ZSMI_BLOCKS_IN_FLIGHT")) { long v = atol(e); if (v >= 64) c->maxBlocksInFlight = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_DEC_FAST")) c->decodeFast = atoi(e) != 0;
     if (const char *e = getenv("ZSMI_SEQ_LOG9_G")) c->seqLog9Group = (uint32_t)atol(e);
-    if (const char *e = getenv("ZSMI_DEC_FUSE_BELOW")) c->decodeFuseBelow = (uint32_t)atol(e);
+    if (const char *e = getenv("ZSMI_DEC_FUSE_BELOW")) { c->decodeFuseBelow = (uint32_t)atol(e); c->decodeFuseSet = true; }
+    { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0) c->cus = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_DEC_POOL")) { long v = atol(e); if (v >= 2 && v <= (1 << 20)) c->decodePool = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_ITEMS_IN_FLIGHT")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->maxItemsInFlight = (uint32_t)v; }
 #ifdef ZSMI_DEBUG_HOOKS
@@ -492,7 +495,14 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
             {   // every block index of the items in one launch per kernel class (the grid: maxBlocks runs of the items' groups; a wavefront whose items
                 // have no such block leaves at once)
                 const uint32_t mb = maxBlocks, vcnt = cnt * mb;                 // (item, block) pairs: what a launch's rounds of workgroups count
-                if (vcnt <= c->decodeFuseBelow && mb == 1) {
+                // One launch for the four entropy kernels, or one each?  Both are rounds of workgroups of an item's chain each: fused, a CU holds 4 workgroups of
+                // the 37 KiB image and a round is 2 CUs' worth of Huffman AND sequence groups (8192 items on 256 CUs, ~0.48 ms); apart, 5 workgroups of 30 KiB and
+                // a round of each kind is 20480 items (~0.55 ms, twice).  The fewer round-milliseconds win - measured over 8192 .. 65536 frames of 32 KiB: fused
+                // below 20480 items except right at it, at 22528 .. 32768 (4.42 against 4.64 ms at 28672) and 49152; apart at 20480, 36864 .. 45056, 53248 .. 61440.
+                bool fuse;
+                if (c->decodeFuseSet) fuse = vcnt <= c->decodeFuseBelow;
+                else { const uint32_t perF = 32u * c->cus, perS = 80u * c->cus; fuse = ((vcnt + perF - 1) / perF) * 48u < 2u * ((vcnt + perS - 1) / perS) * 55u; }
+                if (fuse && mb == 1) {
                     // a round of workgroups or less of one-block items: the four entropy launches as one (k_dec_entropy), the 2.5 KiB sequence class at 4 items a wavefront as below
                     // (items of several blocks - 128 KiB frames: 64 KiB blocks, the 2.5 KiB table class at 16 a wavefront - keep the separate launches: 8192 two-block frames of text
                     //  decoded at 100 GiB/s fused against 135 apart)
