@@ -617,6 +617,22 @@ def test_runs_of_one_byte_are_parsed_as_in_the_oracle(codec, level):
         assert O.decompress(f, len(inputs[k])) == inputs[k], k
 
 
+def test_decode_calls_on_both_sides_of_the_launch_shape_rules(codec):
+    """the decoder picks its launch shapes by the call's size (zsmi_api.hip): the entropy stage as one launch or one per kernel by the rounds of workgroups
+    either takes, the execute kernel at 8 wavefronts a SIMD where that makes one round of two (7169 .. 8192 items on 256 CUs).  Calls of 7100, 7600, 8192 and
+    8300 small frames (and 20480 / 22528: apart / fused) must all restore their chunks; mixed content so every kernel has work."""
+    log = D.zipf_log(9000 * 1500 + 4096, seed_lo=91).tobytes()
+    rng = np.random.default_rng(77)
+    for n in (7100, 7600, 8192, 8300, 20480, 22528):
+        sizes = rng.integers(600, 1500, n)
+        starts = rng.integers(0, len(log) - 1500, n)
+        chunks = [log[int(a):int(a) + int(z)] for a, z in zip(starts, sizes)]
+        frames = _compress_many(codec, chunks, 3)
+        got = _decompress_many(codec, frames, [len(c) for c in chunks])
+        bad = [i for i, ((sz, data), c) in enumerate(zip(got, chunks)) if sz != len(c) or data != c]
+        assert not bad, (n, bad[:5])
+
+
 def test_decode_wide_alphabets_flat_huffman_table(codec):
     """literals over all 256 byte values with a long tail of rare ones: more 9-bit prefixes hold 10 / 11-bit codes than the fast path's two-level
     Huffman table has sub-tables, so k_dec_prep emits the flat 2^11 table and k_dec_huffman's flat class decodes them (before round 3's end such

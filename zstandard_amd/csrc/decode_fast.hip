@@ -768,7 +768,8 @@ k_dec_entropy(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ 
 // ---------------------------------------------------------------------------------------------------------------------
 #define ZS_EXEC_WINDOW 32768u           // output bytes whose literal bits a wavefront holds in LDS at a time
 // wavefronts per SIMD the kernel is compiled for: 6 = 80 VGPRs (9 spilled), 7 = 72 (more spills).  Per 57344 frames of 32 KiB: 5: 3.79 ms, 6: 3.57,
-// 7: 3.41, 8: 3.65; per 16384 frames of 128 KiB: 6: 5.42, 7: 5.57 - so a call of one-block items takes the 7 form, any other the 6 form (MW)
+// 7: 3.41, 8: 3.65; per 16384 frames of 128 KiB: 6: 5.42, 7: 5.57 - so a call of one-block items takes the 7 form, any other the 6 form (MW); the 8 form (64 VGPRs) only
+// where it turns two rounds of wavefronts into one (zsmi_api.hip)
 template <int F, int MW>
 __global__ void __launch_bounds__(64 * F, MW)
 k_dec_execute(const uint8_t *__restrict__ srcAll, const ZsDecItem *__restrict__ items, uint32_t nItems, ZsFastDesc *__restrict__ descs,

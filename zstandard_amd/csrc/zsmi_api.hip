@@ -148,6 +148,7 @@ struct zsmi_ctx {
     uint32_t seqLog9Group = 0;               // experiment: force the 2.5 KiB sequence-table class to 16 or 4 items a wavefront (ZSMI_SEQ_LOG9_G; 0: the heuristic)
     uint32_t decodeFuseBelow = 0;            // ZSMI_DEC_FUSE_BELOW given: (item, block) pairs of a call up to which the entropy kernels are one launch (0: never) - instead of the rule below
     bool decodeFuseSet = false;
+    int execWaves = 0;                       // ZSMI_EXEC_WAVES=7 / 8: force the execute kernel's form for one-block items (0: by the call's size, below)
     uint32_t cus = 256;                      // compute units of the device (rounds of workgroups a launch takes)
     uint32_t decodePool = 3072;              // wavefronts of that pool (ZSMI_DEC_POOL): the chip holds 10 a CU x 256
     size_t lastDecodeScratch = 0;            // bytes of scratch the last decode call needed (INTEGRATION.md states them)
@@ -205,6 +206,7 @@ extern "C" zsmi_ctx *zsmi_createCtx(int device, void *hipStream)
     if (const char *e = getenv("ZSMI_DEC_FAST")) c->decodeFast = atoi(e) != 0;
     if (const char *e = getenv("ZSMI_SEQ_LOG9_G")) c->seqLog9Group = (uint32_t)atol(e);
     if (const char *e = getenv("ZSMI_DEC_FUSE_BELOW")) { c->decodeFuseBelow = (uint32_t)atol(e); c->decodeFuseSet = true; }
+    if (const char *e = getenv("ZSMI_EXEC_WAVES")) c->execWaves = atoi(e);
     { int v = 0; if (hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, c->device) == hipSuccess && v > 0) c->cus = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_DEC_POOL")) { long v = atol(e); if (v >= 2 && v <= (1 << 20)) c->decodePool = (uint32_t)v; }
     if (const char *e = getenv("ZSMI_ITEMS_IN_FLIGHT")) { long v = atol(e); if (v >= 64 && v <= (1 << 20)) c->maxItemsInFlight = (uint32_t)v; }
@@ -523,7 +525,14 @@ static int decompressBatchDeviceImpl(zsmi_ctx *c, const void *dSrc, const uint64
                     LAUNCH(c, "k_dec_sequences", (k_dec_sequences<true, 4u>), dim3(((cnt + 3) / 4) * mb), dim3(64), 0, (const uint8_t *)dSrc, dI, cnt, dD, (const uint8_t *)c->dSeqTabs.p, (ZsFastSeq *)c->dSeqOut.p, mb, cap, (const uint32_t *)dLists, seqCap, 0u, many);
                 }
             }
-            if (maxBlocks == 1)
+            // one-block items: 7 wavefronts a SIMD (decode_fast.hip) - but a call that fits ONE round of wavefronts at 8 a SIMD and not at 7 (7169 .. 8192 items on 256 CUs)
+            // takes the 8 form: a round of it is ~12 % longer (64 VGPRs: more spills), one round instead of two is not (8192 frames: execute 0.67 -> 0.59 ms; at every
+            // other size measured, 4096 .. 57344, the 7 form is as fast or faster)
+            const bool oneRoundAt8 = cnt > 7u * 4u * c->cus && cnt <= 8u * 4u * c->cus;
+            if (maxBlocks == 1 && (c->execWaves == 8 || (c->execWaves == 0 && oneRoundAt8)))
+                LAUNCH(c, "k_dec_execute", (k_dec_execute<4, 8>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (ZsFastSeq *)c->dSeqOut.p,
+                       (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap, descSlots, litStride, seqCap);
+            else if (maxBlocks == 1)
                 LAUNCH(c, "k_dec_execute", (k_dec_execute<4, 7>), dim3((cnt + 3) / 4), dim3(256), 0, (const uint8_t *)dSrc, dI, cnt, dD, (ZsFastSeq *)c->dSeqOut.p,
                        (uint8_t *)c->dLitScratch.p, (uint8_t *)dDst, dDstSizes + i0, cap, descSlots, litStride, seqCap);
             else
